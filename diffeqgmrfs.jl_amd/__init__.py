@@ -1,0 +1,21 @@
+"""diffeqgmrfs.jl_amd -- MI355X-native block-tridiagonal GMRF factor/solve/sample path.
+
+The directory name carries a dot (it mirrors the reference's name, DiffEqGMRFs.jl), so it
+cannot be imported with a plain `import`; use `__graft_entry__.load_package()` (or
+`importlib` with an alias), which registers it as `diffeqgmrfs_jl_amd`.
+
+Layout:
+    csrc/           hand-written HIP kernels + the C ABI (libgmrf_hip.so, include/gmrf_hip.h)
+    _cabi.py        ctypes binding of the C ABI
+    api.py          host mirror of the reference's operator surface (tridiagonal_cholesky, ldiv, ...)
+    posterior.py    posterior mean / samples / variances and their sharding across ranks
+    workloads.py    synthetic FEM precision matrices for the BASELINE configs (inputs only)
+"""
+from . import _cabi, api, workloads  # noqa: F401
+from .api import (CsrMatrix, GmrfError, NotPositiveDefinite, TridiagonalCholeskyFactor,  # noqa: F401
+                  backward_solve, extract_blocks, forward_solve, ldiv, ldiv_, logdet, make_chunks,
+                  tridiagonal_cholesky)
+
+__all__ = ["TridiagonalCholeskyFactor", "tridiagonal_cholesky", "forward_solve", "backward_solve",
+           "ldiv", "ldiv_", "make_chunks", "extract_blocks", "logdet", "CsrMatrix", "GmrfError",
+           "NotPositiveDefinite", "workloads", "api"]

@@ -1,0 +1,397 @@
+"""Host-side mirror of the reference's operator surface for the block-tridiagonal path.
+
+Same names, argument meaning and error behaviour as
+/root/reference/src/tridiagonal_cholesky.jl (`tridiagonal_cholesky` :65-82,
+`forward_solve` :43-52, `backward_solve` :24-33, `ldiv!`/`ldiv` :54-63, `make_chunks`
+:11-14, struct fields `N`, `chos`, `Cs` :5-9) and scripts/solve_burger.jl:182-254
+(`extract_blocks`), with every numeric step done by libgmrf_hip.so on the GPU.  Julia is not
+available in this image, so this Python layer stands where the Julia shim
+(julia/DiffEqGMRFsHIP.jl) stands in a Julia session; both are thin wrappers over the same
+C ABI (include/gmrf_hip.h).
+
+Vectors / matrices may be NumPy arrays (host) or torch CUDA tensors (device resident; no
+PCIe traffic).  Matrices of right-hand sides are n x k in column-major order (Julia
+layout): pass `np.asfortranarray(B)` or a torch tensor of shape (k, n) via `.T`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _cabi
+from ._cabi import GmrfError, NotPositiveDefinite  # noqa: F401  (re-exported)
+
+
+def _is_torch(x) -> bool:
+    return hasattr(x, "data_ptr") and hasattr(x, "device")
+
+
+def _colmajor(b, n: int):
+    """Return (array_or_tensor, k, ld, was_1d) with column-major n x k storage."""
+    if _is_torch(b):
+        import torch
+        if b.dtype != torch.float64:
+            raise TypeError("float64 required")
+        if b.dim() == 1:
+            if b.shape[0] != n:
+                raise ValueError("dimension mismatch")
+            return b.contiguous(), 1, n, True
+        # a (n, k) tensor whose transpose is contiguous is column-major
+        if b.shape[0] != n:
+            raise ValueError("dimension mismatch")
+        bt = b.t()
+        if not bt.is_contiguous():
+            bt = bt.contiguous()
+        return bt, b.shape[1], n, False          # bt is (k, n) row-major == n x k column-major
+    a = np.asarray(b, dtype=np.float64)
+    if a.ndim == 1:
+        if a.shape[0] != n:
+            raise ValueError("dimension mismatch")
+        return np.ascontiguousarray(a), 1, n, True
+    if a.shape[0] != n:
+        raise ValueError("dimension mismatch")
+    return np.asfortranarray(a), a.shape[1], n, False
+
+
+def _alloc_like(ref, n: int, k: int, one_d: bool):
+    if _is_torch(ref):
+        import torch
+        out = torch.empty((k, n), dtype=torch.float64, device=ref.device)
+        return out, (out[0] if one_d else out.t())
+    out = np.empty((n, k), dtype=np.float64, order="F")
+    return out, (out[:, 0] if one_d else out)
+
+
+class CsrMatrix:
+    """Device-resident sparse matrix for `Q * x` (K6).  For a symmetric matrix the CSC arrays
+    of a SparseMatrixCSC are the CSR arrays of the same matrix."""
+
+    def __init__(self, A, device: int = 0, values_f32: bool = False, stream: int = 0):
+        A = sp.csr_matrix(A)
+        A.sort_indices()
+        self.shape = A.shape
+        self.nnz = int(A.nnz)
+        self._h = C.c_void_p()
+        rp = A.indptr.astype(np.int64)
+        ci = A.indices.astype(np.int64)
+        v = A.data.astype(np.float64)
+        lib = _cabi.load()
+        _cabi.check(lib.gmrf_csr_create(device, C.c_void_p(stream), A.shape[0], A.shape[1], _cabi.ptr(rp),
+                                        _cabi.ptr(ci), _cabi.ptr(v), 0, int(values_f32), C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _cabi.load().gmrf_csr_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def __matmul__(self, X):
+        return self.matmul(X)
+
+    def matmul(self, X):
+        n = self.shape[1]
+        xa, k, ld, one_d = _colmajor(X, n)
+        store, view = _alloc_like(xa, self.shape[0], k, one_d)
+        _cabi.check(_cabi.load().gmrf_spmm(self._h, _cabi.ptr(xa), _cabi.ptr(store), k, ld, self.shape[0]))
+        return view
+
+
+class _LazyBlocks(Sequence):
+    """`F.chos` / `F.Cs`: dense blocks copied from the device on access."""
+
+    def __init__(self, owner: "TridiagonalCholeskyFactor", kind: int, count: int):
+        self._o, self._kind, self._count = owner, kind, count
+
+    def __len__(self):
+        return self._count
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self._count))]
+        if i < 0:
+            i += self._count
+        if not 0 <= i < self._count:
+            raise IndexError(i)
+        return self._o.get_block(self._kind, i)
+
+
+class TridiagonalCholeskyFactor:
+    """Handle wrapper of the device-resident factor (struct at src/tridiagonal_cholesky.jl:5-9).
+
+    `N` is the total size n (as in the reference, NOT the block count); `chos[i]` is the
+    lower-triangular L_i, `Cs[i]` = L_{i+1,i}.
+    """
+
+    def __init__(self, device: int = 0, stream: int = 0):
+        self._h = C.c_void_p()
+        self._lib = _cabi.load()
+        _cabi.check(self._lib.gmrf_bt_create(device, C.c_void_p(stream), C.byref(self._h)))
+        self.N = 0
+        self.n_blocks = 0
+        self.block_size = 0
+        self.device = device
+        self._pattern = None
+
+    # -- life cycle
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gmrf_bt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- factorisation
+    def factor(self, A, N_blocks: int):
+        A = sp.csc_matrix(A)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("matrix must be square")
+        if not A.has_sorted_indices:
+            A = A.copy()
+            A.sort_indices()
+        n = A.shape[0]
+        colptr = A.indptr.astype(np.int64)
+        rowval = A.indices.astype(np.int64)
+        nz = np.ascontiguousarray(A.data, dtype=np.float64)
+        info = C.c_int32(0)
+        st = self._lib.gmrf_bt_factor_csc(self._h, n, int(N_blocks), _cabi.ptr(colptr), _cabi.ptr(rowval),
+                                          _cabi.ptr(nz), 0, C.byref(info))
+        _cabi.check(st, info.value)
+        self._set_shape(n, int(N_blocks))
+        self._pattern = (colptr, rowval)
+        return self
+
+    def factor_blocks(self, diag_blocks, off_diag_blocks):
+        """Factor from the output of `extract_blocks` (lists of sparse bs x bs blocks)."""
+        nb = len(diag_blocks)
+        bs = diag_blocks[0].shape[0]
+        keep = []
+
+        def mk(blocks):
+            arr = (_cabi.SparseBlock * max(len(blocks), 1))()
+            for i, b in enumerate(blocks):
+                b = sp.csc_matrix(b)
+                b.sort_indices()
+                p = b.indptr.astype(np.int64); ix = b.indices.astype(np.int64); v = b.data.astype(np.float64)
+                keep.extend([p, ix, v])
+                arr[i].nnz = b.nnz
+                arr[i].ptr = p.ctypes.data; arr[i].idx = ix.ctypes.data; arr[i].val = v.ctypes.data
+            return arr
+
+        d = mk(diag_blocks)
+        lo = mk(off_diag_blocks)
+        info = C.c_int32(0)
+        st = self._lib.gmrf_bt_factor_blocks(self._h, nb * bs, nb, C.cast(d, C.c_void_p), C.cast(lo, C.c_void_p),
+                                             0, 1, C.byref(info))
+        _cabi.check(st, info.value)
+        self._set_shape(nb * bs, nb)
+        return self
+
+    def refactor(self, nzval):
+        """New values on the sparsity pattern of the last `factor` (nzval in CSC order;
+        NumPy array or torch CUDA tensor)."""
+        info = C.c_int32(0)
+        if not _is_torch(nzval):
+            nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+        st = self._lib.gmrf_bt_refactor_values(self._h, _cabi.ptr(nzval), C.byref(info))
+        _cabi.check(st, info.value)
+        return self
+
+    def _set_shape(self, n, nb):
+        self.N = n
+        self.n_blocks = nb
+        self.block_size = n // nb
+        self.chos = _LazyBlocks(self, _cabi.BLOCK_L, nb)
+        self.Cs = _LazyBlocks(self, _cabi.BLOCK_C, nb - 1)
+        self.inverses = _LazyBlocks(self, _cabi.BLOCK_LINV, nb)
+
+    # -- solves
+    def _solve(self, b, mode: int, out=None):
+        xa, k, ld, one_d = _colmajor(b, self.N)
+        if out is None:
+            store, view = _alloc_like(xa, self.N, k, one_d)
+        else:
+            store, view = out, out
+        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(xa), _cabi.ptr(store), k, ld, mode))
+        return view
+
+    def get_block(self, kind: int, i: int) -> np.ndarray:
+        bs = self.block_size
+        out = np.empty((bs, bs), dtype=np.float64, order="F")
+        _cabi.check(self._lib.gmrf_bt_get_block(self._h, kind, i, _cabi.ptr(out), bs))
+        return out
+
+    def logdet(self) -> float:
+        v = C.c_double(0.0)
+        _cabi.check(self._lib.gmrf_bt_logdet(self._h, C.byref(v)))
+        return v.value
+
+    def normals(self, k: int, seed: int = 0x5EED, first_id: int = 0, like=None):
+        store, view = _alloc_like(like if like is not None else np.empty(0), self.N, k, False)
+        _cabi.check(self._lib.gmrf_bt_normals(self._h, seed, first_id, k, _cabi.ptr(store), self.N))
+        return view
+
+    def sample(self, k: int, mean=None, z=None, seed: int = 0x5EED, first_id: int = 0, like=None):
+        """k posterior samples mean + L^-T z as an n x k matrix (rand(rng, x_cond))."""
+        ref = like if like is not None else (z if z is not None else (mean if mean is not None else np.empty(0)))
+        za = None
+        if z is not None:
+            za, kz, _, _ = _colmajor(z, self.N)
+            k = kz
+        if mean is not None and not _is_torch(mean):
+            mean = np.ascontiguousarray(mean, dtype=np.float64)
+        store, view = _alloc_like(ref if _is_torch(ref) else np.empty(0), self.N, k, False)
+        _cabi.check(self._lib.gmrf_bt_sample(self._h, seed, first_id, k, _cabi.ptr(mean), _cabi.ptr(za),
+                                             _cabi.ptr(store), self.N))
+        return view
+
+    def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None):
+        m = {"exact": _cabi.VAR_EXACT, "rbmc": _cabi.VAR_RBMC, "mc": _cabi.VAR_MC}[method]
+        out = np.empty(self.N, dtype=np.float64)
+        _cabi.check(self._lib.gmrf_bt_marginal_var(self._h, m, k, seed, Q._h if Q is not None else None,
+                                                   _cabi.ptr(out)))
+        return out
+
+    def var_accumulate(self, acc, method: str, first_id: int, k: int, seed: int = 0x5EED,
+                       Q: Optional[CsrMatrix] = None):
+        m = {"rbmc": _cabi.VAR_RBMC, "mc": _cabi.VAR_MC}[method]
+        _cabi.check(self._lib.gmrf_bt_var_accumulate(self._h, m, first_id, k, seed,
+                                                     Q._h if Q is not None else None, _cabi.ptr(acc)))
+        return acc
+
+    def stats(self) -> dict:
+        s = _cabi.Stats()
+        _cabi.check(self._lib.gmrf_bt_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in s._fields_}
+
+    def set_profiling(self, level: int):
+        _cabi.check(self._lib.gmrf_bt_set_profiling(self._h, level))
+
+    def set_eager(self, eager: bool):
+        _cabi.check(self._lib.gmrf_bt_set_eager(self._h, int(eager)))
+
+    def synchronize(self):
+        _cabi.check(self._lib.gmrf_bt_synchronize(self._h))
+
+    def factor_buffer(self, kind: int) -> Tuple[int, int]:
+        p = C.c_void_p()
+        nbytes = C.c_int64(0)
+        _cabi.check(self._lib.gmrf_bt_factor_buffer(self._h, kind, C.byref(p), C.byref(nbytes)))
+        return int(p.value or 0), int(nbytes.value)
+
+    def adopt_shape(self, n: int, n_blocks: int):
+        _cabi.check(self._lib.gmrf_bt_adopt_shape(self._h, n, n_blocks))
+        self._set_shape(n, n_blocks)
+
+    def adopt_commit(self):
+        _cabi.check(self._lib.gmrf_bt_adopt_commit(self._h))
+
+    def factor_begin(self, A, N_blocks: int):
+        A = sp.csc_matrix(A)
+        n = A.shape[0]
+        colptr = A.indptr.astype(np.int64); rowval = A.indices.astype(np.int64)
+        nz = np.ascontiguousarray(A.data, dtype=np.float64)
+        _cabi.check(self._lib.gmrf_bt_factor_begin_csc(self._h, n, int(N_blocks), _cabi.ptr(colptr),
+                                                       _cabi.ptr(rowval), _cabi.ptr(nz), 0))
+        self._set_shape(n, int(N_blocks))
+
+    def factor_begin_values(self, nzval):
+        """Start a pipelined re-factorisation on the analysed pattern (nzval host or device)."""
+        if not _is_torch(nzval):
+            nzval = np.ascontiguousarray(nzval, dtype=np.float64)
+        _cabi.check(self._lib.gmrf_bt_factor_begin_csc(self._h, self.N, self.n_blocks, None, None,
+                                                       _cabi.ptr(nzval), 0))
+
+    def factor_step_async(self, i0: int, i1: int):
+        _cabi.check(self._lib.gmrf_bt_factor_step_async(self._h, i0, i1))
+
+    def factor_end(self):
+        info = C.c_int32(0)
+        st = self._lib.gmrf_bt_factor_end(self._h, C.byref(info))
+        _cabi.check(st, info.value)
+
+
+# ----------------------------------------------------------------------------- reference surface
+
+def tridiagonal_cholesky(A, N_blocks: int, device: int = 0, stream: int = 0) -> TridiagonalCholeskyFactor:
+    """tridiagonal_cholesky(A::SparseMatrixCSC, N_blocks)  (src/tridiagonal_cholesky.jl:65-82).
+
+    Raises NotPositiveDefinite (PosDefException) with the failing block index, ValueError
+    when size(A,1) is not a multiple of N_blocks (the reference would silently mis-factor),
+    GmrfError(ERR_BAND) when entries lie outside the block tri-band (the reference silently
+    ignores them)."""
+    n = A.shape[0]
+    if N_blocks <= 0 or n % N_blocks != 0:
+        raise ValueError("size(A,1) must be a positive multiple of N_blocks")
+    return TridiagonalCholeskyFactor(device, stream).factor(A, N_blocks)
+
+
+def forward_solve(L: TridiagonalCholeskyFactor, b):
+    """y = L^-1 b  (src/tridiagonal_cholesky.jl:43-52); returns the flat vector/matrix."""
+    return L._solve(b, _cabi.SOLVE_FORWARD)
+
+
+def backward_solve(L: TridiagonalCholeskyFactor, b):
+    """x = L^-T b  (src/tridiagonal_cholesky.jl:24-33)."""
+    return L._solve(b, _cabi.SOLVE_BACKWARD)
+
+
+def ldiv(L: TridiagonalCholeskyFactor, b):
+    """ldiv(L, b) = A^-1 b  (src/tridiagonal_cholesky.jl:60-63)."""
+    return L._solve(b, _cabi.SOLVE_FULL)
+
+
+def ldiv_(y, L: TridiagonalCholeskyFactor, b):
+    """ldiv!(y, L, b)  (src/tridiagonal_cholesky.jl:54-58): result written into y, which is
+    returned.  y may alias b."""
+    res = L._solve(b, _cabi.SOLVE_FULL)
+    if _is_torch(y):
+        y.copy_(res)
+    else:
+        y[...] = res
+    return y
+
+
+def make_chunks(X, n: int):
+    """src/tridiagonal_cholesky.jl:11-14: n contiguous views, the last takes the remainder."""
+    c = X.shape[0] // n
+    return [X[c * k:(X.shape[0] if k == n - 1 else c * k + c)] for k in range(n)]
+
+
+def extract_blocks(I, J, V, block_size: int):
+    """scripts/solve_burger.jl:182-254 on 1-based COO triplets: (diag_blocks, off_diag_blocks),
+    the lower off-diagonal convention, entries outside the tri-band dropped as the reference
+    does.  Vectorised host code (no per-entry Python loop)."""
+    I = np.asarray(I, dtype=np.int64) - 1
+    J = np.asarray(J, dtype=np.int64) - 1
+    V = np.asarray(V)
+    if I.size == 0:
+        return [], []
+    bi, bj = I // block_size, J // block_size
+    nb = int(bi.max()) + 1
+    diag, off = [], []
+    is_d = bi == bj
+    is_o = bi == bj + 1
+    order_d = np.flatnonzero(is_d)
+    order_o = np.flatnonzero(is_o)
+    for b in range(nb):
+        sel = order_d[bi[order_d] == b]
+        diag.append(sp.coo_matrix((V[sel], (I[sel] - b * block_size, J[sel] - b * block_size)),
+                                  shape=(block_size, block_size)).tocsc())
+        if b > 0:
+            sel = order_o[bi[order_o] == b]
+            off.append(sp.coo_matrix((V[sel], (I[sel] - b * block_size, J[sel] - (b - 1) * block_size)),
+                                     shape=(block_size, block_size)).tocsc())
+    return diag, off
+
+
+def logdet(L: TridiagonalCholeskyFactor) -> float:
+    return L.logdet()

@@ -1,0 +1,1263 @@
+// libgmrf_hip.so -- C ABI (include/gmrf_hip.h) over the gfx950 kernels of this directory.
+//
+// Host orchestration of the block-tridiagonal Cholesky path of DiffEqGMRFs.jl
+// (/root/reference/src/tridiagonal_cholesky.jl): symbolic analysis of the CSC matrix into
+// per-block entry lists, then per block  scatter -> C = B Linv^T -> S = D - C C^T ->
+// potrf(S) by 64-wide panels -> Linv by recursive doubling;  sweeps as chains of
+// matrix-panel products.  Launch sequences are captured once into HIP graphs and replayed
+// (the chains are launch-latency bound: ~60 dependent launches per block).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/gmrf_hip.h"
+#include "gemm_f64.hpp"
+#include "misc_kernels.hpp"
+#include "potrf_tile.hpp"
+#include "sweep.hpp"
+
+using namespace gmrf;
+
+static thread_local std::string g_last_error;
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);               \
+            return GMRF_ERR_HIP;                                                            \
+        }                                                                                   \
+    } while (0)
+
+#define GCHK(expr)                                                                          \
+    do {                                                                                    \
+        gmrf_status _s = (expr);                                                            \
+        if (_s != GMRF_OK) return _s;                                                       \
+    } while (0)
+
+static gmrf_status bad_shape(const char* msg) {
+    g_last_error = msg;
+    return GMRF_ERR_BAD_SHAPE;
+}
+
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();   // unregistered host memory: clear the sticky error
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+static int64_t next_pow2(int64_t v) {
+    int64_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------ csr
+struct gmrf_csr {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n_rows = 0, n_cols = 0, nnz = 0;
+    int64_t* d_rowptr = nullptr;
+    int32_t* d_colidx = nullptr;
+    double* d_vals = nullptr;
+    float* d_vals32 = nullptr;
+    double* d_diag = nullptr;
+    double* d_stage_x = nullptr;
+    double* d_stage_y = nullptr;
+    int64_t stage_cap = 0;
+};
+
+// ------------------------------------------------------------------------------------ handle
+struct EvPair {
+    hipEvent_t a, b;
+    int kind;       // 0 gemm, 1 tile, 2 sweep
+    double work;    // flops or bytes
+};
+
+struct gmrf_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, N = 0, bs = 0, bsp = 0, n_pad = 0;
+    // symbolic
+    int64_t nnz_in = 0, n_entries = 0;
+    uint64_t* d_keys = nullptr;
+    double* d_vals = nullptr;
+    int64_t* d_src = nullptr;          // entry -> index into the caller's nzval
+    double* d_nz_stage = nullptr;      // staging for host nzval
+    std::vector<int64_t> diag_first, diag_count, low_first, low_count;
+    bool analyzed = false;
+    // factor storage
+    double *d_L = nullptr, *d_C = nullptr, *d_Linv = nullptr;
+    double *d_S = nullptr, *d_B = nullptr, *d_T = nullptr, *d_W = nullptr;
+    int* d_info = nullptr;
+    double* d_logdet = nullptr;
+    int64_t alloc_N = 0, alloc_bsp = 0;
+    bool factored = false;
+    // right-hand-side panels
+    double *d_P = nullptr, *d_Y = nullptr, *d_Tp = nullptr;
+    int64_t kp_cap = 0;
+    double* d_stage = nullptr;
+    int64_t stage_cap = 0;
+    double* d_mean = nullptr;
+    double* d_acc = nullptr;           // variance accumulator (n)
+    // graphs
+    bool eager = false;
+    hipGraphExec_t factor_graph = nullptr;
+    int64_t factor_graph_i0 = -1, factor_graph_i1 = -1;
+    std::map<int64_t, hipGraphExec_t> sweep_graphs;   // key = mode * 4096 + kp
+    // profiling
+    int profiling = 0;
+    std::vector<EvPair> events;
+    std::vector<hipEvent_t> ev_pool;
+    gmrf_stats stats;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+static void destroy_graphs(gmrf_handle* h) {
+    if (h->factor_graph) { (void)hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
+    for (auto& kv : h->sweep_graphs) (void)hipGraphExecDestroy(kv.second);
+    h->sweep_graphs.clear();
+}
+
+static hipEvent_t ev_get(gmrf_handle* h) {
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct ProfScope {
+    gmrf_handle* h;
+    EvPair p;
+    bool on;
+    ProfScope(gmrf_handle* hh, int kind, double work) : h(hh), on(hh->profiling > 0) {
+        if (on) {
+            p.kind = kind; p.work = work;
+            p.a = ev_get(h); p.b = ev_get(h);
+            (void)hipEventRecord(p.a, h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (on) {
+            (void)hipEventRecord(p.b, h->stream);
+            h->events.push_back(p);
+        }
+    }
+};
+
+static void prof_collect(gmrf_handle* h) {
+    for (auto& p : h->events) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, p.a, p.b);
+        if (p.kind == 0) { h->stats.gemm_ms += ms; h->stats.gemm_flops += p.work; h->stats.gemm_launches++; }
+        else if (p.kind == 1) { h->stats.tile_ms += ms; h->stats.tile_launches++; }
+        else { h->stats.sweep_kernel_ms += ms; h->stats.sweep_kernel_bytes += p.work; h->stats.sweep_launches++; }
+        h->ev_pool.push_back(p.a);
+        h->ev_pool.push_back(p.b);
+    }
+    h->events.clear();
+}
+
+// ------------------------------------------------------------------------------------ helpers
+static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K, int tri, int lower_only,
+                        double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
+                        double beta, double* C, int64_t ldc, int batch = 1, int64_t sA = 0,
+                        int64_t sB = 0, int64_t sC = 0) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.strideA = sA; g.strideB = sB; g.strideC = sC;
+    g.M = M; g.N = N; g.K = K; g.tri = tri; g.lower_only = lower_only;
+    g.alpha = alpha; g.beta = beta;
+    double flops = 2.0 * M * N * (double)K * batch;
+    if (lower_only) flops *= 0.5 * (1.0 + 64.0 / std::max(M, 64));
+    if (tri) flops *= 0.5 * (1.0 + 64.0 / std::max(K, 64));
+    ProfScope ps(h, 0, flops);
+    HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch));
+    return GMRF_OK;
+}
+
+static void free_dev(void* p) {
+    if (p) (void)hipFree(p);
+}
+
+static gmrf_status alloc_factor(gmrf_handle* h) {
+    if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->d_L) return GMRF_OK;
+    destroy_graphs(h);
+    free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
+    free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
+    free_dev(h->d_logdet);
+    h->d_L = h->d_C = h->d_Linv = h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
+    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double);
+    HIPCHK(hipMalloc(&h->d_L, blk * h->N));
+    HIPCHK(hipMalloc(&h->d_Linv, blk * h->N));
+    HIPCHK(hipMalloc(&h->d_C, blk * std::max<int64_t>(h->N - 1, 1)));
+    HIPCHK(hipMalloc(&h->d_S, blk));
+    HIPCHK(hipMalloc(&h->d_B, blk));
+    HIPCHK(hipMalloc(&h->d_T, blk));
+    HIPCHK(hipMalloc(&h->d_W, blk));
+    HIPCHK(hipMalloc(&h->d_logdet, sizeof(double) * h->N));
+    // tiles strictly above the block diagonal of L / Linv are never written: keep them zero
+    HIPCHK(hipMemsetAsync(h->d_L, 0, blk * h->N, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_Linv, 0, blk * h->N, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_C, 0, blk * std::max<int64_t>(h->N - 1, 1), h->stream));
+    h->alloc_N = h->N; h->alloc_bsp = h->bsp;
+    h->stats.factor_bytes = (int64_t)(blk * (3 * h->N - 1));
+    return GMRF_OK;
+}
+
+static gmrf_status set_shape(gmrf_handle* h, int64_t n, int64_t N) {
+    if (n <= 0 || N <= 0 || n % N != 0) return bad_shape("n must be a positive multiple of N_blocks");
+    const int64_t bs = n / N;
+    if (bs > (1 << 20)) return bad_shape("block size too large");
+    if (h->n != n || h->N != N) {
+        destroy_graphs(h);
+        h->factored = false;
+        h->analyzed = false;
+    }
+    h->n = n; h->N = N; h->bs = bs;
+    h->bsp = 64 * next_pow2((bs + 63) / 64);
+    h->n_pad = h->bsp * N;
+    h->stats.n = n; h->stats.n_blocks = N; h->stats.block_size = bs; h->stats.block_size_padded = h->bsp;
+    h->stats.factor_flops = (double)N * bs * bs * bs / 3.0 + (double)(N - 1) * 2.0 * bs * bs * bs;
+    return GMRF_OK;
+}
+
+static gmrf_status ensure_panels(gmrf_handle* h, int64_t kp) {
+    if (kp <= h->kp_cap && h->d_P) return GMRF_OK;
+    for (auto& kv : h->sweep_graphs) (void)hipGraphExecDestroy(kv.second);
+    h->sweep_graphs.clear();
+    free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
+    h->d_P = h->d_Y = h->d_Tp = nullptr;
+    HIPCHK(hipMalloc(&h->d_P, sizeof(double) * kp * h->n_pad));
+    HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * kp * h->n_pad));
+    HIPCHK(hipMalloc(&h->d_Tp, sizeof(double) * kp * h->bsp));
+    h->kp_cap = kp;
+    return GMRF_OK;
+}
+
+static gmrf_status ensure_stage(gmrf_handle* h, int64_t elems) {
+    if (elems <= h->stage_cap && h->d_stage) return GMRF_OK;
+    free_dev(h->d_stage);
+    h->d_stage = nullptr;
+    HIPCHK(hipMalloc(&h->d_stage, sizeof(double) * elems));
+    h->stage_cap = elems;
+    return GMRF_OK;
+}
+
+// ------------------------------------------------------------------------------------ symbolic
+struct HostEntry { uint64_t key; int64_t src; };
+
+static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<HostEntry>>& dg,
+                                  const std::vector<std::vector<HostEntry>>& lo, int64_t nnz_in) {
+    const int64_t N = h->N;
+    h->diag_first.assign(N, 0); h->diag_count.assign(N, 0);
+    h->low_first.assign(N, 0); h->low_count.assign(N, 0);
+    std::vector<uint64_t> keys;
+    std::vector<int64_t> src;
+    for (int64_t i = 0; i < N; ++i) {
+        h->diag_first[i] = (int64_t)keys.size(); h->diag_count[i] = (int64_t)dg[i].size();
+        for (auto& e : dg[i]) { keys.push_back(e.key); src.push_back(e.src); }
+        h->low_first[i] = (int64_t)keys.size(); h->low_count[i] = (int64_t)lo[i].size();
+        for (auto& e : lo[i]) { keys.push_back(e.key); src.push_back(e.src); }
+    }
+    destroy_graphs(h);
+    free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
+    h->d_keys = nullptr; h->d_vals = nullptr; h->d_src = nullptr; h->d_nz_stage = nullptr;
+    h->n_entries = (int64_t)keys.size();
+    h->nnz_in = nnz_in;
+    const size_t ne = std::max<size_t>(keys.size(), 1);
+    HIPCHK(hipMalloc(&h->d_keys, ne * sizeof(uint64_t)));
+    HIPCHK(hipMalloc(&h->d_vals, ne * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_src, ne * sizeof(int64_t)));
+    HIPCHK(hipMalloc(&h->d_nz_stage, std::max<int64_t>(nnz_in, 1) * sizeof(double)));
+    if (!keys.empty()) {
+        HIPCHK(hipMemcpy(h->d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    h->analyzed = true;
+    h->factored = false;
+    return GMRF_OK;
+}
+
+static gmrf_status analyze_csc(gmrf_handle* h, int64_t n, int64_t N, const int64_t* colptr,
+                               const int64_t* rowval, int32_t base) {
+    if (!colptr || !rowval) return bad_shape("null CSC arrays");
+    GCHK(set_shape(h, n, N));
+    const int64_t bs = h->bs;
+    std::vector<std::vector<HostEntry>> dg(N), lo(N);
+    const int64_t nnz = colptr[n] - base;
+    for (int64_t c = 0; c < n; ++c) {
+        const int64_t bj = c / bs;
+        for (int64_t p = colptr[c] - base; p < colptr[c + 1] - base; ++p) {
+            const int64_t r = rowval[p] - base;
+            if (r < 0 || r >= n) return bad_shape("row index out of range");
+            const int64_t bi = r / bs;
+            if (bi == bj) {
+                if (r >= c) dg[bi].push_back({((uint64_t)(r - bi * bs) << 32) | (uint64_t)(c - bj * bs), p});
+            } else if (bi == bj + 1) {
+                lo[bi].push_back({((uint64_t)(r - bi * bs) << 32) | (uint64_t)(c - bj * bs), p});
+            } else if (bi + 1 == bj) {
+                // upper block: never read by the reference (src/tridiagonal_cholesky.jl:73,76)
+            } else {
+                g_last_error = "entry outside the block tri-band of the partition";
+                return GMRF_ERR_BAND;
+            }
+        }
+    }
+    return upload_entries(h, dg, lo, nnz);
+}
+
+__global__ void gather_values(const double* __restrict__ nz, const int64_t* __restrict__ src,
+                              int64_t count, double* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) vals[i] = nz[src[i]];
+}
+
+static gmrf_status load_values(gmrf_handle* h, const double* nzval) {
+    if (!nzval) return bad_shape("null nzval");
+    const double* d_nz = nzval;
+    if (!is_device_ptr(nzval)) {
+        HIPCHK(hipMemcpyAsync(h->d_nz_stage, nzval, sizeof(double) * h->nnz_in, hipMemcpyHostToDevice, h->stream));
+        d_nz = h->d_nz_stage;
+    }
+    if (h->n_entries > 0) {
+        const int bl = 256;
+        hipLaunchKernelGGL(gather_values, dim3((unsigned)((h->n_entries + bl - 1) / bl)), dim3(bl), 0,
+                           h->stream, d_nz, h->d_src, h->n_entries, h->d_vals);
+        HIPCHK(hipGetLastError());
+    }
+    return GMRF_OK;
+}
+
+// ------------------------------------------------------------------------------------ numeric factor
+static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, double* T, int blk_id) {
+    const int bsp = (int)h->bsp;
+    const int64_t ld = bsp;
+    const int nt = bsp / 64;
+    for (int j = 0; j < nt; ++j) {
+        const int64_t o = (int64_t)j * 64;
+        TileArgs ta;
+        ta.S = S + o * ld + o; ta.lds = ld;
+        ta.L = L + o * ld + o; ta.ldl = ld;
+        ta.X = X + o * ld + o; ta.ldx = ld;
+        ta.info = h->d_info; ta.blk = blk_id;
+        {
+            ProfScope ps(h, 1, 0.0);
+            hipLaunchKernelGGL(potrf_tile64_inv, dim3(1), dim3(64), 0, h->stream, ta);
+            HIPCHK(hipGetLastError());
+        }
+        const int rem = bsp - (j + 1) * 64;
+        if (rem > 0) {
+            const int64_t o1 = o + 64;
+            // panel: L[o1:, o] = S[o1:, o] * Xjj^T
+            GCHK(gemm(h, false, false, rem, 64, 64, TRI_B_UPPER, 0, 1.0, S + o1 * ld + o, ld,
+                      X + o * ld + o, ld, 0.0, L + o1 * ld + o, ld));
+            // trailing: S[o1:, o1:] -= L[o1:, o] L[o1:, o]^T   (lower tiles only)
+            GCHK(gemm(h, false, false, rem, rem, 64, 0, 1, -1.0, L + o1 * ld + o, ld,
+                      L + o1 * ld + o, ld, 1.0, S + o1 * ld + o1, ld));
+        }
+    }
+    // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
+    for (int hh = 64; hh < bsp; hh *= 2) {
+        const int pairs = bsp / (2 * hh);
+        const int64_t st = (int64_t)2 * hh * ld + 2 * hh;
+        // T21 = L21 * X11
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld, ld, X, ld, 0.0,
+                  T + (int64_t)hh * ld, ld, pairs, st, st, st));
+        // X21 = -X22 * T21
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld,
+                  T + (int64_t)hh * ld, ld, 0.0, X + (int64_t)hh * ld, ld, pairs, st, st, st));
+    }
+    return GMRF_OK;
+}
+
+static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
+    const int bsp = (int)h->bsp;
+    const int64_t ld = bsp;
+    const size_t blk_bytes = (size_t)bsp * bsp * sizeof(double);
+    const int64_t bstride = (int64_t)bsp * bsp;
+    for (int64_t i = i0; i < i1; ++i) {
+        double* L = h->d_L + i * bstride;
+        double* X = h->d_Linv + i * bstride;
+        HIPCHK(hipMemsetAsync(h->d_S, 0, blk_bytes, h->stream));
+        if (h->diag_count[i] > 0) {
+            hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256)), dim3(256), 0,
+                               h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld);
+            HIPCHK(hipGetLastError());
+        }
+        if (h->bsp > h->bs) {
+            hipLaunchKernelGGL(pad_identity, dim3((unsigned)((h->bsp - h->bs + 255) / 256)), dim3(256), 0,
+                               h->stream, h->d_S, ld, (int)h->bs, bsp);
+            HIPCHK(hipGetLastError());
+        }
+        if (i > 0) {
+            double* C = h->d_C + (i - 1) * bstride;
+            const double* Xp = h->d_Linv + (i - 1) * bstride;
+            HIPCHK(hipMemsetAsync(h->d_B, 0, blk_bytes, h->stream));
+            if (h->low_count[i] > 0) {
+                hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256)), dim3(256), 0,
+                                   h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld);
+                HIPCHK(hipGetLastError());
+            }
+            // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74)
+            GCHK(gemm(h, false, false, bsp, bsp, bsp, TRI_B_UPPER, 0, 1.0, h->d_B, ld, Xp, ld, 0.0, C, ld));
+            // S = D - C C^T             (src/tridiagonal_cholesky.jl:77)
+            GCHK(gemm(h, false, false, bsp, bsp, bsp, 0, 1, -1.0, C, ld, C, ld, 1.0, h->d_S, ld));
+        }
+        GCHK(potrf_block(h, h->d_S, L, X, h->d_T, (int)(i + 1)));
+    }
+    return GMRF_OK;
+}
+
+static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
+    if (h->eager || h->profiling) return factor_blocks_range(h, i0, i1);
+    if (!h->factor_graph || h->factor_graph_i0 != i0 || h->factor_graph_i1 != i1) {
+        if (h->factor_graph) { (void)hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
+        hipGraph_t graph = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        gmrf_status s = factor_blocks_range(h, i0, i1);
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (s != GMRF_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&h->factor_graph, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        h->factor_graph_i0 = i0; h->factor_graph_i1 = i1;
+    }
+    HIPCHK(hipGraphLaunch(h->factor_graph, h->stream));
+    return GMRF_OK;
+}
+
+static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
+    int hinfo = 0;
+    HIPCHK(hipMemcpyAsync(&hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (info) *info = hinfo;
+    if (hinfo != 0) {
+        h->factored = false;
+        g_last_error = "matrix is not positive definite; failed block " + std::to_string(hinfo);
+        return GMRF_ERR_NOT_SPD;
+    }
+    h->factored = true;
+    return GMRF_OK;
+}
+
+static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* info) {
+    if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
+    GCHK(alloc_factor(h));
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    GCHK(load_values(h, nzval));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    GCHK(run_factor(h, 0, h->N));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    gmrf_status s = factor_finish(h, info);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    h->stats.factor_ms = ms;
+    if (h->profiling) prof_collect(h);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------ sweeps
+static double sweep_bytes(const gmrf_handle* h, int64_t k) {
+    const double bs = (double)h->bs, N = (double)h->N;
+    return 8.0 * (N * bs * (bs + 1) / 2.0 + (N - 1) * bs * bs) + 16.0 * (double)h->n * (double)k;
+}
+
+static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const double* Pin, double* Yout) {
+    const int bsp = (int)h->bsp;
+    const int64_t ld = bsp, bstride = (int64_t)bsp * bsp, npad = h->n_pad;
+    const int64_t N = h->N;
+    SweepArgs s;
+    s.ld = ld; s.bs = bsp;
+    const double blk_bytes_c = 8.0 * bsp * (double)bsp, blk_bytes_t = 4.0 * bsp * (double)(bsp + 1);
+    for (int64_t step = 0; step < N; ++step) {
+        const int64_t i = backward ? (N - 1 - step) : step;
+        const double* rhs = Pin + i * bsp;
+        if (step > 0) {
+            // T = P_i - C y_prev      forward: C_{i-1} y_{i-1};  backward: C_i^T x_{i+1}
+            const int64_t ci = backward ? i : (i - 1);
+            const int64_t prev = backward ? (i + 1) : (i - 1);
+            s.Mat = h->d_C + ci * bstride;
+            s.Xin = Yout + prev * bsp; s.ldx = npad;
+            s.Bin = rhs; s.ldb = npad;
+            s.Out = h->d_Tp; s.ldo = bsp;
+            s.sub = 1;
+            {
+                ProfScope ps(h, 2, blk_bytes_c);
+                HIPCHK(launch_sweep(h->stream, backward, false, kp, s));
+            }
+            rhs = h->d_Tp;
+        }
+        // y_i = Linv_i T   /   x_i = Linv_i^T T
+        s.Mat = h->d_Linv + i * bstride;
+        s.Xin = rhs; s.ldx = (step > 0) ? bsp : npad;
+        s.Bin = nullptr; s.ldb = 0;
+        s.Out = Yout + i * bsp; s.ldo = npad;
+        s.sub = 0;
+        {
+            ProfScope ps(h, 2, blk_bytes_t);
+            HIPCHK(launch_sweep(h->stream, backward, true, kp, s));
+        }
+    }
+    return GMRF_OK;
+}
+
+// mode: 1 forward P->Y, 2 backward P->Y, 0 full P->Y->P (result in P)
+static gmrf_status run_sweeps(gmrf_handle* h, int mode, int kp) {
+    auto body = [&]() -> gmrf_status {
+        if (mode == GMRF_SOLVE_FORWARD) return sweep_launches(h, false, kp, h->d_P, h->d_Y);
+        if (mode == GMRF_SOLVE_BACKWARD) return sweep_launches(h, true, kp, h->d_P, h->d_Y);
+        GCHK(sweep_launches(h, false, kp, h->d_P, h->d_Y));
+        return sweep_launches(h, true, kp, h->d_Y, h->d_P);
+    };
+    if (h->eager || h->profiling) return body();
+    const int64_t key = (int64_t)mode * 4096 + kp;
+    auto it = h->sweep_graphs.find(key);
+    if (it == h->sweep_graphs.end()) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        gmrf_status s = body();
+        hipError_t e = hipStreamEndCapture(h->stream, &graph);
+        if (s != GMRF_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(graph);
+        it = h->sweep_graphs.emplace(key, exec).first;
+    }
+    HIPCHK(hipGraphLaunch(it->second, h->stream));
+    return GMRF_OK;
+}
+
+static int pad_k(int64_t k) { return k == 1 ? 1 : (int)((k + 15) / 16 * 16); }
+
+static gmrf_status launch_pack(gmrf_handle* h, const double* d_src, int64_t ld, int k, int kp) {
+    const int64_t total = (int64_t)kp * h->n_pad;
+    hipLaunchKernelGGL(pack_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d_src, ld,
+                       h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, (int)h->N, k, kp);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+static gmrf_status launch_unpack(gmrf_handle* h, const double* panel, double* d_dst, int64_t ld, int k,
+                                 const double* d_mean) {
+    const int64_t total = h->n * (int64_t)k;
+    hipLaunchKernelGGL(unpack_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, panel,
+                       h->n_pad, d_dst, ld, (int)h->bs, (int)h->bsp, h->n, k, d_mean);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+constexpr int64_t KP_CHUNK = 128;
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" {
+
+int32_t gmrf_version(void) { return 100; }
+const char* gmrf_last_error(void) { return g_last_error.c_str(); }
+
+gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
+    if (!out) return bad_shape("null out pointer");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        g_last_error = "no HIP device visible (libgmrf_hip needs an MI355X / gfx950 GPU)";
+        return GMRF_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    gmrf_handle* h = new gmrf_handle();
+    memset(&h->stats, 0, sizeof(h->stats));
+    h->device = device;
+    if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
+    else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    HIPCHK(hipMalloc(&h->d_info, sizeof(int)));
+    HIPCHK(hipMemset(h->d_info, 0, sizeof(int)));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    *out = h;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
+    if (!h) return GMRF_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    destroy_graphs(h);
+    free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
+    free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
+    free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
+    free_dev(h->d_info); free_dev(h->d_logdet);
+    free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
+    free_dev(h->d_stage); free_dev(h->d_mean); free_dev(h->d_acc);
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
+    if (!h) return bad_shape("null handle");
+    h->profiling = level;
+    h->stats.gemm_ms = h->stats.gemm_flops = 0; h->stats.gemm_launches = 0;
+    h->stats.tile_ms = 0; h->stats.tile_launches = 0;
+    h->stats.sweep_kernel_ms = h->stats.sweep_kernel_bytes = 0; h->stats.sweep_launches = 0;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
+    if (!h) return bad_shape("null handle");
+    h->eager = eager != 0;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_synchronize(gmrf_handle* h) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_stats(gmrf_handle* h, gmrf_stats* out) {
+    if (!h || !out) return bad_shape("null pointer");
+    *out = h->stats;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_factor_csc(gmrf_handle* h, int64_t n, int64_t n_blocks, const int64_t* colptr,
+                               const int64_t* rowval, const double* nzval, int32_t index_base,
+                               int32_t* info) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (info) *info = 0;
+    GCHK(analyze_csc(h, n, n_blocks, colptr, rowval, index_base));
+    return numeric_factor(h, nzval, info);
+}
+
+gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks, const int64_t* colptr,
+                                     const int64_t* rowval, const double* nzval, int32_t index_base) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (colptr) GCHK(analyze_csc(h, n, n_blocks, colptr, rowval, index_base));
+    if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
+    GCHK(alloc_factor(h));
+    GCHK(load_values(h, nzval));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    h->factored = false;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_factor_step_async(gmrf_handle* h, int64_t i0, int64_t i1) {
+    if (!h) return bad_shape("null handle");
+    if (i0 < 0 || i1 > h->N || i0 > i1) return bad_shape("bad block range");
+    HIPCHK(hipSetDevice(h->device));
+    // block ranges are launched directly (a graph per range would have to be re-captured)
+    return factor_blocks_range(h, i0, i1);
+}
+
+gmrf_status gmrf_bt_factor_end(gmrf_handle* h, int32_t* info) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    gmrf_status s = factor_finish(h, info);
+    if (h->profiling) prof_collect(h);
+    return s;
+}
+
+gmrf_status gmrf_bt_refactor_values(gmrf_handle* h, const double* nzval, int32_t* info) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    if (info) *info = 0;
+    return numeric_factor(h, nzval, info);
+}
+
+gmrf_status gmrf_bt_factor_blocks(gmrf_handle* h, int64_t n, int64_t n_blocks, const gmrf_sparse_block* diag,
+                                  const gmrf_sparse_block* lower, int32_t index_base,
+                                  int32_t compressed_by_column, int32_t* info) {
+    if (!h || !diag || (n_blocks > 1 && !lower)) return bad_shape("null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    if (info) *info = 0;
+    GCHK(set_shape(h, n, n_blocks));
+    const int64_t bs = h->bs;
+    std::vector<std::vector<HostEntry>> dg(n_blocks), lo(n_blocks);
+    std::vector<double> vals;
+    auto add_block = [&](const gmrf_sparse_block& b, std::vector<HostEntry>& dst, bool lower_tri_only) -> bool {
+        for (int64_t o = 0; o < bs; ++o) {
+            for (int64_t p = b.ptr[o] - index_base; p < b.ptr[o + 1] - index_base; ++p) {
+                const int64_t in = b.idx[p] - index_base;
+                if (in < 0 || in >= bs) return false;
+                const int64_t r = compressed_by_column ? in : o, c = compressed_by_column ? o : in;
+                if (lower_tri_only && r < c) continue;
+                dst.push_back({((uint64_t)r << 32) | (uint64_t)c, (int64_t)vals.size()});
+                vals.push_back(b.val[p]);
+            }
+        }
+        return true;
+    };
+    for (int64_t i = 0; i < n_blocks; ++i) {
+        if (!add_block(diag[i], dg[i], true)) return bad_shape("block index out of range");
+        if (i > 0 && !add_block(lower[i - 1], lo[i], false)) return bad_shape("block index out of range");
+    }
+    GCHK(upload_entries(h, dg, lo, (int64_t)vals.size()));
+    return numeric_factor(h, vals.data(), info);
+}
+
+gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    GCHK(set_shape(h, n, n_blocks));
+    GCHK(alloc_factor(h));
+    h->factored = false;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h) {
+    if (!h || !h->d_L) return bad_shape("no factor storage");
+    h->factored = true;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr, int64_t* bytes) {
+    if (!h || !dev_ptr || !bytes) return bad_shape("null pointer");
+    if (!h->d_L) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
+    const int64_t blk = h->bsp * h->bsp * (int64_t)sizeof(double);
+    if (kind == GMRF_BLOCK_L) { *dev_ptr = h->d_L; *bytes = blk * h->N; }
+    else if (kind == GMRF_BLOCK_C) { *dev_ptr = h->d_C; *bytes = blk * (h->N - 1); }
+    else if (kind == GMRF_BLOCK_LINV) { *dev_ptr = h->d_Linv; *bytes = blk * h->N; }
+    else return bad_shape("bad block kind");
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* out, int64_t ld) {
+    if (!h || !out) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "no factor"; return GMRF_ERR_NO_FACTOR; }
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t bs = h->bs, bsp = h->bsp;
+    if (ld < bs) return bad_shape("ld < block_size");
+    const double* src;
+    if (kind == GMRF_BLOCK_L) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_L + i * bsp * bsp; }
+    else if (kind == GMRF_BLOCK_LINV) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_Linv + i * bsp * bsp; }
+    else if (kind == GMRF_BLOCK_C) { if (i < 0 || i >= h->N - 1) return bad_shape("block index"); src = h->d_C + i * bsp * bsp; }
+    else return bad_shape("bad block kind");
+    std::vector<double> tmp((size_t)bsp * bsp);
+    HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    const bool dev_out = is_device_ptr(out);
+    std::vector<double> cm;
+    double* dst = out;
+    int64_t ldd = ld;
+    if (dev_out) { cm.resize((size_t)bs * bs); dst = cm.data(); ldd = bs; }
+    for (int64_t r = 0; r < bs; ++r)
+        for (int64_t c = 0; c < bs; ++c) dst[c * ldd + r] = tmp[(size_t)r * bsp + c];   // row-major -> column-major
+    if (dev_out) HIPCHK(hipMemcpy2D(out, ld * sizeof(double), cm.data(), bs * sizeof(double), bs * sizeof(double), bs, hipMemcpyHostToDevice));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k, int64_t ld, int32_t mode) {
+    if (!h || !b || !y) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "solve before factor"; return GMRF_ERR_NO_FACTOR; }
+    if (k <= 0 || ld < h->n || mode < 0 || mode > 2) return bad_shape("bad k / ld / mode");
+    HIPCHK(hipSetDevice(h->device));
+    const bool b_dev = is_device_ptr(b), y_dev = is_device_ptr(y);
+    h->stats.solve_ms = 0.0;
+    for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
+        const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
+        const int kp = pad_k(kc);
+        GCHK(ensure_panels(h, kp));
+        const double* bsrc = b + c0 * ld;
+        double* ydst = y + c0 * ld;
+        const double* d_b = bsrc;
+        if (!b_dev || !y_dev) GCHK(ensure_stage(h, (int64_t)kc * h->n));
+        if (!b_dev) {
+            HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), bsrc, ld * sizeof(double),
+                                    h->n * sizeof(double), kc, hipMemcpyHostToDevice, h->stream));
+            d_b = h->d_stage;
+        }
+        GCHK(launch_pack(h, d_b, b_dev ? ld : h->n, kc, kp));
+        HIPCHK(hipEventRecord(h->ev0, h->stream));
+        GCHK(run_sweeps(h, mode, kp));
+        HIPCHK(hipEventRecord(h->ev1, h->stream));
+        const double* result = (mode == GMRF_SOLVE_FULL) ? h->d_P : h->d_Y;
+        if (y_dev) {
+            GCHK(launch_unpack(h, result, ydst, ld, kc, nullptr));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        } else {
+            GCHK(launch_unpack(h, result, h->d_stage, h->n, kc, nullptr));
+            HIPCHK(hipMemcpy2DAsync(ydst, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
+                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+        h->stats.solve_ms += ms;
+        const int nsweeps = (mode == GMRF_SOLVE_FULL) ? 2 : 1;
+        h->stats.sweep_ms = ms / nsweeps;
+        h->stats.sweep_bytes = sweep_bytes(h, kc);
+        if (h->profiling) prof_collect(h);
+    }
+    return GMRF_OK;
+}
+
+static gmrf_status stage_vector(gmrf_handle* h, const double* v, double** d_buf, const double** d_out) {
+    if (!v) { *d_out = nullptr; return GMRF_OK; }
+    if (is_device_ptr(v)) { *d_out = v; return GMRF_OK; }
+    if (!*d_buf) HIPCHK(hipMalloc(d_buf, sizeof(double) * h->n));
+    HIPCHK(hipMemcpyAsync(*d_buf, v, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    *d_out = *d_buf;
+    return GMRF_OK;
+}
+
+// draws (or loads) z for samples [first_id + c0, +kc) into panel P and runs the backward sweep -> panel Y
+static gmrf_status sample_chunk(gmrf_handle* h, uint64_t seed, int64_t first_id, int kc, const double* z,
+                                int64_t ldz) {
+    const int kp = pad_k(kc);
+    GCHK(ensure_panels(h, kp));
+    if (z) {
+        const double* d_z = z;
+        int64_t ldd = ldz;
+        if (!is_device_ptr(z)) {
+            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), z, ldz * sizeof(double),
+                                    h->n * sizeof(double), kc, hipMemcpyHostToDevice, h->stream));
+            d_z = h->d_stage; ldd = h->n;
+        }
+        GCHK(launch_pack(h, d_z, ldd, kc, kp));
+    } else {
+        const int64_t total = (int64_t)kp * h->n_pad;
+        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id);
+        HIPCHK(hipGetLastError());
+    }
+    return run_sweeps(h, GMRF_SOLVE_BACKWARD, kp);
+}
+
+gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k, const double* mean,
+                           const double* z, double* out, int64_t ld) {
+    if (!h || !out) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "sample before factor"; return GMRF_ERR_NO_FACTOR; }
+    if (k <= 0 || ld < h->n) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(h->device));
+    const double* d_mean = nullptr;
+    GCHK(stage_vector(h, mean, &h->d_mean, &d_mean));
+    const bool out_dev = is_device_ptr(out);
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
+        const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
+        GCHK(sample_chunk(h, seed, first_id + c0, kc, z ? z + c0 * ld : nullptr, ld));
+        if (out_dev) {
+            GCHK(launch_unpack(h, h->d_Y, out + c0 * ld, ld, kc, d_mean));
+        } else {
+            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            GCHK(launch_unpack(h, h->d_Y, h->d_stage, h->n, kc, d_mean));
+            HIPCHK(hipMemcpy2DAsync(out + c0 * ld, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
+                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+        }
+    }
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    h->stats.sample_ms = ms;
+    if (h->profiling) prof_collect(h);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k, double* z, int64_t ld) {
+    if (!h || !z) return bad_shape("null pointer");
+    if (h->n <= 0) return bad_shape("no shape set");
+    if (k <= 0 || ld < h->n) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(h->device));
+    const bool z_dev = is_device_ptr(z);
+    for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
+        const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
+        const int kp = pad_k(kc);
+        GCHK(ensure_panels(h, kp));
+        const int64_t total = (int64_t)kp * h->n_pad;
+        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
+                           h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id + c0);
+        HIPCHK(hipGetLastError());
+        if (z_dev) {
+            GCHK(launch_unpack(h, h->d_P, z + c0 * ld, ld, kc, nullptr));
+        } else {
+            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            GCHK(launch_unpack(h, h->d_P, h->d_stage, h->n, kc, nullptr));
+            HIPCHK(hipMemcpy2DAsync(z + c0 * ld, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
+                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+        }
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out) {
+    if (!h || !out) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "logdet before factor"; return GMRF_ERR_NO_FACTOR; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N), dim3(256), 0, h->stream, h->d_L,
+                       h->bsp * h->bsp, h->bsp, (int)h->bs, h->d_logdet);
+    HIPCHK(hipGetLastError());
+    std::vector<double> part((size_t)h->N);
+    HIPCHK(hipMemcpyAsync(part.data(), h->d_logdet, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    double s = 0.0;
+    for (double v : part) s += v;
+    *out = 2.0 * s;
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- CSR / SpMM
+gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_t n_cols, const int64_t* rowptr,
+                            const int64_t* colidx, const double* vals, int32_t index_base, int32_t values_f32,
+                            gmrf_csr** out) {
+    if (!out || !rowptr || !colidx || !vals || n_rows <= 0 || n_cols <= 0) return bad_shape("bad CSR arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        g_last_error = "no HIP device visible";
+        return GMRF_ERR_NO_DEVICE;
+    }
+    HIPCHK(hipSetDevice(device));
+    const int64_t nnz = rowptr[n_rows] - index_base;
+    std::vector<int64_t> rp((size_t)n_rows + 1);
+    for (int64_t i = 0; i <= n_rows; ++i) rp[i] = rowptr[i] - index_base;
+    std::vector<int32_t> ci((size_t)nnz);
+    for (int64_t p = 0; p < nnz; ++p) {
+        const int64_t c = colidx[p] - index_base;
+        if (c < 0 || c >= n_cols) return bad_shape("column index out of range");
+        ci[p] = (int32_t)c;
+    }
+    gmrf_csr* m = new gmrf_csr();
+    m->device = device;
+    if (stream) { m->stream = (hipStream_t)stream; } else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
+    HIPCHK(hipMalloc(&m->d_rowptr, sizeof(int64_t) * (n_rows + 1)));
+    HIPCHK(hipMalloc(&m->d_colidx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    HIPCHK(hipMemcpy(m->d_rowptr, rp.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(m->d_colidx, ci.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    if (values_f32) {
+        std::vector<float> vf((size_t)nnz);
+        for (int64_t p = 0; p < nnz; ++p) vf[p] = (float)vals[p];
+        HIPCHK(hipMalloc(&m->d_vals32, sizeof(float) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMemcpy(m->d_vals32, vf.data(), sizeof(float) * nnz, hipMemcpyHostToDevice));
+    } else {
+        HIPCHK(hipMalloc(&m->d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        HIPCHK(hipMemcpy(m->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice));
+    }
+    if (n_rows == n_cols) {
+        HIPCHK(hipMalloc(&m->d_diag, sizeof(double) * n_rows));
+        hipLaunchKernelGGL(csr_extract_diag, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, m->stream,
+                           m->d_rowptr, m->d_colidx, m->d_vals, m->d_vals32, n_rows, m->d_diag);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(m->stream));
+    }
+    *out = m;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_csr_destroy(gmrf_csr* m) {
+    if (!m) return GMRF_OK;
+    (void)hipSetDevice(m->device);
+    (void)hipStreamSynchronize(m->stream);
+    free_dev(m->d_rowptr); free_dev(m->d_colidx); free_dev(m->d_vals); free_dev(m->d_vals32);
+    free_dev(m->d_diag); free_dev(m->d_stage_x); free_dev(m->d_stage_y);
+    if (m->own_stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+    return GMRF_OK;
+}
+
+static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* d_X, int64_t ldx, double* d_Y,
+                               int64_t ldy, int k) {
+    const double avg = (double)S->nnz / (double)S->n_rows;
+    const int bl = 256;
+    auto grid_for = [&](int G) { return dim3((unsigned)((S->n_rows * G + bl - 1) / bl)); };
+#define SPMM_LAUNCH(VT, G, VP)                                                                               \
+    hipLaunchKernelGGL((csr_spmm<VT, G>), grid_for(G), dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP,        \
+                       S->n_rows, d_X, ldx, d_Y, ldy, k)
+    if (S->d_vals32) {
+        if (avg > 40) SPMM_LAUNCH(float, 64, S->d_vals32);
+        else if (avg > 20) SPMM_LAUNCH(float, 32, S->d_vals32);
+        else if (avg > 10) SPMM_LAUNCH(float, 16, S->d_vals32);
+        else SPMM_LAUNCH(float, 8, S->d_vals32);
+    } else {
+        if (avg > 40) SPMM_LAUNCH(double, 64, S->d_vals);
+        else if (avg > 20) SPMM_LAUNCH(double, 32, S->d_vals);
+        else if (avg > 10) SPMM_LAUNCH(double, 16, S->d_vals);
+        else SPMM_LAUNCH(double, 8, S->d_vals);
+    }
+#undef SPMM_LAUNCH
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy) {
+    if (!S || !X || !Y) return bad_shape("null pointer");
+    if (k <= 0 || ldx < S->n_cols || ldy < S->n_rows) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(S->device));
+    gmrf_csr* m = const_cast<gmrf_csr*>(S);
+    const bool x_dev = is_device_ptr(X), y_dev = is_device_ptr(Y);
+    const double* d_X = X;
+    double* d_Y = Y;
+    int64_t lx = ldx, ly = ldy;
+    const int64_t need = k * std::max(S->n_rows, S->n_cols);
+    if ((!x_dev || !y_dev) && need > m->stage_cap) {
+        free_dev(m->d_stage_x); free_dev(m->d_stage_y);
+        m->d_stage_x = m->d_stage_y = nullptr;
+        HIPCHK(hipMalloc(&m->d_stage_x, sizeof(double) * need));
+        HIPCHK(hipMalloc(&m->d_stage_y, sizeof(double) * need));
+        m->stage_cap = need;
+    }
+    if (!x_dev) {
+        HIPCHK(hipMemcpy2DAsync(m->d_stage_x, S->n_cols * sizeof(double), X, ldx * sizeof(double),
+                                S->n_cols * sizeof(double), k, hipMemcpyHostToDevice, S->stream));
+        d_X = m->d_stage_x; lx = S->n_cols;
+    }
+    if (!y_dev) { d_Y = m->d_stage_y; ly = S->n_rows; }
+    GCHK(spmm_device(S, S->stream, d_X, lx, d_Y, ly, (int)k));
+    if (!y_dev)
+        HIPCHK(hipMemcpy2DAsync(Y, ldy * sizeof(double), d_Y, S->n_rows * sizeof(double),
+                                S->n_rows * sizeof(double), k, hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- variances
+static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
+    // S_NN = Linv_N^T Linv_N ;  S_ii = Linv_i^T Linv_i + G^T S_{i+1,i+1} G,  G = C_i Linv_i
+    const int bsp = (int)h->bsp;
+    const int64_t ld = bsp, bstride = (int64_t)bsp * bsp;
+    double* Sg = h->d_S;     // current Sigma_{i+1,i+1}
+    double* G = h->d_B;
+    double* Hm = h->d_T;
+    double* Sn = h->d_W;
+    for (int64_t i = h->N - 1; i >= 0; --i) {
+        const double* X = h->d_Linv + i * bstride;
+        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld));
+        if (i < h->N - 1) {
+            const double* C = h->d_C + i * bstride;
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld));
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld));
+            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld));
+        }
+        hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((h->bs + 255) / 256)), dim3(256), 0, h->stream,
+                           Sn, ld, (int)h->bs, d_out + i * h->bs);
+        HIPCHK(hipGetLastError());
+        std::swap(Sg, Sn);
+    }
+    return GMRF_OK;
+}
+
+static gmrf_status var_accumulate_dev(gmrf_handle* h, int method, int64_t first_id, int64_t k, uint64_t seed,
+                                      const gmrf_csr* Q, double* d_acc) {
+    for (int64_t c0 = 0; c0 < k; c0 += 64) {
+        const int kc = (int)std::min<int64_t>(64, k - c0);
+        GCHK(sample_chunk(h, seed, first_id + c0, kc, nullptr, 0));
+        GCHK(ensure_stage(h, 2 * (int64_t)kc * h->n));
+        double* Xc = h->d_stage;
+        double* QX = h->d_stage + (int64_t)kc * h->n;
+        GCHK(launch_unpack(h, h->d_Y, Xc, h->n, kc, nullptr));
+        if (method == GMRF_VAR_RBMC) {
+            GCHK(spmm_device(Q, h->stream, Xc, h->n, QX, h->n, kc));
+            hipLaunchKernelGGL(rbmc_accumulate, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, QX, Xc,
+                               h->n, Q->d_diag, h->n, kc, d_acc);
+        } else {
+            hipLaunchKernelGGL(mc_accumulate, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, Xc, h->n,
+                               h->n, kc, d_acc);
+        }
+        HIPCHK(hipGetLastError());
+    }
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_var_accumulate(gmrf_handle* h, int32_t method, int64_t first_id, int64_t k, uint64_t seed,
+                                   const gmrf_csr* Q, double* acc) {
+    if (!h || !acc) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "variance before factor"; return GMRF_ERR_NO_FACTOR; }
+    if (method != GMRF_VAR_RBMC && method != GMRF_VAR_MC) return bad_shape("accumulate needs RBMC or MC");
+    if (method == GMRF_VAR_RBMC && (!Q || Q->n_rows != h->n || !Q->d_diag)) return bad_shape("RBMC needs the square matrix Q");
+    if (k <= 0) return bad_shape("k <= 0");
+    HIPCHK(hipSetDevice(h->device));
+    const bool dev = is_device_ptr(acc);
+    double* d_acc = acc;
+    if (!dev) {
+        if (!h->d_acc) HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n));
+        HIPCHK(hipMemcpyAsync(h->d_acc, acc, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+        d_acc = h->d_acc;
+    }
+    GCHK(var_accumulate_dev(h, method, first_id, k, seed, Q, d_acc));
+    if (!dev) HIPCHK(hipMemcpyAsync(acc, d_acc, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed, const gmrf_csr* Q,
+                                 double* var_out) {
+    if (!h || !var_out) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "variance before factor"; return GMRF_ERR_NO_FACTOR; }
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->d_acc) HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n));
+    const bool dev = is_device_ptr(var_out);
+    double* d_out = var_out;
+    if (!dev) { GCHK(ensure_stage(h, std::max<int64_t>(h->n, 1))); }
+    if (method == GMRF_VAR_EXACT) {
+        // selected inversion writes into d_acc (stage may be reused by nothing here)
+        GCHK(var_exact(h, h->d_acc));
+        if (dev) HIPCHK(hipMemcpyAsync(d_out, h->d_acc, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+        else HIPCHK(hipMemcpyAsync(var_out, h->d_acc, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->profiling) prof_collect(h);
+        return GMRF_OK;
+    }
+    if (method != GMRF_VAR_RBMC && method != GMRF_VAR_MC) return bad_shape("bad variance method");
+    if (method == GMRF_VAR_RBMC && (!Q || Q->n_rows != h->n || !Q->d_diag)) return bad_shape("RBMC needs the square matrix Q");
+    if (k <= 0) return bad_shape("k <= 0");
+    HIPCHK(hipMemsetAsync(h->d_acc, 0, sizeof(double) * h->n, h->stream));
+    GCHK(var_accumulate_dev(h, method, 0, k, seed, Q, h->d_acc));
+    // finish in place: var = base + acc / k
+    double* d_fin = h->d_acc;
+    hipLaunchKernelGGL(var_finish, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, h->d_acc,
+                       method == GMRF_VAR_RBMC ? Q->d_diag : (const double*)nullptr, 1.0 / (double)k, h->n, d_fin);
+    HIPCHK(hipGetLastError());
+    if (dev) HIPCHK(hipMemcpyAsync(d_out, d_fin, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(hipMemcpyAsync(var_out, d_fin, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->profiling) prof_collect(h);
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- test hooks
+gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int32_t transA, int32_t transB,
+                           int32_t tri_flags, int32_t lower_only, double alpha, const double* A, int64_t lda,
+                           const double* B, int64_t ldb, double beta, double* C, int64_t ldc) {
+    if (M % 64 || N % 64 || K % 16 || (lda & 1) || (ldb & 1)) return bad_shape("gemm test sizes");
+    HIPCHK(hipSetDevice(device));
+    const int64_t a_rows = transA ? K : M, b_rows = transB ? N : K;
+    double *dA, *dB, *dC;
+    HIPCHK(hipMalloc(&dA, sizeof(double) * a_rows * lda));
+    HIPCHK(hipMalloc(&dB, sizeof(double) * b_rows * ldb));
+    HIPCHK(hipMalloc(&dC, sizeof(double) * M * ldc));
+    HIPCHK(hipMemcpy(dA, A, sizeof(double) * a_rows * lda, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, B, sizeof(double) * b_rows * ldb, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dC, C, sizeof(double) * M * ldc, hipMemcpyHostToDevice));
+    GemmArgs g;
+    g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
+    g.alpha = alpha; g.beta = beta;
+    // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
+    HIPCHK(launch_gemm(nullptr, transA != 0, transB == 0, g, 1));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64, double* inv64, int32_t* info) {
+    HIPCHK(hipSetDevice(device));
+    double *dS, *dL, *dX;
+    int* dinfo;
+    HIPCHK(hipMalloc(&dS, sizeof(double) * 4096));
+    HIPCHK(hipMalloc(&dL, sizeof(double) * 4096));
+    HIPCHK(hipMalloc(&dX, sizeof(double) * 4096));
+    HIPCHK(hipMalloc(&dinfo, sizeof(int)));
+    HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
+    HIPCHK(hipMemcpy(dS, tile64, sizeof(double) * 4096, hipMemcpyHostToDevice));
+    TileArgs ta;
+    ta.S = dS; ta.lds = 64; ta.L = dL; ta.ldl = 64; ta.X = dX; ta.ldx = 64; ta.info = dinfo; ta.blk = 1;
+    hipLaunchKernelGGL(potrf_tile64_inv, dim3(1), dim3(64), 0, nullptr, ta);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(tile64, dL, sizeof(double) * 4096, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(inv64, dX, sizeof(double) * 4096, hipMemcpyDeviceToHost));
+    int hi = 0;
+    HIPCHK(hipMemcpy(&hi, dinfo, sizeof(int), hipMemcpyDeviceToHost));
+    if (info) *info = hi;
+    hipFree(dS); hipFree(dL); hipFree(dX); hipFree(dinfo);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double* Linv, int32_t* info) {
+    if (bs % 64 || next_pow2(bs / 64) != bs / 64) return bad_shape("bs must be 64 * 2^p");
+    gmrf_handle* h = nullptr;
+    GCHK(gmrf_bt_create(device, nullptr, &h));
+    h->N = 1; h->n = bs; h->bs = bs; h->bsp = bs; h->n_pad = bs;
+    gmrf_status s = alloc_factor(h);
+    if (s == GMRF_OK) {
+        hipError_t e = hipMemcpyAsync(h->d_S, S, sizeof(double) * bs * bs, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) s = potrf_block(h, h->d_S, h->d_L, h->d_Linv, h->d_T, 1);
+        if (s == GMRF_OK) {
+            int hi = 0;
+            (void)hipMemcpyAsync(&hi, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream);
+            (void)hipMemcpyAsync(S, h->d_L, sizeof(double) * bs * bs, hipMemcpyDeviceToHost, h->stream);
+            (void)hipMemcpyAsync(Linv, h->d_Linv, sizeof(double) * bs * bs, hipMemcpyDeviceToHost, h->stream);
+            if (hipStreamSynchronize(h->stream) != hipSuccess) s = GMRF_ERR_HIP;
+            if (info) *info = hi;
+        }
+    }
+    gmrf_bt_destroy(h);
+    return s;
+}
+
+gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops) {
+    HIPCHK(hipSetDevice(device));
+    double* d;
+    HIPCHK(hipMalloc(&d, 64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const int iters = 20000, blocks = 256 * 2;
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, nullptr, d, 100);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(a, nullptr));
+    hipLaunchKernelGGL(mfma_f64_rate_kernel, dim3(blocks), dim3(256), 0, nullptr, d, iters);
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2048.0;
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    hipFree(d); hipEventDestroy(a); hipEventDestroy(b);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps) {
+    HIPCHK(hipSetDevice(device));
+    double2* src;
+    double* d;
+    HIPCHK(hipMalloc(&src, bytes));
+    HIPCHK(hipMalloc(&d, 64));
+    HIPCHK(hipMemset(src, 0, bytes));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    const int64_t n16 = bytes / 16;
+    hipLaunchKernelGGL(hbm_read_kernel, dim3(2048), dim3(256), 0, nullptr, src, n16, d);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(a, nullptr));
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(hbm_read_kernel, dim3(2048), dim3(256), 0, nullptr, src, n16, d);
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *gbps = 5.0 * (double)bytes / (ms * 1e-3) / 1e9;
+    hipFree(src); hipFree(d); hipEventDestroy(a); hipEventDestroy(b);
+    return GMRF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,243 @@
+// Memory-bound helper kernels of the hot path: sparse-block scatter (K0), right-hand-side
+// panel pack/unpack, Philox normals, CSR SpMV/SpMM (K6) and the variance accumulators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gmrf {
+
+// ------------------------------------------------------------------------------- K0
+// Scatter the stored entries of one sparse block into a zeroed dense row-major block.
+// Replaces `Array(A[rows, cols])` of /root/reference/src/tridiagonal_cholesky.jl:67,73,76.
+// Entries are (row << 32 | col) keys local to the block.
+__global__ void scatter_block(const uint64_t* __restrict__ keys, const double* __restrict__ vals,
+                              int64_t first, int64_t count, double* __restrict__ dst, int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t key = keys[first + i];
+    const int64_t r = (int64_t)(key >> 32), c = (int64_t)(key & 0xffffffffu);
+    dst[r * ld + c] = vals[first + i];
+}
+
+// Identity on the padding rows [bs, bsp) of a padded diagonal block.
+__global__ void pad_identity(double* __restrict__ dst, int64_t ld, int bs, int bsp) {
+    const int i = bs + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bsp) dst[(int64_t)i * ld + i] = 1.0;
+}
+
+// ------------------------------------------------------------------------------- panels
+// user matrix (column-major n x k, leading dimension ld) <-> padded panel P[rhs][n_pad]
+__global__ void pack_panel(const double* __restrict__ src, int64_t ld, double* __restrict__ P,
+                           int64_t n_pad, int bs, int bsp, int nblk, int k, int kp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)kp * n_pad;
+    if (idx >= total) return;
+    const int64_t r = idx / n_pad, j = idx % n_pad;
+    const int64_t blk = j / bsp, off = j % bsp;
+    double v = 0.0;
+    if (r < k && off < bs) v = src[r * ld + blk * bs + off];
+    P[idx] = v;
+}
+
+__global__ void unpack_panel(const double* __restrict__ P, int64_t n_pad, double* __restrict__ dst,
+                             int64_t ld, int bs, int bsp, int64_t n, int k,
+                             const double* __restrict__ mean) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * (int64_t)k) return;
+    const int64_t r = idx / n, j = idx % n;
+    const int64_t blk = j / bs, off = j % bs;
+    double v = P[r * n_pad + blk * bsp + off];
+    if (mean) v += mean[j];
+    dst[r * ld + j] = v;
+}
+
+// ------------------------------------------------------------------------------- RNG
+// Philox4x32-10 (Salmon et al. 2011), key = seed, counter = (dof, sample id).
+__device__ __host__ inline void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__device__ __host__ inline double philox_normal(uint64_t seed, uint64_t dof, uint64_t sample) {
+    uint32_t c[4] = {(uint32_t)dof, (uint32_t)(dof >> 32), (uint32_t)sample, (uint32_t)(sample >> 32)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t a = ((uint64_t)c[1] << 32) | c[0];
+    const uint64_t b = ((uint64_t)c[3] << 32) | c[2];
+    const double u1 = ((double)(a >> 11) + 0.5) * (1.0 / 9007199254740992.0);   // (0,1)
+    const double u2 = ((double)(b >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+    return sqrt(-2.0 * log(u1)) * cos(6.283185307179586476925 * u2);
+}
+
+// Fill the padded panel rows [0,k) with normals of samples first_id.. (padding stays zero).
+__global__ void fill_normals_panel(double* __restrict__ P, int64_t n_pad, int bs, int bsp,
+                                   int k, int kp, uint64_t seed, int64_t first_id) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)kp * n_pad) return;
+    const int64_t r = idx / n_pad, j = idx % n_pad;
+    const int64_t blk = j / bsp, off = j % bsp;
+    double v = 0.0;
+    if (r < k && off < bs) v = philox_normal(seed, (uint64_t)(blk * bs + off), (uint64_t)(first_id + r));
+    P[idx] = v;
+}
+
+// ------------------------------------------------------------------------------- K6
+// CSR SpMV/SpMM  Y = S X, X and Y stored one right-hand side after the other (strides
+// ldx/ldy).  Replaces SparseArrays' `Q * x` (scripts/solve_burger.jl:157-158,166,177 and the
+// RBMC variance estimator).  G lanes cooperate on one row: column indices and values are
+// read once, coalesced, and reused for every right-hand side; partial sums are combined by
+// a butterfly inside the lane group.  VT = float stores fp32 values (config 5), the
+// accumulation is fp64 either way.
+template <typename VT, int G>
+__global__ __launch_bounds__(256) void csr_spmm(const int64_t* __restrict__ rowptr,
+                                                const int32_t* __restrict__ colidx,
+                                                const VT* __restrict__ vals, int64_t n_rows,
+                                                const double* __restrict__ X, int64_t ldx,
+                                                double* __restrict__ Y, int64_t ldy, int k) {
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
+    const int sub = threadIdx.x % G;
+    if (gid >= n_rows) return;            // whole lane group leaves together
+    const int64_t p0 = rowptr[gid], p1 = rowptr[gid + 1];
+    for (int r0 = 0; r0 < k; r0 += 4) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        const int kr = min(4, k - r0);
+        for (int64_t p = p0 + sub; p < p1; p += G) {
+            const int64_t c = colidx[p];
+            const double v = (double)vals[p];
+            const double* x = X + (int64_t)r0 * ldx + c;
+            s0 = fma(v, x[0], s0);
+            if (kr > 1) s1 = fma(v, x[ldx], s1);
+            if (kr > 2) s2 = fma(v, x[2 * ldx], s2);
+            if (kr > 3) s3 = fma(v, x[3 * ldx], s3);
+        }
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) {
+            s0 += __shfl_xor(s0, off, G);
+            s1 += __shfl_xor(s1, off, G);
+            s2 += __shfl_xor(s2, off, G);
+            s3 += __shfl_xor(s3, off, G);
+        }
+        if (sub == 0) {
+            double* y = Y + (int64_t)r0 * ldy + gid;
+            y[0] = s0;
+            if (kr > 1) y[ldy] = s1;
+            if (kr > 2) y[2 * ldy] = s2;
+            if (kr > 3) y[3 * ldy] = s3;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- variances
+// acc[i] += sum_s ((QX[s][i] - d_i X[s][i]) / d_i)^2     (RBMC off-diagonal term)
+__global__ void rbmc_accumulate(const double* __restrict__ QX, const double* __restrict__ X,
+                                int64_t ld, const double* __restrict__ diag, int64_t n, int k,
+                                double* __restrict__ acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double d = diag[i];
+    double s = 0.0;
+    for (int r = 0; r < k; ++r) {
+        const double o = (QX[(int64_t)r * ld + i] - d * X[(int64_t)r * ld + i]) / d;
+        s = fma(o, o, s);
+    }
+    acc[i] += s;
+}
+
+// acc[i] += sum_s X[s][i]^2
+__global__ void mc_accumulate(const double* __restrict__ X, int64_t ld, int64_t n, int k,
+                              double* __restrict__ acc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < k; ++r) {
+        const double v = X[(int64_t)r * ld + i];
+        s = fma(v, v, s);
+    }
+    acc[i] += s;
+}
+
+__global__ void csr_extract_diag(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ colidx,
+                                 const double* __restrict__ vals, const float* __restrict__ vals32,
+                                 int64_t n, double* __restrict__ diag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double d = 0.0;
+    for (int64_t p = rowptr[i]; p < rowptr[i + 1]; ++p)
+        if (colidx[p] == i) d += vals ? vals[p] : (double)vals32[p];
+    diag[i] = d;
+}
+
+// var = base + acc * scale     (base: 1/Q_ii for RBMC, 0 for MC)
+__global__ void var_finish(const double* __restrict__ acc, const double* __restrict__ diag,
+                           double scale, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = (diag ? 1.0 / diag[i] : 0.0) + acc[i] * scale;
+}
+
+// sum over the diagonal of log(L[j][j]) for every block; one workgroup per block,
+// fixed-order tree so the result is reproducible.
+__global__ __launch_bounds__(256) void logdet_blocks(const double* __restrict__ L, int64_t blk_stride,
+                                                     int64_t ld, int bs, double* __restrict__ out) {
+    const double* Lb = L + (int64_t)blockIdx.x * blk_stride;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < bs; j += 256) s += log(Lb[(int64_t)j * ld + j]);
+    __shared__ double red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+// diag(S) of a dense block into out (selected inversion output)
+__global__ void extract_diag_dense(const double* __restrict__ S, int64_t ld, int bs,
+                                   double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bs) out[i] = S[(int64_t)i * ld + i];
+}
+
+// S = 0.5 (S + S^T) is not needed: selected inversion keeps symmetry to rounding.
+
+// dense identity add: M[i][i] += 1
+__global__ void add_identity(double* __restrict__ M, int64_t ld, int bs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bs) M[(int64_t)i * ld + i] += 1.0;
+}
+
+// micro-benchmarks -------------------------------------------------------------------
+typedef double mb_v4d __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_f64_rate_kernel(double* out, int iters) {
+    mb_v4d a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0}, a3 = {0, 0, 0, 0};
+    const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+    }
+    const mb_v4d s = a0 + a1 + a2 + a3;
+    if (s[0] + s[1] + s[2] + s[3] == 12345.678) out[0] = s[0];
+}
+
+__global__ __launch_bounds__(256) void hbm_read_kernel(const double2* __restrict__ src, int64_t n16,
+                                                       double* out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = src[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 12345.678) out[0] = acc;
+}
+
+}  // namespace gmrf

@@ -1,0 +1,159 @@
+// Block-bidiagonal sweep kernels: one block step of
+//   forward_solve  (/root/reference/src/tridiagonal_cholesky.jl:43-52)   y_i = L_i^-1 (b_i - C_{i-1} y_{i-1})
+//   backward_solve (/root/reference/src/tridiagonal_cholesky.jl:24-33)   x_i = L_i^-T (y_i - C_i^T x_{i+1})
+// on the device-resident factor (dense row-major C_i and explicit lower-triangular
+// inverse Linv_i, so that a triangular solve is a matrix product and a block step is two
+// dependent launches instead of bs/64 of them).
+//
+// Right-hand sides live in a panel P[rhs][n_pad] (each right-hand side contiguous, the
+// column-major n x k layout of a Julia Matrix).  Two kernel families:
+//   * sweep_mm   : kp = multiple of 16 right-hand sides, v_mfma_f64_16x16x4_f64; one
+//                  16(rhs) x 16(rows) output tile per workgroup, its 4 waves split K, fixed
+//                  order LDS reduction (deterministic);
+//   * sweep_gemv : one right-hand side (posterior mean), pure HBM streaming of the block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.hpp"
+
+namespace gmrf {
+
+struct SweepArgs {
+    const double* Mat; int64_t ld;      // bs x bs row-major block (C_i or Linv_i)
+    const double* Xin; int64_t ldx;     // input vectors, one per rhs, stride ldx between rhs
+    const double* Bin; int64_t ldb;     // optional addend (Out = Bin - Mat*X when sub != 0)
+    double* Out; int64_t ldo;
+    int bs;
+    int sub;
+};
+
+// TRANS = false: out[m] = sum_k Mat[m][k] x[k]   (TRI: Mat lower triangular, k <= m)
+// TRANS = true : out[m] = sum_k Mat[k][m] x[k]   (TRI: Mat lower triangular, k >= m)
+template <bool TRANS, bool TRI>
+__global__ __launch_bounds__(256) void sweep_mm(SweepArgs s) {
+    const int m0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    int kb = 0, ke = s.bs;
+    if (TRI) {
+        if (!TRANS) ke = m0 + 16; else kb = m0;
+    }
+    // split [kb, ke) over the 4 waves in multiples of 8
+    const int total = ke - kb;
+    const int chunk = ((total / 4 + 7) / 8) * 8;
+    const int k_lo = kb + w * chunk;
+    const int k_hi = min(ke, k_lo + chunk);
+
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ xrow = s.Xin + (int64_t)(r0 + li) * s.ldx;
+    if (!TRANS) {
+        const double* __restrict__ mrow = s.Mat + (int64_t)(m0 + li) * s.ld;
+#pragma unroll 4
+        for (int k = k_lo; k < k_hi; k += 8) {
+            const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
+            const v2d b = *reinterpret_cast<const v2d*>(mrow + k + 2 * lq);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc, 0, 0, 0);
+        }
+    } else {
+        const double* __restrict__ mcol = s.Mat + m0 + li;
+#pragma unroll 4
+        for (int k = k_lo; k < k_hi; k += 8) {
+            const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
+            const double b0 = mcol[(int64_t)(k + 2 * lq) * s.ld];
+            const double b1 = mcol[(int64_t)(k + 2 * lq + 1) * s.ld];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc, 0, 0, 0);
+        }
+    }
+    __shared__ double red[4][256];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][r * 64 + lane] = acc[r];
+    __syncthreads();
+    // element t of the 16x16 tile: reg = t >> 6, lane' = t & 63 -> rhs = (lane' >> 4) + 4 reg, m = lane' & 15
+    const double sum = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    const int rhs = ((t & 63) >> 4) + 4 * (t >> 6);
+    const int m = t & 15;
+    double v = sum;
+    if (s.sub) v = s.Bin[(int64_t)(r0 + rhs) * s.ldb + m0 + m] - sum;
+    s.Out[(int64_t)(r0 + rhs) * s.ldo + m0 + m] = v;
+}
+
+// One right-hand side, non-transposed: one wave per row, 16-byte loads along the row.
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= s.bs) return;
+    const int ke = TRI ? (row + 1) : s.bs;
+    const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
+    const double* __restrict__ x = s.Xin;
+    double sum0 = 0.0, sum1 = 0.0;
+    const int ke2 = ke & ~1;
+    for (int k = lane * 2; k < ke2; k += 128) {
+        const v2d mv = *reinterpret_cast<const v2d*>(mrow + k);
+        const v2d xv = *reinterpret_cast<const v2d*>(x + k);
+        sum0 = fma(mv.x, xv.x, sum0);
+        sum1 = fma(mv.y, xv.y, sum1);
+    }
+    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], x[ke - 1], sum0);
+    double sum = sum0 + sum1;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) {
+        double v = sum;
+        if (s.sub) v = s.Bin[row] - sum;
+        s.Out[row] = v;
+    }
+}
+
+// One right-hand side, transposed: a workgroup owns 16 adjacent output columns (one 128-byte
+// line per matrix row); thread (c = t & 15, g = t >> 4) walks rows g, g+16, ...; fixed-order
+// LDS reduction over the 16 row groups.
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
+    const int t = threadIdx.x;
+    const int c = t & 15, gidx = t >> 4;
+    const int col0 = blockIdx.x * 16;
+    const int kb = TRI ? col0 : 0;          // lower triangular: rows >= column
+    const double* __restrict__ x = s.Xin;
+    const double* __restrict__ mp = s.Mat + col0 + c;
+    double sum = 0.0;
+#pragma unroll 8
+    for (int k = kb + gidx; k < s.bs; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
+    __shared__ double red[16][17];
+    red[gidx][c] = sum;
+    __syncthreads();
+    if (t < 16) {
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tot += red[i][t];
+        double v = tot;
+        if (s.sub) v = s.Bin[col0 + t] - tot;
+        s.Out[col0 + t] = v;
+    }
+}
+
+inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s) {
+    if (kp == 1) {
+        if (!trans) {
+            dim3 grid((s.bs + 3) / 4), block(256);
+            if (tri) hipLaunchKernelGGL((sweep_gemv_n<true>), grid, block, 0, st, s);
+            else hipLaunchKernelGGL((sweep_gemv_n<false>), grid, block, 0, st, s);
+        } else {
+            dim3 grid(s.bs / 16), block(256);
+            if (tri) hipLaunchKernelGGL((sweep_gemv_t<true>), grid, block, 0, st, s);
+            else hipLaunchKernelGGL((sweep_gemv_t<false>), grid, block, 0, st, s);
+        }
+    } else {
+        dim3 grid(s.bs / 16, kp / 16), block(256);
+        if (!trans && !tri) hipLaunchKernelGGL((sweep_mm<false, false>), grid, block, 0, st, s);
+        else if (!trans && tri) hipLaunchKernelGGL((sweep_mm<false, true>), grid, block, 0, st, s);
+        else if (trans && !tri) hipLaunchKernelGGL((sweep_mm<true, false>), grid, block, 0, st, s);
+        else hipLaunchKernelGGL((sweep_mm<true, true>), grid, block, 0, st, s);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gmrf

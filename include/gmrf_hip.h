@@ -1,0 +1,210 @@
+/*
+ * gmrf_hip.h -- C ABI of libgmrf_hip.so: MI355X (gfx950) block-tridiagonal Cholesky
+ * factor / solve / sample path for GMRF posteriors.
+ *
+ * Drop-in boundary for ONE path of timweiland/DiffEqGMRFs.jl (all citations relative to
+ * /root/reference):
+ *     src/tridiagonal_cholesky.jl   tridiagonal_cholesky :65-82, forward_solve :43-52,
+ *                                   backward_solve :24-33, ldiv!/ldiv :54-63,
+ *                                   TridiagonalCholeskyFactor :5-9
+ *     scripts/solve_burger.jl       extract_blocks :182-254 (block input form)
+ *     SpMV call sites               scripts/solve_burger.jl:157-158,166,177 (Q * x)
+ * The reference has no FFI of its own (pure Julia); these are the entry points a
+ * `ccall` shim binds (julia/DiffEqGMRFsHIP.jl).
+ *
+ * Conventions
+ *   - every function returns a gmrf_status (0 = OK, negative = error class);
+ *   - no C++ types, no exceptions, no torch types cross this boundary;
+ *   - data pointers (`double*`, `float*`) may be HOST or DEVICE pointers; the library asks
+ *     the HIP runtime which (hipPointerGetAttributes) and stages host data itself;
+ *   - matrices of right-hand sides are column-major n x k with leading dimension ld >= n
+ *     (Julia Matrix{Float64} layout);
+ *   - one handle = one GPU + one HIP stream; a handle is used by one host thread at a time;
+ *   - calls are synchronous at return unless the name ends in _async.
+ */
+#ifndef GMRF_HIP_H
+#define GMRF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int32_t gmrf_status;
+
+enum {
+    GMRF_OK = 0,
+    GMRF_ERR_NOT_SPD = -1,     /* Julia PosDefException: *info = failing block (1-based)   */
+    GMRF_ERR_BAD_SHAPE = -2,   /* n % N_blocks != 0, k <= 0, ld < n, null pointer ...       */
+    GMRF_ERR_BAND = -3,        /* an entry lies outside the block tri-band of the partition */
+    GMRF_ERR_HIP = -4,         /* a HIP runtime call failed (gmrf_last_error has the text)  */
+    GMRF_ERR_NO_FACTOR = -5,   /* solve/sample before a successful factor                    */
+    GMRF_ERR_NO_DEVICE = -6,   /* no gfx950 device visible                                   */
+    GMRF_ERR_ALLOC = -7
+};
+
+enum { GMRF_SOLVE_FULL = 0, GMRF_SOLVE_FORWARD = 1, GMRF_SOLVE_BACKWARD = 2 };
+enum { GMRF_VAR_EXACT = 0, GMRF_VAR_RBMC = 1, GMRF_VAR_MC = 2 };
+enum { GMRF_BLOCK_L = 0, GMRF_BLOCK_C = 1, GMRF_BLOCK_LINV = 2 };
+
+typedef struct gmrf_handle gmrf_handle;   /* block-tridiagonal factor context  */
+typedef struct gmrf_csr gmrf_csr;         /* device-resident CSR matrix (K6)   */
+
+/* One sparse block in compressed-sparse-row or -column form, as extract_blocks
+ * (scripts/solve_burger.jl:240-247) returns them: `ptr` has dim+1 entries. */
+typedef struct {
+    int64_t nnz;
+    const int64_t* ptr;
+    const int64_t* idx;
+    const double* val;
+} gmrf_sparse_block;
+
+/* Per-phase statistics of the last calls on a handle (gmrf_bt_stats). */
+typedef struct {
+    double factor_ms;          /* last gmrf_bt_factor_*                                     */
+    double solve_ms;           /* last gmrf_bt_solve (device part)                          */
+    double sample_ms;          /* last gmrf_bt_sample                                       */
+    double factor_flops;       /* N bs^3/3 + (N-1) 2 bs^3 (LAPACK counts, logical bs)       */
+    double sweep_bytes;        /* 8 [N bs(bs+1)/2 + (N-1) bs^2] + 16 n k of the last sweep   */
+    double sweep_ms;           /* duration of the last single sweep                         */
+    int64_t n, n_blocks, block_size, block_size_padded;
+    int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
+    /* per-kernel accounting filled when profiling is on (gmrf_bt_set_profiling):           */
+    double gemm_ms, gemm_flops;  int64_t gemm_launches;    /* dense MFMA f64 GEMM kernel     */
+    double tile_ms;              int64_t tile_launches;    /* 64x64 potrf + inverse kernel   */
+    double sweep_kernel_ms, sweep_kernel_bytes; int64_t sweep_launches;
+} gmrf_stats;
+
+/* ------------------------------------------------------------------ life cycle */
+
+/* device >= 0: HIP device ordinal.  stream: a hipStream_t to run on (e.g. the caller's
+ * PyTorch stream) or NULL to let the handle create its own. */
+gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out);
+gmrf_status gmrf_bt_destroy(gmrf_handle* h);
+const char* gmrf_last_error(void);
+int32_t gmrf_version(void);
+
+/* ------------------------------------------------------------------ factor
+ * tridiagonal_cholesky(A::SparseMatrixCSC, N_blocks)  (src/tridiagonal_cholesky.jl:65-82).
+ * colptr/rowval/nzval are the SparseMatrixCSC fields (index_base = 1 from Julia, 0 from
+ * SciPy).  Only entries in the lower blocks (i,i) and (i,i-1) are used, as in the
+ * reference (:73,:76); the (i,i+1) blocks are ignored; anything further out is
+ * GMRF_ERR_BAND.  The factor stays resident on the device inside `h`. */
+gmrf_status gmrf_bt_factor_csc(gmrf_handle* h, int64_t n, int64_t n_blocks,
+                               const int64_t* colptr, const int64_t* rowval,
+                               const double* nzval, int32_t index_base, int32_t* info);
+
+/* Same from the output of extract_blocks (scripts/solve_burger.jl:182-254): n_blocks
+ * diagonal blocks and n_blocks-1 lower off-diagonal blocks, each block_size square, CSC
+ * (compressed by column, like SparseMatrixCSC) when `compressed_by_column` != 0. */
+gmrf_status gmrf_bt_factor_blocks(gmrf_handle* h, int64_t n, int64_t n_blocks,
+                                  const gmrf_sparse_block* diag,
+                                  const gmrf_sparse_block* lower,
+                                  int32_t index_base, int32_t compressed_by_column,
+                                  int32_t* info);
+
+/* Re-run the factorisation with new values on the SAME sparsity pattern as the last
+ * gmrf_bt_factor_csc (Gauss-Newton loop, scripts/solve_burger.jl:143-149). */
+gmrf_status gmrf_bt_refactor_values(gmrf_handle* h, const double* nzval, int32_t* info);
+
+/* ------------------------------------------------------------------ solves
+ * mode FULL:     y = A^-1 b           ldiv!/ldiv      (:54-63)
+ * mode FORWARD:  y = L^-1 b           forward_solve   (:43-52)
+ * mode BACKWARD: y = L^-T b           backward_solve  (:24-33)
+ * b, y: n x k column-major, leading dimension ld; b == y allowed. */
+gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
+                          int64_t ld, int32_t mode);
+
+/* k samples  x_s = mean + L^-T z_s  (rand(rng, x_cond), solve_darcy_gmrf-fem.jl:191).
+ * z == NULL: z_s[dof] is Philox4x32-10(key = seed, counter = (dof, first_id + s)) through
+ * Box-Muller, independent of GPU count and launch geometry.  z != NULL: n x k column-major
+ * standard normals supplied by the caller (parity mode).  mean may be NULL (zero). */
+gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k,
+                           const double* mean, const double* z, double* out, int64_t ld);
+
+/* The N(0,1) draws gmrf_bt_sample would use (for tests and for callers that need z). */
+gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k,
+                            double* z, int64_t ld);
+
+/* Marginal variances diag(A^-1)  (std(x_cond), solve_darcy_gmrf-fem.jl:192).
+ * EXACT: block-tridiagonal selected inversion (deterministic).
+ * RBMC:  Rao-Blackwellised Monte Carlo over k Philox samples, needs Q (the factored matrix).
+ * MC:    plain Monte Carlo over k samples. */
+gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed,
+                                 const gmrf_csr* Q, double* var_out);
+
+/* Accumulators for sharded variance estimation: adds this rank's contribution of samples
+ * [first_id, first_id + k) to acc (length n; RBMC: sum of squared off-diagonal terms,
+ * MC: sum of squares).  The caller all-reduces acc and finishes with
+ * var = 1/Q_ii + acc / K_total (RBMC) or acc / K_total (MC). */
+gmrf_status gmrf_bt_var_accumulate(gmrf_handle* h, int32_t method, int64_t first_id,
+                                   int64_t k, uint64_t seed, const gmrf_csr* Q,
+                                   double* acc);
+
+/* logdet(A) = 2 sum_i sum_j log (L_i)_jj. */
+gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out);
+
+/* ------------------------------------------------------------------ factor access
+ * Copy one dense block of the factor to `out` (block_size x block_size, column-major,
+ * leading dimension ld):  kind L -> chos[i].L, kind C -> Cs[i] (= L_{i+2,i+1} in 1-based
+ * block numbering; i in [0, n_blocks-1)), kind LINV -> inv(chos[i].L).  i is 0-based. */
+gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* out,
+                              int64_t ld);
+
+/* Device buffers of the factor, the unit of the RCCL broadcast: kind L / C / LINV gives
+ * the base pointer and byte count of that contiguous array of padded row-major blocks. */
+gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr,
+                                  int64_t* bytes);
+
+/* Allocate factor storage for a given shape WITHOUT factoring (a rank that receives the
+ * factor by broadcast), then mark it valid once the buffers have been filled. */
+gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks);
+gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h);
+
+/* Pipelined factorisation (factor block ranges so a broadcast of finished blocks can
+ * overlap): begin uploads the matrix, step_async enqueues blocks [i0, i1) and returns,
+ * end synchronises and reports SPD failures. */
+gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks,
+                                     const int64_t* colptr, const int64_t* rowval,
+                                     const double* nzval, int32_t index_base);
+gmrf_status gmrf_bt_factor_step_async(gmrf_handle* h, int64_t i0, int64_t i1);
+gmrf_status gmrf_bt_factor_end(gmrf_handle* h, int32_t* info);
+
+gmrf_status gmrf_bt_stats(gmrf_handle* h, gmrf_stats* out);
+gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
+/* 0: replay captured HIP graphs (default); 1: plain stream launches. */
+gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
+gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
+
+/* ------------------------------------------------------------------ K6: CSR SpMV / SpMM
+ * Device-resident sparse matrix built from CSR arrays (rowptr has n_rows+1 entries) --
+ * or, for a symmetric matrix, from the CSC arrays of the same matrix.  values_f32 != 0
+ * stores the values in fp32 and accumulates in fp64 (BASELINE config 5). */
+gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_t n_cols,
+                            const int64_t* rowptr, const int64_t* colidx,
+                            const double* vals, int32_t index_base, int32_t values_f32,
+                            gmrf_csr** out);
+gmrf_status gmrf_csr_destroy(gmrf_csr* m);
+/* Y = S X ;  X: n_cols x k, Y: n_rows x k, column-major with leading dimensions ldx, ldy. */
+gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k,
+                      int64_t ldx, int64_t ldy);
+
+/* ------------------------------------------------------------------ test hooks
+ * Direct access to the dense device kernels for the parity tests (row-major operands on
+ * the HOST; not part of the drop-in surface). */
+gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int32_t transA,
+                           int32_t transB, int32_t tri_flags, int32_t lower_only,
+                           double alpha, const double* A, int64_t lda, const double* B,
+                           int64_t ldb, double beta, double* C, int64_t ldc);
+gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64 /* in: SPD, out: L */,
+                                 double* inv64, int32_t* info);
+gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/out: L */,
+                                  double* Linv, int32_t* info);
+gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
+gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMRF_HIP_H */

@@ -1,0 +1,256 @@
+"""ORACLE (test infrastructure, never shipped, never on the measured GPU path).
+
+CPU restatement, in NumPy/SciPy (LAPACK-backed like Julia's LinearAlgebra), of the
+block-tridiagonal Cholesky path of timweiland/DiffEqGMRFs.jl:
+
+    /root/reference/src/tridiagonal_cholesky.jl      (factor :65-82, sweeps :24-33, :43-52,
+                                                      chunking :11-14, ldiv :54-63)
+    /root/reference/scripts/solve_burger.jl:182-254  (extract_blocks)
+
+PARITY UNPINNED: the reference cannot be executed here (no Julia toolchain, the GMRF
+dependency is un-vendored and unpinned) and its test-suite holds no golden vector or
+known-answer test for this path (test/runtests.jl:5-9 is Aqua only).  The oracle is
+therefore pinned by (i) mathematical identities, (ii) independent solvers
+(scipy dense Cholesky / SuperLU) and (iii) closed-form cases -- see tests/test_oracle.py.
+
+The three defects of the reference's solve half (`L.u`, assigning
+Vectors into a Vector{SubArray}, returning chunks instead of a flat vector) are corrected
+to the evident intent  y = L^-T L^-1 b ; everything else follows the source line by line.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+
+@dataclass
+class TridiagonalCholeskyFactor:
+    """src/tridiagonal_cholesky.jl:5-9.  `N` is the TOTAL size n (not the block count);
+    `chos[i]` is the lower Cholesky factor L_i of the i-th Schur complement (Julia stores
+    U = L_i^T; same numbers), `Cs[i]` = L_{i+1,i} = B_{i+1} L_i^-T."""
+
+    N: int
+    chos: List[np.ndarray]
+    Cs: List[np.ndarray]
+
+    @property
+    def n_blocks(self) -> int:
+        return len(self.chos)
+
+    @property
+    def block_size(self) -> int:
+        return self.chos[0].shape[0]
+
+
+def make_chunks(X: np.ndarray, n: int):
+    """src/tridiagonal_cholesky.jl:11-14: n contiguous views of length len//n, the last one
+    absorbing the remainder."""
+    c = X.shape[0] // n
+    return [X[c * k:(X.shape[0] if k == n - 1 else c * k + c)] for k in range(n)]
+
+
+def _chol_forward(L: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """forward_solve(::Cholesky, b) = L.L \\ b  (:35-37)."""
+    return sla.solve_triangular(L, b, lower=True, check_finite=False)
+
+
+def _chol_backward(L: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """backward_solve(::Cholesky, b) = L.U \\ b  (:16-18, `L.u` defect corrected)."""
+    return sla.solve_triangular(L, b, lower=True, trans="T", check_finite=False)
+
+
+class NotPositiveDefinite(Exception):
+    """Julia's PosDefException; `.block` is the 1-based block index that failed."""
+
+    def __init__(self, block: int):
+        super().__init__(f"block {block} is not positive definite")
+        self.block = block
+
+
+def tridiagonal_cholesky(A, N_blocks: int) -> TridiagonalCholeskyFactor:
+    """src/tridiagonal_cholesky.jl:65-82.  Reads only the lower blocks (i,i) and (i,i-1)."""
+    A = sp.csc_matrix(A)
+    n = A.shape[0]
+    bs = n // N_blocks                                   # :66
+    if bs * N_blocks != n:
+        raise ValueError("size(A,1) must be divisible by N_blocks")
+    A = A.tocsr()
+
+    def dense(r0, c0):
+        return A[r0:r0 + bs, c0:c0 + bs].toarray()
+
+    def chol(M, blk):
+        try:
+            return sla.cholesky(M, lower=True, check_finite=False)
+        except sla.LinAlgError:
+            raise NotPositiveDefinite(blk) from None
+
+    chos = [chol(dense(0, 0), 1)]                        # :67
+    Cs = []
+    for i in range(1, N_blocks):                         # :70
+        r0 = i * bs
+        B = dense(r0, r0 - bs)                           # :73
+        C = _chol_forward(chos[-1], B.T).T               # :74
+        Cs.append(C)                                     # :75
+        D = dense(r0, r0)                                # :76
+        chos.append(chol(D - C @ C.T, i + 1))            # :77
+    return TridiagonalCholeskyFactor(n, chos, Cs)
+
+
+def forward_solve(F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
+    """y = L^-1 b  (:43-52).  b is (n,) or (n,k); returns the flat result."""
+    N = F.n_blocks
+    bch = make_chunks(b, N)
+    x = [None] * N
+    x[0] = _chol_forward(F.chos[0], bch[0])                                     # :47
+    for i in range(1, N):
+        x[i] = _chol_forward(F.chos[i], bch[i] - F.Cs[i - 1] @ x[i - 1])        # :49
+    return np.concatenate(x, axis=0)
+
+
+def backward_solve(F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
+    """x = L^-T b  (:24-33)."""
+    N = F.n_blocks
+    bch = make_chunks(b, N)
+    x = [None] * N
+    x[N - 1] = _chol_backward(F.chos[N - 1], bch[N - 1])                        # :28
+    for i in range(N - 2, -1, -1):
+        x[i] = _chol_backward(F.chos[i], bch[i] - F.Cs[i].T @ x[i + 1])         # :30
+    return np.concatenate(x, axis=0)
+
+
+def ldiv(F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
+    """:60-63."""
+    return backward_solve(F, forward_solve(F, b))
+
+
+def ldiv_(y: np.ndarray, F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
+    """ldiv!(y, L, b)  (:54-58)."""
+    y[...] = ldiv(F, b)
+    return y
+
+
+def logdet(F: TridiagonalCholeskyFactor) -> float:
+    """2 sum log diag(L_i)  (the way the scripts get log-determinants from a Cholesky,
+    scripts/burgers/solve_burgers_gmrf-collocation.jl:208-211)."""
+    return 2.0 * float(sum(np.log(np.diag(L)).sum() for L in F.chos))
+
+
+def extract_blocks(I, J, V, block_size: int):
+    """scripts/solve_burger.jl:182-254 on 1-based COO triplets: stable sort by row, keep an
+    entry when its column is in the same block range (diagonal block) or in the previous
+    one (lower off-diagonal block); every other entry is dropped, as in the reference.
+    Returns (diag_blocks, off_diag_blocks) as CSC matrices with duplicates summed."""
+    I = np.asarray(I, dtype=np.int64)
+    J = np.asarray(J, dtype=np.int64)
+    V = np.asarray(V)
+    p = np.argsort(I, kind="stable")                      # :183
+    I, J, V = I[p], J[p], V[p]
+    diag, off = [], []
+    cur = ([], [], [])
+    curo = ([], [], [])
+    lo = 1                                                # cur_diag_block_range = lo:lo+bs-1
+    for idx in range(I.shape[0]):
+        i = int(I[idx])
+        while i > lo + block_size - 1:                    # :205
+            diag.append(cur)
+            if lo - block_size > 0:                       # cur_off_diag_block_range[1] > 0
+                off.append(curo)
+            cur = ([], [], [])
+            curo = ([], [], [])
+            lo += block_size
+        j = int(J[idx])
+        if lo <= j <= lo + block_size - 1:                # :228
+            cur[0].append(i - lo); cur[1].append(j - lo); cur[2].append(V[idx])
+        if lo - block_size <= j <= lo - 1:                # :234
+            curo[0].append(i - lo); curo[1].append(j - (lo - block_size)); curo[2].append(V[idx])
+    diag.append(cur)
+    if lo - block_size > 0:
+        off.append(curo)
+
+    def mk(t):
+        return sp.coo_matrix((np.asarray(t[2], dtype=V.dtype), (t[0], t[1])),
+                             shape=(block_size, block_size)).tocsc()
+
+    return [mk(t) for t in diag], [mk(t) for t in off]
+
+
+# ----------------------------------------------------------------------------- posterior use
+
+def posterior_mean(F: TridiagonalCholeskyFactor, rhs: np.ndarray) -> np.ndarray:
+    """mean(x_cond) = Q_post^-1 (information vector)  (solve_darcy_gmrf-fem.jl:190)."""
+    return ldiv(F, rhs)
+
+
+def sample(F: TridiagonalCholeskyFactor, mean: np.ndarray, Z: np.ndarray) -> np.ndarray:
+    """rand(rng, x_cond) = mean + L^-T z  (solve_darcy_gmrf-fem.jl:191)."""
+    X = backward_solve(F, Z)
+    return X + (mean[:, None] if Z.ndim == 2 else mean)
+
+
+def marginal_variances_exact(F: TridiagonalCholeskyFactor) -> np.ndarray:
+    """diag(A^-1) by block-tridiagonal selected inversion:
+    S_NN = L_N^-T L_N^-1,  S_ii = L_i^-T (I + C_i^T S_{i+1,i+1} C_i) L_i^-1   (C_i = Cs[i])."""
+    N, bs = F.n_blocks, F.block_size
+    out = np.empty(F.N)
+    eye = np.eye(bs)
+    Li = _chol_forward(F.chos[N - 1], eye)
+    S = Li.T @ Li
+    out[(N - 1) * bs:] = np.diag(S)
+    for i in range(N - 2, -1, -1):
+        C = F.Cs[i]
+        Li = _chol_forward(F.chos[i], eye)
+        S = Li.T @ (eye + C.T @ S @ C) @ Li
+        S = 0.5 * (S + S.T)
+        out[i * bs:(i + 1) * bs] = np.diag(S)
+    return out
+
+
+def marginal_variances_rbmc(Q, X: np.ndarray) -> np.ndarray:
+    """Rao-Blackwellised Monte-Carlo variances from centred samples X (n x S):
+    var_i ~ 1/Q_ii + mean_s ( (1/Q_ii) sum_{j != i} Q_ij x_j^(s) )^2
+    (RBMCStrategy of GaussianMarkovRandomFields.jl, solve_darcy_gmrf-fem.jl:100,192)."""
+    Q = sp.csr_matrix(Q)
+    d = Q.diagonal()
+    QX = Q @ X
+    off = (QX - d[:, None] * X) / d[:, None]
+    return 1.0 / d + np.mean(off * off, axis=1)
+
+
+def marginal_variances_mc(X: np.ndarray) -> np.ndarray:
+    """Plain Monte-Carlo variances from centred samples."""
+    return np.mean(X * X, axis=1)
+
+
+# ----------------------------------------------------------------------------- helpers
+
+def reconstruct(F: TridiagonalCholeskyFactor) -> np.ndarray:
+    """Dense L L^T from the block factor (tests only, small n)."""
+    N, bs = F.n_blocks, F.block_size
+    L = np.zeros((F.N, F.N))
+    for i in range(N):
+        L[i * bs:(i + 1) * bs, i * bs:(i + 1) * bs] = F.chos[i]
+        if i > 0:
+            L[i * bs:(i + 1) * bs, (i - 1) * bs:i * bs] = F.Cs[i - 1]
+    return L @ L.T
+
+
+def rmse(pred, soln):
+    """src/metrics.jl:3-5."""
+    return float(np.sqrt(np.mean((pred - soln) ** 2)))
+
+
+def max_err(pred, soln):
+    """src/metrics.jl:7-9."""
+    return float(np.max(np.abs(pred - soln)))
+
+
+def rel_err(pred, soln):
+    """src/metrics.jl:11-13."""
+    return float(np.linalg.norm(pred - soln) / np.linalg.norm(soln))

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path through the C ABI against the oracle (oracle/bt_oracle.py)
+on the same seeded inputs.  fp64 tolerances are stated per test; they are relative l2 unless
+noted, and sized from cond(Q) ~ 1e7 (darcy) * eps."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import bt_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_FACTOR = 1e-11     # max-abs / max-abs on factor blocks
+TOL_SOLVE = 1e-10      # BASELINE.md parity gate: posterior mean rel l2 <= 1e-10
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(np.asarray(b)))
+
+
+@pytest.fixture(scope="module", params=["darcy32", "darcy64", "burgers64x8", "elliptic32"])
+def case(request, pkg):
+    w = pkg.workloads.make(request.param)
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    return w, F, Fo
+
+
+def test_factor_blocks_match(case):
+    w, F, Fo = case
+    assert F.N == Fo.N and len(F.chos) == len(Fo.chos) and len(F.Cs) == len(Fo.Cs)
+    for i in range(0, w.n_blocks, max(1, w.n_blocks // 5)):
+        L = F.chos[i]
+        assert np.max(np.abs(np.tril(L) - Fo.chos[i])) / np.max(np.abs(Fo.chos[i])) < TOL_FACTOR
+        assert np.allclose(np.triu(L, 1), 0.0)
+        if i < w.n_blocks - 1:
+            assert np.max(np.abs(F.Cs[i] - Fo.Cs[i])) / np.max(np.abs(Fo.Cs[i])) < TOL_FACTOR
+
+
+def test_mean_and_half_solves(case, pkg):
+    w, F, Fo = case
+    mu = pkg.ldiv(F, w.rhs)
+    assert rel(mu, O.ldiv(Fo, w.rhs)) < TOL_SOLVE
+    assert rel(pkg.forward_solve(F, w.rhs), O.forward_solve(Fo, w.rhs)) < TOL_SOLVE
+    assert rel(pkg.backward_solve(F, w.rhs), O.backward_solve(Fo, w.rhs)) < TOL_SOLVE
+    r = w.Q @ mu - w.rhs
+    qn = abs(w.Q).sum(axis=1).max()
+    assert np.linalg.norm(r) / (qn * np.linalg.norm(mu) + np.linalg.norm(w.rhs)) < 1e-14
+    y = np.empty_like(w.rhs)
+    assert pkg.ldiv_(y, F, w.rhs) is y and rel(y, mu) == 0.0
+
+
+@pytest.mark.parametrize("k", [2, 16, 33, 64])
+def test_matrix_right_hand_sides(case, pkg, k):
+    w, F, Fo = case
+    B = np.random.default_rng(k).standard_normal((w.n, k))
+    assert rel(pkg.ldiv(F, B), O.ldiv(Fo, B)) < TOL_SOLVE
+    assert rel(pkg.backward_solve(F, B), O.backward_solve(Fo, B)) < TOL_SOLVE
+    assert rel(pkg.forward_solve(F, B), O.forward_solve(Fo, B)) < TOL_SOLVE
+
+
+def test_samples_with_given_z_and_logdet(case, pkg):
+    w, F, Fo = case
+    mu_o = O.ldiv(Fo, w.rhs)
+    Z = np.random.default_rng(3).standard_normal((w.n, 24))
+    X = F.sample(24, mean=mu_o, z=Z)
+    assert rel(X, O.sample(Fo, mu_o, Z)) < TOL_SOLVE
+    assert abs(F.logdet() - O.logdet(Fo)) < 1e-9 * abs(O.logdet(Fo))
+
+
+def test_exact_marginal_variances(case, pkg):
+    w, F, Fo = case
+    v = F.marginal_var("exact")
+    vo = O.marginal_variances_exact(Fo)
+    assert np.max(np.abs(v - vo) / vo) < 1e-9          # exact variances rel <= 1e-9
+    if w.n <= 1024:
+        vd = np.diag(np.linalg.inv(w.Q.toarray()))
+        assert np.max(np.abs(v - vd) / vd) < 1e-7
+
+
+def test_rbmc_and_mc_variances_with_device_philox(case, pkg):
+    w, F, Fo = case
+    Q = pkg.CsrMatrix(w.Q)
+    k = 48
+    Z = F.normals(k, seed=77)
+    X = O.backward_solve(Fo, Z)
+    v_rbmc = F.marginal_var("rbmc", k=k, seed=77, Q=Q)
+    v_mc = F.marginal_var("mc", k=k, seed=77)
+    assert np.max(np.abs(v_rbmc - O.marginal_variances_rbmc(w.Q, X)) / v_rbmc) < 1e-8
+    assert np.max(np.abs(v_mc - O.marginal_variances_mc(X)) / v_mc) < 1e-8
+    # sharded accumulation (two "ranks") gives the same estimator
+    acc = np.zeros(w.n)
+    F.var_accumulate(acc, "mc", 0, 20, seed=77)
+    F.var_accumulate(acc, "mc", 20, 28, seed=77)
+    assert np.max(np.abs(acc / k - v_mc) / v_mc) < 1e-12
+
+
+def test_philox_normals_are_geometry_independent_and_standard(pkg):
+    w = pkg.workloads.make("darcy32")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Z = F.normals(40, seed=5)
+    Z2 = F.normals(8, seed=5, first_id=16)
+    assert np.array_equal(Z[:, 16:24], Z2)              # keyed by (seed, sample id, dof) only
+    assert abs(Z.mean()) < 0.02 and abs(Z.std() - 1.0) < 0.02
+    from tests.philox_ref import philox_normal
+    ref = np.array([[philox_normal(5, d, s) for s in (0, 7)] for d in (0, 1, 1023)])
+    assert np.max(np.abs(Z[[0, 1, 1023]][:, [0, 7]] - ref)) < 1e-13
+
+
+def test_spmm_fp64_and_fp32_values(pkg):
+    w = pkg.workloads.make("darcy32")
+    X = np.random.default_rng(1).standard_normal((w.n, 5))
+    Q = pkg.CsrMatrix(w.Q)
+    assert rel(Q @ X, w.Q @ X) < 1e-14
+    assert rel(Q @ X[:, 0], w.Q @ X[:, 0]) < 1e-14
+    Q32 = pkg.CsrMatrix(w.Q, values_f32=True)
+    ref32 = sp.csr_matrix((w.Q.tocsr().data.astype(np.float32).astype(np.float64), w.Q.tocsr().indices,
+                           w.Q.tocsr().indptr), shape=w.Q.shape) @ X
+    assert rel(Q32 @ X, ref32) < 1e-14
+
+
+def test_refactor_values_same_pattern(pkg):
+    w = pkg.workloads.make("darcy32")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Q2 = w.Q.copy()
+    Q2.data = Q2.data * 1.5
+    F.refactor(Q2.data)
+    assert rel(pkg.ldiv(F, w.rhs), O.ldiv(O.tridiagonal_cholesky(Q2, w.n_blocks), w.rhs)) < TOL_SOLVE
+
+
+def test_eager_and_graph_paths_agree_bitwise(pkg):
+    w = pkg.workloads.make("darcy32")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    a = pkg.ldiv(F, w.rhs)
+    F.set_eager(True)
+    F.refactor(w.Q.data)
+    b = pkg.ldiv(F, w.rhs)
+    assert np.array_equal(a, b)
+
+
+def test_extract_blocks_route_and_padding(pkg):
+    # block size 40 is padded to 64 inside the library; blocks come from extract_blocks
+    w = pkg.workloads.random_block_tridiagonal(5, 40, seed=3)
+    coo = w.Q.tocoo()
+    d, o = pkg.extract_blocks(coo.row + 1, coo.col + 1, coo.data, 40)
+    do, oo = O.extract_blocks(coo.row + 1, coo.col + 1, coo.data, 40)
+    assert all((a != b).nnz == 0 for a, b in zip(d, do)) and all((a != b).nnz == 0 for a, b in zip(o, oo))
+    F = pkg.TridiagonalCholeskyFactor().factor_blocks(d, o)
+    Fo = O.tridiagonal_cholesky(w.Q, 5)
+    assert rel(pkg.ldiv(F, w.rhs), O.ldiv(Fo, w.rhs)) < 1e-12
+    assert np.max(np.abs(np.tril(F.chos[4]) - Fo.chos[4])) < 1e-12
+
+
+def test_error_paths(pkg):
+    w = pkg.workloads.random_block_tridiagonal(4, 64, seed=1)
+    with pytest.raises(ValueError):
+        pkg.tridiagonal_cholesky(w.Q, 3)                       # n % N != 0
+    bad = w.Q.tolil(); bad[200, 10] = 1.0; bad[10, 200] = 1.0
+    with pytest.raises(pkg.GmrfError) as e:
+        pkg.tridiagonal_cholesky(bad.tocsc(), 4)               # outside the tri-band
+    assert e.value.status == pkg._cabi.ERR_BAND
+    ns = w.Q.tolil(); ns[130, 130] = -50.0
+    with pytest.raises(pkg.NotPositiveDefinite) as e:
+        pkg.tridiagonal_cholesky(ns.tocsc(), 4)
+    assert e.value.info == 3                                   # 1-based failing block
+    with pytest.raises(O.NotPositiveDefinite) as eo:
+        O.tridiagonal_cholesky(ns.tocsc(), 4)
+    assert eo.value.block == 3
+    F = pkg.TridiagonalCholeskyFactor()
+    F.N = 256
+    with pytest.raises(pkg.GmrfError):
+        pkg.ldiv(F, np.zeros(256))                             # solve before factor
+
+
+def test_degenerate_shapes(pkg):
+    # N = 1 (plain dense Cholesky) and a long chain of small blocks
+    w1 = pkg.workloads.random_block_tridiagonal(1, 128, seed=2)
+    F1 = pkg.tridiagonal_cholesky(w1.Q, 1)
+    assert rel(pkg.ldiv(F1, w1.rhs), np.linalg.solve(w1.Q.toarray(), w1.rhs)) < 1e-12
+    w2 = pkg.workloads.random_block_tridiagonal(40, 8, seed=4)
+    F2 = pkg.tridiagonal_cholesky(w2.Q, 40)
+    assert rel(pkg.ldiv(F2, w2.rhs), O.ldiv(O.tridiagonal_cholesky(w2.Q, 40), w2.rhs)) < 1e-12
+
+
+def test_torch_device_resident_io(pkg):
+    import torch
+    w = pkg.workloads.make("darcy32")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    b = torch.from_numpy(w.rhs).cuda()
+    mu = pkg.ldiv(F, b)
+    assert mu.is_cuda and rel(mu.cpu().numpy(), pkg.ldiv(F, w.rhs)) == 0.0
+    X = F.sample(16, mean=mu, seed=9, like=b)
+    assert X.is_cuda and X.shape == (w.n, 16)
+    Xh = F.sample(16, mean=mu.cpu().numpy(), seed=9)
+    assert np.array_equal(X.cpu().numpy(), Xh)
