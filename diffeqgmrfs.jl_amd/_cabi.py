@@ -25,12 +25,12 @@ EXPORTS = [
     "gmrf_bt_factor_csc", "gmrf_bt_factor_blocks", "gmrf_bt_refactor_values",
     "gmrf_bt_solve", "gmrf_bt_sample", "gmrf_bt_normals", "gmrf_bt_marginal_var",
     "gmrf_bt_var_accumulate", "gmrf_bt_logdet", "gmrf_bt_get_block", "gmrf_bt_factor_buffer",
-    "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_factor_begin_csc",
+    "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
     "gmrf_test_gemm", "gmrf_test_potrf_tile", "gmrf_test_potrf_block",
-    "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate",
+    "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
 ]
 
 
@@ -44,10 +44,7 @@ class Stats(C.Structure):
         ("factor_flops", C.c_double), ("sweep_bytes", C.c_double), ("sweep_ms", C.c_double),
         ("n", C.c_int64), ("n_blocks", C.c_int64), ("block_size", C.c_int64),
         ("block_size_padded", C.c_int64), ("factor_bytes", C.c_int64),
-        ("gemm_ms", C.c_double), ("gemm_flops", C.c_double), ("gemm_launches", C.c_int64),
-        ("tile_ms", C.c_double), ("tile_launches", C.c_int64),
-        ("sweep_kernel_ms", C.c_double), ("sweep_kernel_bytes", C.c_double),
-        ("sweep_launches", C.c_int64),
+        ("kernel_ms", C.c_double * 8), ("kernel_work", C.c_double * 8), ("kernel_launches", C.c_int64 * 8),
     ]
 
 
@@ -74,6 +71,14 @@ def load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C diffeqgmrfs.jl_amd/csrc` (the HIP library is the only compute path)")
+    # PyTorch wheels bundle their own libamdhip64 (same SONAME as /opt/rocm's).  Two HIP
+    # runtimes in one process cannot both own the GPU, so when torch is installed it is
+    # imported FIRST: the loader then binds this library to the runtime torch already
+    # mapped, and device pointers / streams can be shared between the two.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64, u64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double
     P = C.POINTER
@@ -93,6 +98,8 @@ def load() -> C.CDLL:
         "gmrf_bt_get_block": [vp, i32, i64, vp, i64],
         "gmrf_bt_factor_buffer": [vp, i32, P(vp), P(i64)],
         "gmrf_bt_adopt_shape": [vp, i64, i64],
+        "gmrf_bt_storage_bytes": [i64, i64, P(i64), P(i64), P(i64)],
+        "gmrf_bt_set_storage": [vp, i64, i64, vp, vp, vp],
         "gmrf_bt_adopt_commit": [vp],
         "gmrf_bt_factor_begin_csc": [vp, i64, i64, vp, vp, vp, i32],
         "gmrf_bt_factor_step_async": [vp, i64, i64],
@@ -109,6 +116,7 @@ def load() -> C.CDLL:
         "gmrf_test_potrf_block": [i32, i64, vp, vp, P(i32)],
         "gmrf_test_mfma_f64_rate": [i32, P(dbl)],
         "gmrf_test_hbm_rate": [i32, i64, P(dbl)],
+        "gmrf_test_microbench": [i32, vp, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

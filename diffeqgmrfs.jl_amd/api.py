@@ -270,7 +270,11 @@ class TridiagonalCholeskyFactor:
     def stats(self) -> dict:
         s = _cabi.Stats()
         _cabi.check(self._lib.gmrf_bt_stats(self._h, C.byref(s)))
-        return {f: getattr(s, f) for f, _ in s._fields_}
+        out = {}
+        for f, _ in s._fields_:
+            v = getattr(s, f)
+            out[f] = list(v) if hasattr(v, "__len__") else v
+        return out
 
     def set_profiling(self, level: int):
         _cabi.check(self._lib.gmrf_bt_set_profiling(self._h, level))

@@ -80,7 +80,7 @@ __device__ __forceinline__ void gemm_store_tile(double* sm, int t, const v2d& r0
 }
 
 template <bool A_T, bool B_N>
-__global__ __launch_bounds__(256) void gemm_f64_mfma(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     const int bm = blockIdx.y, bn = blockIdx.x;
     if (g.lower_only && bn > bm) return;
     const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <cmath>
@@ -18,6 +19,7 @@
 
 #include "../../include/gmrf_hip.h"
 #include "gemm_f64.hpp"
+#include "microbench.hpp"
 #include "misc_kernels.hpp"
 #include "potrf_tile.hpp"
 #include "sweep.hpp"
@@ -82,7 +84,7 @@ struct gmrf_csr {
 // ------------------------------------------------------------------------------------ handle
 struct EvPair {
     hipEvent_t a, b;
-    int kind;       // 0 gemm, 1 tile, 2 sweep
+    int kind;       // kernel class, see gmrf_stats
     double work;    // flops or bytes
 };
 
@@ -101,6 +103,7 @@ struct gmrf_handle {
     bool analyzed = false;
     // factor storage
     double *d_L = nullptr, *d_C = nullptr, *d_Linv = nullptr;
+    bool external_storage = false;
     double *d_S = nullptr, *d_B = nullptr, *d_T = nullptr, *d_W = nullptr;
     int* d_info = nullptr;
     double* d_logdet = nullptr;
@@ -166,9 +169,7 @@ static void prof_collect(gmrf_handle* h) {
     for (auto& p : h->events) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, p.a, p.b);
-        if (p.kind == 0) { h->stats.gemm_ms += ms; h->stats.gemm_flops += p.work; h->stats.gemm_launches++; }
-        else if (p.kind == 1) { h->stats.tile_ms += ms; h->stats.tile_launches++; }
-        else { h->stats.sweep_kernel_ms += ms; h->stats.sweep_kernel_bytes += p.work; h->stats.sweep_launches++; }
+        h->stats.kernel_ms[p.kind] += ms; h->stats.kernel_work[p.kind] += p.work; h->stats.kernel_launches[p.kind]++;
         h->ev_pool.push_back(p.a);
         h->ev_pool.push_back(p.b);
     }
@@ -198,8 +199,10 @@ static void free_dev(void* p) {
     if (p) (void)hipFree(p);
 }
 
+static gmrf_status alloc_work(gmrf_handle* h);
 static gmrf_status alloc_factor(gmrf_handle* h) {
     if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->d_L) return GMRF_OK;
+    if (h->external_storage) { g_last_error = "external factor storage does not match the shape"; return GMRF_ERR_BAD_SHAPE; }
     destroy_graphs(h);
     free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
@@ -209,6 +212,12 @@ static gmrf_status alloc_factor(gmrf_handle* h) {
     HIPCHK(hipMalloc(&h->d_L, blk * h->N));
     HIPCHK(hipMalloc(&h->d_Linv, blk * h->N));
     HIPCHK(hipMalloc(&h->d_C, blk * std::max<int64_t>(h->N - 1, 1)));
+    GCHK(alloc_work(h));
+    return GMRF_OK;
+}
+
+static gmrf_status alloc_work(gmrf_handle* h) {
+    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double);
     HIPCHK(hipMalloc(&h->d_S, blk));
     HIPCHK(hipMalloc(&h->d_B, blk));
     HIPCHK(hipMalloc(&h->d_T, blk));
@@ -487,7 +496,10 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
     const int64_t N = h->N;
     SweepArgs s;
     s.ld = ld; s.bs = bsp;
-    const double blk_bytes_c = 8.0 * bsp * (double)bsp, blk_bytes_t = 4.0 * bsp * (double)(bsp + 1);
+    // class 3 (k = 1): algorithmic bytes of the block read; class 2: flops of the panel product
+    const int pclass = (kp == 1) ? 3 : 2;
+    const double blk_bytes_c = (kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp;
+    const double blk_bytes_t = (kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp;
     for (int64_t step = 0; step < N; ++step) {
         const int64_t i = backward ? (N - 1 - step) : step;
         const double* rhs = Pin + i * bsp;
@@ -501,7 +513,7 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
             s.Out = h->d_Tp; s.ldo = bsp;
             s.sub = 1;
             {
-                ProfScope ps(h, 2, blk_bytes_c);
+                ProfScope ps(h, pclass, blk_bytes_c);
                 HIPCHK(launch_sweep(h->stream, backward, false, kp, s));
             }
             rhs = h->d_Tp;
@@ -513,7 +525,7 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
         s.Out = Yout + i * bsp; s.ldo = npad;
         s.sub = 0;
         {
-            ProfScope ps(h, 2, blk_bytes_t);
+            ProfScope ps(h, pclass, blk_bytes_t);
             HIPCHK(launch_sweep(h->stream, backward, true, kp, s));
         }
     }
@@ -602,7 +614,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
-    free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
+    if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
     free_dev(h->d_info); free_dev(h->d_logdet);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
@@ -618,9 +630,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
 gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
     if (!h) return bad_shape("null handle");
     h->profiling = level;
-    h->stats.gemm_ms = h->stats.gemm_flops = 0; h->stats.gemm_launches = 0;
-    h->stats.tile_ms = 0; h->stats.tile_launches = 0;
-    h->stats.sweep_kernel_ms = h->stats.sweep_kernel_bytes = 0; h->stats.sweep_launches = 0;
+    for (int i = 0; i < 8; ++i) { h->stats.kernel_ms[i] = h->stats.kernel_work[i] = 0; h->stats.kernel_launches[i] = 0; }
     return GMRF_OK;
 }
 
@@ -717,6 +727,29 @@ gmrf_status gmrf_bt_factor_blocks(gmrf_handle* h, int64_t n, int64_t n_blocks, c
     }
     GCHK(upload_entries(h, dg, lo, (int64_t)vals.size()));
     return numeric_factor(h, vals.data(), info);
+}
+
+
+gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t* bytes_L, int64_t* bytes_C, int64_t* bytes_Linv) {
+    if (n <= 0 || n_blocks <= 0 || n % n_blocks != 0 || !bytes_L || !bytes_C || !bytes_Linv)
+        return bad_shape("n must be a positive multiple of N_blocks");
+    const int64_t bs = n / n_blocks, bsp = 64 * next_pow2((bs + 63) / 64);
+    const int64_t blk = bsp * bsp * (int64_t)sizeof(double);
+    *bytes_L = blk * n_blocks; *bytes_Linv = blk * n_blocks; *bytes_C = blk * std::max<int64_t>(n_blocks - 1, 1);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, void* dev_L, void* dev_C, void* dev_Linv) {
+    if (!h || !dev_L || !dev_C || !dev_Linv) return bad_shape("null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    GCHK(set_shape(h, n, n_blocks));
+    destroy_graphs(h);
+    if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
+    free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W); free_dev(h->d_logdet);
+    h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
+    h->d_L = (double*)dev_L; h->d_C = (double*)dev_C; h->d_Linv = (double*)dev_Linv;
+    h->external_storage = true;
+    return alloc_work(h);
 }
 
 gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
@@ -1234,6 +1267,82 @@ gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops) {
     const double flops = (double)blocks * 4 /*waves*/ * iters * 4.0 * 2048.0;
     *tflops = flops / (ms * 1e-3) / 1e12;
     hipFree(d); hipEventDestroy(a); hipEventDestroy(b);
+    return GMRF_OK;
+}
+
+
+// Micro-benchmark battery; fills out[0..n) (see tools/microbench.py for the meaning).
+gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n) {
+    if (!out || n < 16) return bad_shape("need 16 outputs");
+    HIPCHK(hipSetDevice(device));
+    unsigned long long* d_t; double* d_s; int* d_i;
+    HIPCHK(hipMalloc(&d_t, 64)); HIPCHK(hipMalloc(&d_s, 64)); HIPCHK(hipMalloc(&d_i, 64));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    unsigned long long ht[2];
+    float ms = 0.f;
+    auto timed = [&](auto launch, double flops, int idx) -> gmrf_status {
+        launch(); HIPCHK(hipDeviceSynchronize());              // warm
+        HIPCHK(hipEventRecord(a, nullptr)); launch(); HIPCHK(hipEventRecord(b, nullptr));
+        HIPCHK(hipEventSynchronize(b)); HIPCHK(hipEventElapsedTime(&ms, a, b));
+        HIPCHK(hipMemcpy(ht, d_t, 16, hipMemcpyDeviceToHost));
+        out[idx] = flops / (ms * 1e-3) / 1e12;                 // TFLOP/s
+        out[idx + 1] = (double)ht[0] / (double)ht[1] * 0.1;    // shader clock GHz inside the loop
+        return GMRF_OK;
+    };
+    const int it = 20000;
+    // 0,1: MFMA f64, 1 wave/SIMD (256 blocks), 4 accumulators
+    GCHK(timed([&] { hipLaunchKernelGGL((mb_mfma_f64<4>), dim3(256), dim3(256), 0, nullptr, d_t, d_s, it); },
+               256.0 * 4 * it * 4 * 2048.0, 0));
+    // 2,3: MFMA f64, 2 waves/SIMD
+    GCHK(timed([&] { hipLaunchKernelGGL((mb_mfma_f64<4>), dim3(512), dim3(256), 0, nullptr, d_t, d_s, it); },
+               512.0 * 4 * it * 4 * 2048.0, 2));
+    // 4,5: MFMA f64, 1 wave/SIMD, single dependent accumulator
+    GCHK(timed([&] { hipLaunchKernelGGL((mb_mfma_f64<1>), dim3(256), dim3(256), 0, nullptr, d_t, d_s, it); },
+               256.0 * 4 * it * 1 * 2048.0, 4));
+    // 6,7: VALU f64 FMA, 2 waves/SIMD, 8 chains
+    GCHK(timed([&] { hipLaunchKernelGGL(mb_valu_f64, dim3(512), dim3(256), 0, nullptr, d_t, d_s, it * 4); },
+               512.0 * 256 * (it * 4.0) * 8 * 2.0, 6));
+    // 8,9: one workgroup only (light load): MFMA loop -> cycles per MFMA and clock
+    GCHK(timed([&] { hipLaunchKernelGGL((mb_mfma_f64<4>), dim3(1), dim3(64), 0, nullptr, d_t, d_s, it); },
+               1.0 * it * 4 * 2048.0, 8));
+    out[10] = (double)ht[0] / (it * 4.0);                       // shader cycles per MFMA, one wave
+    // 11: empty-kernel launch cadence (us per launch, back to back on one stream)
+    hipLaunchKernelGGL(mb_null, dim3(1), dim3(64), 0, nullptr, d_i);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL(mb_null, dim3(1), dim3(64), 0, nullptr, d_i);
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b)); HIPCHK(hipEventElapsedTime(&ms, a, b));
+    out[11] = ms * 1e3 / 2000.0;
+    // 12: same through a captured graph of 2000 nodes
+    {
+        hipStream_t st; HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        hipGraph_t g; hipGraphExec_t ge;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 2000; ++i) hipLaunchKernelGGL(mb_null, dim3(1), dim3(64), 0, st, d_i);
+        HIPCHK(hipStreamEndCapture(st, &g));
+        HIPCHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphLaunch(ge, st)); HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipEventRecord(a, st)); HIPCHK(hipGraphLaunch(ge, st)); HIPCHK(hipEventRecord(b, st));
+        HIPCHK(hipEventSynchronize(b)); HIPCHK(hipEventElapsedTime(&ms, a, b));
+        out[12] = ms * 1e3 / 2000.0;
+        (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(st);
+    }
+    // 13,14: light kernel right after 200 ms of idling (clock ramp check)
+    {
+        struct timespec ts = {0, 200000000};
+        nanosleep(&ts, nullptr);
+        HIPCHK(hipEventRecord(a, nullptr));
+        hipLaunchKernelGGL((mb_mfma_f64<4>), dim3(1), dim3(64), 0, nullptr, d_t, d_s, 2000);
+        HIPCHK(hipEventRecord(b, nullptr));
+        HIPCHK(hipEventSynchronize(b)); HIPCHK(hipEventElapsedTime(&ms, a, b));
+        HIPCHK(hipMemcpy(ht, d_t, 16, hipMemcpyDeviceToHost));
+        out[13] = (double)ht[0] / (double)ht[1] * 0.1;
+        out[14] = ms * 1e3;
+    }
+    out[15] = 0;
+    hipFree(d_t); hipFree(d_s); hipFree(d_i); hipEventDestroy(a); hipEventDestroy(b);
     return GMRF_OK;
 }
 

@@ -31,7 +31,7 @@ struct SweepArgs {
 // TRANS = false: out[m] = sum_k Mat[m][k] x[k]   (TRI: Mat lower triangular, k <= m)
 // TRANS = true : out[m] = sum_k Mat[k][m] x[k]   (TRI: Mat lower triangular, k >= m)
 template <bool TRANS, bool TRI>
-__global__ __launch_bounds__(256) void sweep_mm(SweepArgs s) {
+__global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
     const int m0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;

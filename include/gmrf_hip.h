@@ -70,10 +70,13 @@ typedef struct {
     double sweep_ms;           /* duration of the last single sweep                         */
     int64_t n, n_blocks, block_size, block_size_padded;
     int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
-    /* per-kernel accounting filled when profiling is on (gmrf_bt_set_profiling):           */
-    double gemm_ms, gemm_flops;  int64_t gemm_launches;    /* dense MFMA f64 GEMM kernel     */
-    double tile_ms;              int64_t tile_launches;    /* 64x64 potrf + inverse kernel   */
-    double sweep_kernel_ms, sweep_kernel_bytes; int64_t sweep_launches;
+    /* per-kernel-class accounting, filled when profiling is on (gmrf_bt_set_profiling):
+     * class 0 dense MFMA f64 GEMM, 1 potrf panel step (tile Cholesky + inverse + update),
+     * 2 MFMA sweep (k >= 2 right-hand sides), 3 GEMV sweep (k = 1), 4 CSR SpMM, 5 other.
+     * work = algorithmic flops (classes 0-2) or algorithmic bytes (classes 3-5). */
+    double kernel_ms[8];
+    double kernel_work[8];
+    int64_t kernel_launches[8];
 } gmrf_stats;
 
 /* ------------------------------------------------------------------ life cycle */
@@ -157,6 +160,14 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
 gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr,
                                   int64_t* bytes);
 
+/* Caller-owned factor storage (e.g. torch tensors that RCCL broadcasts): sizes for a shape,
+ * then the three device buffers.  Must be set before the first factor / adopt_shape of that
+ * shape; the buffers must outlive the handle's use of them. */
+gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t* bytes_L,
+                                  int64_t* bytes_C, int64_t* bytes_Linv);
+gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, void* dev_L,
+                                void* dev_C, void* dev_Linv);
+
 /* Allocate factor storage for a given shape WITHOUT factoring (a rank that receives the
  * factor by broadcast), then mark it valid once the buffers have been filled. */
 gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks);
@@ -203,6 +214,7 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/ou
                                   double* Linv, int32_t* info);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
 gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps);
+gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n);
 
 #ifdef __cplusplus
 }

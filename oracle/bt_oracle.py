@@ -55,6 +55,15 @@ def make_chunks(X: np.ndarray, n: int):
     return [X[c * k:(X.shape[0] if k == n - 1 else c * k + c)] for k in range(n)]
 
 
+def _mm(A: np.ndarray, B: np.ndarray, trans_a: bool = False) -> np.ndarray:
+    """op(A) @ B through SciPy's BLAS (dgemv / dgemm).  NumPy and SciPy ship separate OpenBLAS
+    thread pools; alternating between them makes the pools fight for the cores and slows the
+    CPU baseline 3-4x, so every dense product of the oracle goes through the SciPy one."""
+    if B.ndim == 1:
+        return sla.blas.dgemv(1.0, A, B, trans=1 if trans_a else 0)
+    return sla.blas.dgemm(1.0, A, B, trans_a=1 if trans_a else 0)
+
+
 def _chol_forward(L: np.ndarray, b: np.ndarray) -> np.ndarray:
     """forward_solve(::Cholesky, b) = L.L \\ b  (:35-37)."""
     return sla.solve_triangular(L, b, lower=True, check_finite=False)
@@ -99,7 +108,9 @@ def tridiagonal_cholesky(A, N_blocks: int) -> TridiagonalCholeskyFactor:
         C = _chol_forward(chos[-1], B.T).T               # :74
         Cs.append(C)                                     # :75
         D = dense(r0, r0)                                # :76
-        chos.append(chol(D - C @ C.T, i + 1))            # :77
+        # D - C*C' : Julia lowers X*X' to dsyrk; only the lower triangle is formed and read
+        S = sla.blas.dsyrk(-1.0, C, beta=1.0, c=D, lower=1, trans=0)
+        chos.append(chol(S, i + 1))                      # :77
     return TridiagonalCholeskyFactor(n, chos, Cs)
 
 
@@ -110,7 +121,7 @@ def forward_solve(F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
     x = [None] * N
     x[0] = _chol_forward(F.chos[0], bch[0])                                     # :47
     for i in range(1, N):
-        x[i] = _chol_forward(F.chos[i], bch[i] - F.Cs[i - 1] @ x[i - 1])        # :49
+        x[i] = _chol_forward(F.chos[i], bch[i] - _mm(F.Cs[i - 1], x[i - 1]))      # :49
     return np.concatenate(x, axis=0)
 
 
@@ -121,7 +132,7 @@ def backward_solve(F: TridiagonalCholeskyFactor, b: np.ndarray) -> np.ndarray:
     x = [None] * N
     x[N - 1] = _chol_backward(F.chos[N - 1], bch[N - 1])                        # :28
     for i in range(N - 2, -1, -1):
-        x[i] = _chol_backward(F.chos[i], bch[i] - F.Cs[i].T @ x[i + 1])         # :30
+        x[i] = _chol_backward(F.chos[i], bch[i] - _mm(F.Cs[i], x[i + 1], True))    # :30
     return np.concatenate(x, axis=0)
 
 

@@ -192,3 +192,54 @@ def test_torch_device_resident_io(pkg):
     assert X.is_cuda and X.shape == (w.n, 16)
     Xh = F.sample(16, mean=mu.cpu().numpy(), seed=9)
     assert np.array_equal(X.cpu().numpy(), Xh)
+
+
+import glob as _glob
+import os as _os
+
+_GOLDEN = sorted(_glob.glob(_os.path.join(_os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[_os.path.basename(p)[:-4] for p in _GOLDEN])
+def test_hip_path_against_golden_fixtures(pkg, path):
+    """Committed input/output vectors produced by an independent dense route
+    (tests/golden/make_golden.py); includes block sizes that the library pads (24, 32)."""
+    gd = np.load(path)
+    n, N = int(gd["n"]), int(gd["n_blocks"])
+    Q = sp.csc_matrix((gd["nzval"], gd["rowval"], gd["colptr"]), shape=(n, n))
+    F = pkg.tridiagonal_cholesky(Q, N)
+    scale = np.abs(gd["chos"]).max()
+    for i in range(N):
+        assert np.max(np.abs(np.tril(F.chos[i]) - gd["chos"][i])) < 1e-11 * scale
+        if i < N - 1:
+            assert np.max(np.abs(F.Cs[i] - gd["Cs"][i])) < 1e-11 * scale
+    assert rel(pkg.ldiv(F, gd["rhs"]), gd["mean"]) < 1e-9
+    assert rel(pkg.forward_solve(F, gd["Z"]), gd["forward"]) < 1e-10
+    assert rel(pkg.backward_solve(F, gd["Z"]), gd["backward"]) < 1e-10
+    assert np.max(np.abs(F.marginal_var("exact") - gd["var"]) / gd["var"]) < 1e-8
+    assert abs(F.logdet() - float(gd["logdet"])) < 1e-10 * abs(float(gd["logdet"]))
+
+
+def test_full_size_properties_darcy256(pkg):
+    """BASELINE metric size: size-independent properties (residual, L L^T x = A x through
+    the two half solves, linearity, logdet additivity under scaling)."""
+    w = pkg.workloads.make("darcy256")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    mu = pkg.ldiv(F, w.rhs)
+    qn = abs(w.Q).sum(axis=1).max()
+    assert np.linalg.norm(w.Q @ mu - w.rhs) / (qn * np.linalg.norm(mu) + np.linalg.norm(w.rhs)) < 1e-14
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((w.n, 3))
+    # A^-1 (A x) = x
+    assert rel(pkg.ldiv(F, w.Q @ X), X) < 1e-7
+    # forward o backward = full; linearity
+    B = rng.standard_normal((w.n, 2))
+    assert rel(pkg.backward_solve(F, pkg.forward_solve(F, B)), pkg.ldiv(F, B)) < 1e-13
+    assert rel(pkg.ldiv(F, 2.0 * B[:, 0] - 3.0 * B[:, 1]), 2.0 * pkg.ldiv(F, B[:, 0]) - 3.0 * pkg.ldiv(F, B[:, 1])) < 1e-10
+    # L^-T z has covariance A^-1:  z^T z == x^T A x for x = L^-T z
+    Z = rng.standard_normal((w.n, 2))
+    Xs = pkg.backward_solve(F, Z)
+    assert np.allclose(np.sum(Xs * (w.Q @ Xs), axis=0), np.sum(Z * Z, axis=0), rtol=1e-9)
+    ld = F.logdet()
+    F.refactor(4.0 * w.Q.data)
+    assert abs(F.logdet() - (ld + w.n * np.log(4.0))) < 1e-9 * abs(ld)

@@ -1,0 +1,83 @@
+"""CPU tests of the host side: C-ABI surface, argument checking, sharding helpers, workloads."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg, lib):
+    hdr = open(os.path.join(ROOT, "include", "gmrf_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(gmrf_[a-z0-9_]+)\(", hdr)) - {"gmrf_status"})
+    assert declared, "no declarations parsed"
+    assert sorted(pkg._cabi.EXPORTS) == declared                 # binding list == header
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg._cabi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (gmrf_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+    for s in declared:
+        assert hasattr(lib, s)
+    assert lib.gmrf_version() >= 100
+
+
+def test_no_gpu_means_loud_failure_not_fallback(pkg, lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    st = lib.gmrf_bt_create(0, None, C.byref(h))
+    assert st == pkg._cabi.ERR_NO_DEVICE
+    with pytest.raises(pkg.GmrfError) as e:
+        pkg.tridiagonal_cholesky(sp.identity(8, format="csc"), 2)
+    assert e.value.status == pkg._cabi.ERR_NO_DEVICE
+    w = pkg.workloads.random_block_tridiagonal(2, 8)
+    with pytest.raises(pkg.GmrfError):
+        pkg.CsrMatrix(w.Q)
+
+
+def test_storage_size_query_needs_no_gpu(pkg, lib):
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    assert lib.gmrf_bt_storage_bytes(65536, 64, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert a.value == 64 * 1024 * 1024 * 8 and b.value == 63 * 1024 * 1024 * 8 and c.value == a.value
+    assert lib.gmrf_bt_storage_bytes(600, 2, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert a.value == 2 * 512 * 512 * 8                            # 300 -> padded to 64 * 8 = 512
+    assert lib.gmrf_bt_storage_bytes(10, 3, C.byref(a), C.byref(b), C.byref(c)) == pkg._cabi.ERR_BAD_SHAPE
+
+
+def test_argument_validation_in_python_layer(pkg):
+    with pytest.raises(ValueError):
+        pkg.tridiagonal_cholesky(sp.identity(10, format="csc"), 3)
+    x = np.arange(10.0)
+    assert [len(c) for c in pkg.make_chunks(x, 4)] == [2, 2, 2, 4]
+
+
+def test_shard_helpers(pkg):
+    from importlib import import_module
+    import __graft_entry__ as g
+    post = import_module(g.PKG_NAME + ".posterior")
+    for total, world in [(64, 8), (65, 8), (7, 3), (0, 2)]:
+        parts = [post.shard_range(total, world, r) for r in range(world)]
+        assert sum(c for _, c in parts) == total
+        assert all(parts[r][0] + parts[r][1] == parts[r + 1][0] for r in range(world - 1))
+    assert post.block_groups(10, 4) == [(0, 4), (4, 8), (8, 10)]
+
+
+@pytest.mark.parametrize("name,n,N", [("darcy64", 4096, 16), ("burgers64x8", 512, 8), ("elliptic32", 1024, 16)])
+def test_workloads_are_spd_block_tridiagonal(pkg, name, n, N):
+    w = pkg.workloads.make(name)
+    assert w.n == n and w.n_blocks == N
+    assert pkg.workloads.block_bandwidth_ok(w.Q, N)
+    assert abs(w.Q - w.Q.T).max() == 0.0
+    if n <= 1024:
+        assert np.linalg.eigvalsh(w.Q.toarray()).min() > 0
+
+
+def test_baseline_config_shapes(pkg):
+    # sizes of SURVEY.md section 8a, without building the big ones
+    w = pkg.workloads.darcy(16)
+    assert (w.n, w.n_blocks, w.block_size) == (256, 4, 64)
+    assert set(pkg.workloads.CONFIGS) >= {"burgers512x64", "darcy64", "darcy256", "elliptic512", "burgers4096x512"}
