@@ -9,9 +9,8 @@
 //   b(k,n) = B_N ? B[k*ldb + n] : B[n*ldb + k]        (B_N: B is stored K x N, else N x K)
 //
 // 64x64 output tile per 256-thread workgroup (4 waves, each a 32x32 quadrant = 2x2 MFMA
-// tiles), K stepped by 16 through a double-buffered, padded LDS image [row][k] so that the
-// MFMA operand reads (lane l: row l&15, k l>>4) are bank-conflict free for ds_read_b64
-// (row stride 18 doubles: 18*i mod 32 is a permutation of the even residues).
+// tiles), K stepped by 32 (16 when K is not a multiple of 32) through a double-buffered,
+// padded LDS image [row][k] (details at the kernel).
 // Triangular operands skip the K range that is structurally zero (the zero part inside
 // the boundary tile must hold real zeros).  All of M, N multiples of 64, K of 16.
 #pragma once
@@ -40,47 +39,73 @@ struct GemmArgs {
     int tri;
     int lower_only;                      // skip tiles strictly above the block diagonal
     double alpha, beta;
+    unsigned long long* stamps;          // diagnostic (tests): s_memtime / s_memrealtime of block 0
 };
 
 constexpr int GEMM_BM = 64;
 constexpr int GEMM_BN = 64;
-constexpr int GEMM_BK = 16;
-constexpr int GEMM_LD = 18;              // padded LDS row stride in doubles
 
-// One 64(row) x 16(k) operand tile: global -> registers (two v2d per thread).
-template <bool ROWS_CONTIG>
-__device__ __forceinline__ void gemm_load_tile(const double* __restrict__ P, int64_t ld,
-                                               int row0, int k0, int t, v2d& r0, v2d& r1) {
-    if (!ROWS_CONTIG) {          // stored [row][k]: 8 threads cover one row's 16 k
-        const int r = t >> 3, kk = (t & 7) * 2;
+// One 64(row) x BK(k) operand tile: global -> registers (BK/8 v2d per thread).
+template <bool ROWS_CONTIG, int BK>
+__device__ __forceinline__ void gemm_load_tile(const double* __restrict__ P, int64_t ld, int row0, int k0,
+                                               int t, v2d (&rg)[BK / 8]) {
+    if (!ROWS_CONTIG) {          // stored [row][k]: BK/2 threads cover one row
+        constexpr int TPR = BK / 2, RPP = 256 / TPR;      // threads per row, rows per pass
+        const int r = t / TPR, kk = (t % TPR) * 2;
         const double* p = P + (int64_t)(row0 + r) * ld + k0 + kk;
-        r0 = *reinterpret_cast<const v2d*>(p);
-        r1 = *reinterpret_cast<const v2d*>(p + 32 * ld);
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) rg[i] = *reinterpret_cast<const v2d*>(p + (int64_t)(i * RPP) * ld);
     } else {                     // stored [k][row]: 32 threads cover one k's 64 rows
         const int kk = t >> 5, r = (t & 31) * 2;
         const double* p = P + (int64_t)(k0 + kk) * ld + row0 + r;
-        r0 = *reinterpret_cast<const v2d*>(p);
-        r1 = *reinterpret_cast<const v2d*>(p + 8 * ld);
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) rg[i] = *reinterpret_cast<const v2d*>(p + (int64_t)(i * 8) * ld);
     }
 }
 
-template <bool ROWS_CONTIG>
-__device__ __forceinline__ void gemm_store_tile(double* sm, int t, const v2d& r0, const v2d& r1) {
+template <bool ROWS_CONTIG, int BK>
+__device__ __forceinline__ void gemm_store_tile(double* sm, int t, const v2d (&rg)[BK / 8]) {
+    constexpr int LD = BK + 4;
     if (!ROWS_CONTIG) {
-        const int r = t >> 3, kk = (t & 7) * 2;
-        *reinterpret_cast<v2d*>(sm + r * GEMM_LD + kk) = r0;
-        *reinterpret_cast<v2d*>(sm + (r + 32) * GEMM_LD + kk) = r1;
+        constexpr int TPR = BK / 2, RPP = 256 / TPR;
+        const int r = t / TPR, kk = (t % TPR) * 2;
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) *reinterpret_cast<v2d*>(sm + (r + i * RPP) * LD + kk) = rg[i];
     } else {
         const int kk = t >> 5, r = (t & 31) * 2;
-        sm[r * GEMM_LD + kk] = r0.x;
-        sm[(r + 1) * GEMM_LD + kk] = r0.y;
-        sm[r * GEMM_LD + kk + 8] = r1.x;
-        sm[(r + 1) * GEMM_LD + kk + 8] = r1.y;
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) {
+            sm[r * LD + kk + 8 * i] = rg[i].x;
+            sm[(r + 1) * LD + kk + 8 * i] = rg[i].y;
+        }
     }
 }
 
-template <bool A_T, bool B_N>
+// K is stepped by BK (16 or 32) through a double-buffered LDS image [row][k] with row stride
+// BK + 4 doubles.  A lane fetches TWO consecutive k (one ds_read_b128, conflict free at this
+// stride for the 4 x 16-lane groups of that instruction) and feeds them to two MFMAs: MFMA 1
+// sums k in {0,2,4,6} of an 8-wide k group, MFMA 2 the odd ones -- any assignment of k to the
+// instruction's four k slots is valid as long as A and B use the same one.  The fragments of
+// the next k group are requested before the MFMAs of the current one are issued, so the LDS
+// latency hides behind 8 x 64 MFMA cycles.  BK = 32 gives every global load 32 MFMAs (2048
+// cycles) per wave to land before it is needed.
+struct GemmFrag { v2d a0, a1, b0, b1; };
+
+template <int LD>
+__device__ __forceinline__ GemmFrag gemm_read_frag(const double* as, const double* bs, int wm, int wn, int li,
+                                                   int lq, int kg) {
+    GemmFrag f;
+    const int k = kg * 8 + 2 * lq;
+    f.a0 = *reinterpret_cast<const v2d*>(as + (wm + li) * LD + k);
+    f.a1 = *reinterpret_cast<const v2d*>(as + (wm + 16 + li) * LD + k);
+    f.b0 = *reinterpret_cast<const v2d*>(bs + (wn + li) * LD + k);
+    f.b1 = *reinterpret_cast<const v2d*>(bs + (wn + 16 + li) * LD + k);
+    return f;
+}
+
+template <bool A_T, bool B_N, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
+    constexpr int LD = BK + 4;
     const int bm = blockIdx.y, bn = blockIdx.x;
     if (g.lower_only && bn > bm) return;
     const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
@@ -94,8 +119,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
     if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + GEMM_BN);
 
-    __shared__ __attribute__((aligned(16))) double As[2][GEMM_BM * GEMM_LD];
-    __shared__ __attribute__((aligned(16))) double Bs[2][GEMM_BN * GEMM_LD];
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double* As0 = gsm;                               // [2][64 * LD]
+    double* Bs0 = gsm + 2 * GEMM_BM * LD;            // [2][64 * LD]
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -108,43 +134,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
 
-    const int nkt = (ke > kb) ? (ke - kb) / GEMM_BK : 0;
-    v2d ra0, ra1, rb0, rb1;
+    const int nkt = (ke > kb) ? (ke - kb) / BK : 0;
+    unsigned long long c0 = 0, r0 = 0;
+    if (g.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
+    v2d ra[BK / 8], rb[BK / 8];
     if (nkt > 0) {
-        gemm_load_tile<A_T>(A, g.lda, m0, kb, t, ra0, ra1);
-        gemm_load_tile<B_N>(B, g.ldb, n0, kb, t, rb0, rb1);
-        gemm_store_tile<A_T>(As[0], t, ra0, ra1);
-        gemm_store_tile<B_N>(Bs[0], t, rb0, rb1);
+        gemm_load_tile<A_T, BK>(A, g.lda, m0, kb, t, ra);
+        gemm_load_tile<B_N, BK>(B, g.ldb, n0, kb, t, rb);
+        gemm_store_tile<A_T, BK>(As0, t, ra);
+        gemm_store_tile<B_N, BK>(Bs0, t, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1 < nkt);
-        if (more) {
-            const int k0 = kb + (kt + 1) * GEMM_BK;
-            gemm_load_tile<A_T>(A, g.lda, m0, k0, t, ra0, ra1);
-            gemm_load_tile<B_N>(B, g.ldb, n0, k0, t, rb0, rb1);
+        if (more && !(g.tri & 512)) {
+            const int k0 = kb + (kt + 1) * BK;
+            gemm_load_tile<A_T, BK>(A, g.lda, m0, k0, t, ra);
+            gemm_load_tile<B_N, BK>(B, g.ldb, n0, k0, t, rb);
         }
-        const double* as = As[cur];
-        const double* bs = Bs[cur];
+        const double* as = As0 + cur * GEMM_BM * LD;
+        const double* bs = Bs0 + cur * GEMM_BN * LD;
+        GemmFrag f = gemm_read_frag<LD>(as, bs, wm, wn, li, lq, 0);
 #pragma unroll
-        for (int ks = 0; ks < GEMM_BK / 4; ++ks) {
-            const double a0 = as[(wm + li) * GEMM_LD + ks * 4 + lq];
-            const double a1 = as[(wm + 16 + li) * GEMM_LD + ks * 4 + lq];
-            const double b0 = bs[(wn + li) * GEMM_LD + ks * 4 + lq];
-            const double b1 = bs[(wn + 16 + li) * GEMM_LD + ks * 4 + lq];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            GemmFrag fn = f;
+            if (kg + 1 < BK / 8 && !(g.tri & 256)) fn = gemm_read_frag<LD>(as, bs, wm, wn, li, lq, kg + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, f.b0.x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, f.b1.x, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, f.b0.x, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, f.b1.x, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, f.b0.y, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, f.b1.y, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, f.b0.y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, f.b1.y, acc[1][1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            f = fn;
         }
-        if (more) {
-            gemm_store_tile<A_T>(As[cur ^ 1], t, ra0, ra1);
-            gemm_store_tile<B_N>(Bs[cur ^ 1], t, rb0, rb1);
+        if (more && !(g.tri & 512)) {
+            gemm_store_tile<A_T, BK>(As0 + (cur ^ 1) * GEMM_BM * LD, t, ra);
+            gemm_store_tile<B_N, BK>(Bs0 + (cur ^ 1) * GEMM_BN * LD, t, rb);
         }
-        __syncthreads();
+        if (!(g.tri & 1024)) __syncthreads();
     }
 
+    if (g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+        g.stamps[0] = __builtin_amdgcn_s_memtime() - c0;
+        g.stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
+    }
     // f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
     const double alpha = g.alpha, beta = g.beta;
 #pragma unroll
@@ -162,14 +200,36 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
             }
 }
 
+template <int BK>
+constexpr size_t gemm_lds_bytes() { return (size_t)4 * 64 * (BK + 4) * sizeof(double); }
+
+// Opt in to the > 64 KiB dynamic LDS of the BK = 32 variants (once per process).
+inline hipError_t gemm_init() {
+    hipError_t e = hipSuccess;
+#define GMRF_GEMM_ATTR(AT, BN)                                                                   \
+    if (e == hipSuccess)                                                                         \
+        e = hipFuncSetAttribute((const void*)gemm_f64_mfma<AT, BN, 32>,                          \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
+    GMRF_GEMM_ATTR(false, false) GMRF_GEMM_ATTR(false, true) GMRF_GEMM_ATTR(true, false) GMRF_GEMM_ATTR(true, true)
+#undef GMRF_GEMM_ATTR
+    return e;
+}
+
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
 inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, int batch) {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
     dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, batch), block(256);
-    if (!a_t && !b_n) hipLaunchKernelGGL((gemm_f64_mfma<false, false>), grid, block, 0, st, g);
-    else if (!a_t && b_n) hipLaunchKernelGGL((gemm_f64_mfma<false, true>), grid, block, 0, st, g);
-    else if (a_t && !b_n) hipLaunchKernelGGL((gemm_f64_mfma<true, false>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((gemm_f64_mfma<true, true>), grid, block, 0, st, g);
+    const bool wide = (g.K % 32 == 0);
+#define GMRF_GEMM_LAUNCH(AT, BN)                                                                 \
+    do {                                                                                         \
+        if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>(), st, g); \
+        else hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 16>), grid, block, gemm_lds_bytes<16>(), st, g);      \
+    } while (0)
+    if (!a_t && !b_n) GMRF_GEMM_LAUNCH(false, false);
+    else if (!a_t && b_n) GMRF_GEMM_LAUNCH(false, true);
+    else if (a_t && !b_n) GMRF_GEMM_LAUNCH(true, false);
+    else GMRF_GEMM_LAUNCH(true, true);
+#undef GMRF_GEMM_LAUNCH
     return hipGetLastError();
 }
 

@@ -21,12 +21,14 @@
 #include "gemm_f64.hpp"
 #include "microbench.hpp"
 #include "misc_kernels.hpp"
-#include "potrf_tile.hpp"
+#include "potrf_step.hpp"
 #include "sweep.hpp"
 
 using namespace gmrf;
 
 static thread_local std::string g_last_error;
+static double g_tile_us = 0.0;
+static unsigned long long g_tile_stamps[32];
 
 #define HIPCHK(expr)                                                                        \
     do {                                                                                    \
@@ -186,7 +188,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = sA; g.strideB = sB; g.strideC = sC;
     g.M = M; g.N = N; g.K = K; g.tri = tri; g.lower_only = lower_only;
-    g.alpha = alpha; g.beta = beta;
+    g.alpha = alpha; g.beta = beta; g.stamps = nullptr;
     double flops = 2.0 * M * N * (double)K * batch;
     if (lower_only) flops *= 0.5 * (1.0 + 64.0 / std::max(M, 64));
     if (tri) flops *= 0.5 * (1.0 + 64.0 / std::max(K, 64));
@@ -362,27 +364,14 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     const int64_t ld = bsp;
     const int nt = bsp / 64;
     for (int j = 0; j < nt; ++j) {
-        const int64_t o = (int64_t)j * 64;
-        TileArgs ta;
-        ta.S = S + o * ld + o; ta.lds = ld;
-        ta.L = L + o * ld + o; ta.ldl = ld;
-        ta.X = X + o * ld + o; ta.ldx = ld;
-        ta.info = h->d_info; ta.blk = blk_id;
-        {
-            ProfScope ps(h, 1, 0.0);
-            hipLaunchKernelGGL(potrf_tile64_inv, dim3(1), dim3(64), 0, h->stream, ta);
-            HIPCHK(hipGetLastError());
-        }
-        const int rem = bsp - (j + 1) * 64;
-        if (rem > 0) {
-            const int64_t o1 = o + 64;
-            // panel: L[o1:, o] = S[o1:, o] * Xjj^T
-            GCHK(gemm(h, false, false, rem, 64, 64, TRI_B_UPPER, 0, 1.0, S + o1 * ld + o, ld,
-                      X + o * ld + o, ld, 0.0, L + o1 * ld + o, ld));
-            // trailing: S[o1:, o1:] -= L[o1:, o] L[o1:, o]^T   (lower tiles only)
-            GCHK(gemm(h, false, false, rem, rem, 64, 0, 1, -1.0, L + o1 * ld + o, ld,
-                      L + o1 * ld + o, ld, 1.0, S + o1 * ld + o1, ld));
-        }
+        StepArgs sa;
+        sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
+        sa.info = h->d_info; sa.blk = blk_id;
+        const int m = nt - j - 1;
+        const double rem = 64.0 * m;
+        ProfScope ps(h, 1, 64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0);
+        hipLaunchKernelGGL(potrf_step, dim3(1 + m * (m + 1) / 2), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+        HIPCHK(hipGetLastError());
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
     for (int hh = 64; hh < bsp; hh *= 2) {
@@ -604,6 +593,8 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipMemset(h->d_info, 0, sizeof(int)));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
+    HIPCHK(gemm_init());
     *out = h;
     return GMRF_OK;
 }
@@ -1195,10 +1186,16 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     g.strideA = g.strideB = g.strideC = 0;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta;
+    unsigned long long* dst = nullptr;
+    HIPCHK(hipMalloc(&dst, 16));
+    g.stamps = dst;
+    HIPCHK(gemm_init());
     // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
     HIPCHK(launch_gemm(nullptr, transA != 0, transB == 0, g, 1));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g_tile_stamps, dst, 16, hipMemcpyDeviceToHost));
+    hipFree(dst);
     hipFree(dA); hipFree(dB); hipFree(dC);
     return GMRF_OK;
 }
@@ -1213,9 +1210,26 @@ gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64, double* inv64, 
     HIPCHK(hipMalloc(&dinfo, sizeof(int)));
     HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
     HIPCHK(hipMemcpy(dS, tile64, sizeof(double) * 4096, hipMemcpyHostToDevice));
-    TileArgs ta;
-    ta.S = dS; ta.lds = 64; ta.L = dL; ta.ldl = 64; ta.X = dX; ta.ldx = 64; ta.info = dinfo; ta.blk = 1;
-    hipLaunchKernelGGL(potrf_tile64_inv, dim3(1), dim3(64), 0, nullptr, ta);
+    (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_TILE_LDS);
+    unsigned long long* dstamps;
+    HIPCHK(hipMalloc(&dstamps, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(dstamps, 0, 32 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    {   // timing: 200 back-to-back launches without stamps, then one stamped launch
+        hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 200; ++i)
+            hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
+        HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        g_tile_us = ms * 1e3 / 200.0;
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
+    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, dstamps);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(g_tile_stamps, dstamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    hipFree(dstamps);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(tile64, dL, sizeof(double) * 4096, hipMemcpyDeviceToHost));
@@ -1224,6 +1238,14 @@ gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64, double* inv64, 
     HIPCHK(hipMemcpy(&hi, dinfo, sizeof(int), hipMemcpyDeviceToHost));
     if (info) *info = hi;
     hipFree(dS); hipFree(dL); hipFree(dX); hipFree(dinfo);
+    return GMRF_OK;
+}
+
+// diagnostics of the last gmrf_test_potrf_tile: out[0] = us per launch, out[1..17] = s_memtime stamps (cycles, relative)
+gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
+    if (!out || n < 18) return bad_shape("need 18 outputs");
+    out[0] = g_tile_us;
+    for (int i = 0; i < 17; ++i) out[1 + i] = (double)(g_tile_stamps[i] - g_tile_stamps[15]);
     return GMRF_OK;
 }
 

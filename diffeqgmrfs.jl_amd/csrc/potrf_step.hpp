@@ -1,0 +1,439 @@
+// One 64-column panel step of the dense block Cholesky (dpotrf of one bs x bs Schur block,
+// /root/reference/src/tridiagonal_cholesky.jl:67,77) in ONE launch:
+//
+//   every workgroup   : S_jj -> L_jj, X_jj = L_jj^-1      (tile_potrf_inv, redundantly per WG)
+//   workgroup (r, c)  : Lr = S[r,j] X_jj^T, Lc = S[c,j] X_jj^T, S[r,c] -= Lr Lc^T   (j < c <= r)
+//   workgroup (r,j+1) : additionally stores Lr as L[r,j];  workgroup 0 stores L_jj and X_jj.
+//
+// The redundant tile factorisation costs nothing in wall time (the other CUs would idle) and
+// removes two dependent launches per panel.
+//
+// tile_potrf_inv: 64x64 tile in LDS, four 16-column panels.  Wave 0 factors a panel with one
+// row per lane (pivot broadcast by v_readlane, rsqrt + 2 Newton steps, rank-1 updates kept in
+// registers); the 16x16 trailing sub-tiles are updated with v_mfma_f64_16x16x4_f64 by all four
+// waves, the sub-tiles the next panel does not need are deferred and overlap with it
+// (look-ahead); the 16x16 diagonal inverses are built by wave 3 off the critical path and the
+// full 64x64 inverse is assembled by two levels of recursive doubling with MFMA products.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gemm_f64.hpp"
+
+namespace gmrf {
+
+constexpr int TLD = 66;                 // LDS row stride (doubles) of a 64x64 tile
+constexpr int TILE_ELEMS = 64 * TLD;
+
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// 1/sqrt(p) to fp64 accuracy: hardware seed + two Newton steps.
+__device__ __forceinline__ double rsqrt_nr(double p) {
+    double y = __builtin_amdgcn_rsq(p);
+    double e = fma(-p * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-p * y, y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
+
+// acc += sign * A(16x16) * B(16x16)^T  with A at a[i*lda + k], B at b[j*ldb + k]   ("NT")
+__device__ __forceinline__ v4d mm16_nt(const double* a, int lda, const double* b, int ldb, v4d acc,
+                                       bool negate, int li, int lq) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        double av = a[li * lda + 4 * ks + lq];
+        const double bv = b[li * ldb + 4 * ks + lq];
+        if (negate) av = -av;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// acc += sign * A(16x16) * B(16x16)  with A at a[i*lda + k], B at b[k*ldb + j]   ("NN")
+__device__ __forceinline__ v4d mm16_nn(const double* a, int lda, const double* b, int ldb, v4d acc,
+                                       bool negate, int li, int lq) {
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        double av = a[li * lda + 4 * ks + lq];
+        const double bv = b[(4 * ks + lq) * ldb + li];
+        if (negate) av = -av;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// MFMA f64 C/D layout: element reg of lane (li, lq) is (row lq + 4 reg, col li).
+__device__ __forceinline__ v4d load_d16(const double* p, int ld, int li, int lq) {
+    v4d v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = p[(lq + 4 * r) * ld + li];
+    return v;
+}
+__device__ __forceinline__ void store_d16(double* p, int ld, const v4d& v, int li, int lq) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[(lq + 4 * r) * ld + li] = v[r];
+}
+
+// 1/p to fp64 accuracy: hardware seed (24 bits) + two Newton steps (measured 1 ulp, tools/acc.hip).
+__device__ __forceinline__ double rcp_nr(double p) {
+    double y = __builtin_amdgcn_rcp(p);
+    double e = fma(-p, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-p, y, 1.0);
+    y = fma(y, e, y);
+    return y;
+}
+
+// Wave 0: factor the 16 columns [c0, c0+16) of the tile for rows >= c0 (one row per lane).
+//
+// A single wave issues one fp64 VALU instruction every ~8 cycles whatever the dependencies
+// (measured, tools/mb2.hip), so this routine is written for instruction count:
+//   * square-root-free (LDL^T) elimination, columns scaled by rsqrt(p_j) at the end, one rsqrt
+//     per lane instead of one per step;
+//   * no row masks: a finished row (r <= j) keeps "updating" only entries above its diagonal,
+//     which nobody reads (the strict upper triangle of the block is zeroed by the caller);
+//   * the pivot and the one multiplicand the next column needs travel lane -> SGPR by
+//     v_readlane; the other multiplicands of a step are re-read from an LDS copy of the column
+//     as wave-uniform operands (one ds_read_b128 per two rank-1 updates).
+__device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double* lcol, int c0, int lane,
+                                               bool& bad) {
+    const int r = lane;
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = Ts[r * TLD + c0 + c];
+    double* pivs = lcol + 16 * 64;          // 16 pivots
+    double up[16];                          // multiplicands of the previous step (LDS broadcast)
+    double wprev = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) up[c] = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const int j = c0 + jj;
+        const double p = bcast_lane(a[jj], j);
+        if (!(p > 0.0)) bad = true;
+        const double pinv = rcp_nr(p);
+        const double u = a[jj];
+        const double w = u * pinv;
+        lcol[jj * 64 + r] = u;
+        pivs[jj] = p;
+        if (jj < 15) {
+            const double uc1 = bcast_lane(u, j + 1);
+            a[jj + 1] = fma(-w, uc1, a[jj + 1]);
+        }
+        // rank-1 updates of the PREVIOUS step on columns jj+1..15: their multiplicands were
+        // requested from LDS one step ago, so the read latency hides behind the work above
+#pragma unroll
+        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-wprev, up[cc], a[cc]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cc = jj + 2; cc < 16; ++cc) up[cc] = lcol[jj * 64 + c0 + cc];
+        wprev = w;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // scale: L[r][j] = u[r][j] / sqrt(p_j); lane c0+c owns pivot c (its u[r][c] is p_c -> sqrt(p_c))
+    const double pown = pivs[(r - c0) & 15];
+    const double rown = rsqrt_nr(pown);
+    if (r >= c0 && r < c0 + 16) rinvs[r] = rown;
+    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the rinvs written above are read below
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Ts[r * TLD + c0 + c] = a[c] * rinvs[c0 + c];
+}
+
+// One wave: X_kk = L_kk^-1 for the 16x16 diagonal block at c0 (lane c < 16 owns column c).
+// Column-oriented substitution: once x[k] is final every later row gets its update at once, so
+// the dependent chain is 16 (mul, fma) pairs instead of 120 accumulations.
+__device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, double* Xs, int c0, int lane) {
+    if (lane >= 16) return;
+    const int c = lane;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        x[k] = (k >= c) ? x[k] * rinvs[c0 + k] : 0.0;
+#pragma unroll
+        for (int r = k + 1; r < 16; ++r) x[r] = fma(-Ts[(c0 + r) * TLD + c0 + k], x[k], x[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Xs[(c0 + r) * TLD + c0 + c] = x[r];
+}
+
+// Trailing sub-tile (I, J) of the tile: T[I][J] -= P_I P_J^T with the panel at columns c0..c0+15.
+__device__ __forceinline__ void subtile_update(double* Ts, int I, int J, int c0, int li, int lq) {
+    double* ct = Ts + (16 * I) * TLD + 16 * J;
+    v4d acc = load_d16(ct, TLD, li, lq);
+    acc = mm16_nt(Ts + (16 * I) * TLD + c0, TLD, Ts + (16 * J) * TLD + c0, TLD, acc, true, li, lq);
+    store_d16(ct, TLD, acc, li, lq);
+}
+
+// Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
+// Wk: scratch of 4 * 16 * 18 doubles.  All 256 threads of the workgroup must call this.
+struct SideLoad {          // global 64x64 tiles staged into LDS by waves 1-3 during the first panel
+    const double* gA; double* sA;
+    const double* gB; double* sB;
+    int64_t ld;
+    unsigned long long* stamps;     // diagnostic: s_memtime at phase boundaries (tests only)
+};
+
+#define TILE_STAMP(i) do { if (side.stamps && tid == 0) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+
+__device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int64_t ld, double* s, int t192) {
+    for (int idx = t192; idx < 2048; idx += 192) {
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        *reinterpret_cast<v2d*>(s + r * TLD + c) = *reinterpret_cast<const v2d*>(g + (int64_t)r * ld + c);
+    }
+}
+
+__device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid,
+                                               bool& bad, const SideLoad& side) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    // clear X (its strict upper part and the blocks the assembly does not write stay zero) and
+    // the 16x16 blocks of the input above the block diagonal (they are part of the output L)
+    TILE_STAMP(0);
+    // zero the six 16x16 blocks above the block diagonal of L (part of the output) and of X
+    for (int i = tid; i < 6 * 256; i += 256) {
+        const int b = i >> 8, e = i & 255;
+        const int I = (b < 3) ? 0 : ((b < 5) ? 1 : 2);
+        const int J = (b < 3) ? b + 1 : ((b < 5) ? b - 1 : 3);
+        const int off = (16 * I + (e >> 4)) * TLD + 16 * J + (e & 15);
+        Ts[off] = 0.0;
+        Xs[off] = 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int c0 = 16 * kb;
+        TILE_STAMP(1 + 3 * kb);
+        if (wave == 0) {
+            panel_factor16(Ts, rinvs, Wk, c0, lane, bad);
+            TILE_STAMP(2 + 3 * kb);
+        } else if (kb == 0) {
+            if (side.gA) side_load_tile(side.gA, side.ld, side.sA, tid - 64);
+            if (side.gB) side_load_tile(side.gB, side.ld, side.sB, tid - 64);
+        } else {
+            // deferred work of the previous panel (columns c0-16..c0-1): sub-tiles (I, J >= kb+1)
+            const int pc0 = c0 - 16;
+            if (kb == 1) {
+                if (wave == 1) subtile_update(Ts, 2, 2, pc0, li, lq);
+                if (wave == 2) subtile_update(Ts, 3, 2, pc0, li, lq);
+                if (wave == 3) { subtile_update(Ts, 3, 3, pc0, li, lq); }
+            } else if (kb == 2) {
+                if (wave == 1) subtile_update(Ts, 3, 3, pc0, li, lq);
+            }
+            if (wave == 3) inv16(Ts, rinvs, Xs, pc0, lane);
+        }
+        __syncthreads();
+        TILE_STAMP(3 + 3 * kb);
+        if (kb < 3) {
+            // sub-tiles of the next panel's columns: (I, kb+1), I = kb+1 .. 3
+            const int I = kb + 1 + wave;
+            if (I <= 3) subtile_update(Ts, I, kb + 1, c0, li, lq);
+        }
+        __syncthreads();
+    }
+    TILE_STAMP(13);
+    // rows above a panel's diagonal received don't-care values: zero the strict upper triangles
+    // of the four diagonal 16x16 blocks (waves 1, 2; waves 0 and 3 start the inverse assembly)
+    if (wave == 1 || wave == 2) {
+        for (int i = tid - 64; i < 4 * 256; i += 128) {
+            const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
+            if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
+        }
+    }
+    // --- inverse assembly.  wave 3: last diagonal inverse; wave 0: T = L10 X00 of pair 0
+    double* W0 = Wk;
+    double* W1 = Wk + 16 * 18;
+    double* W2 = Wk + 2 * 16 * 18;
+    double* W3 = Wk + 3 * 16 * 18;
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (wave == 3) inv16(Ts, rinvs, Xs, 48, lane);
+    if (wave == 0) {
+        v4d t = mm16_nn(Ts + 16 * TLD, TLD, Xs, TLD, zero, false, li, lq);             // L10 X00
+        store_d16(W0, 18, t, li, lq);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        v4d x = mm16_nn(Xs + 16 * TLD + 16, TLD, W0, 18, zero, true, li, lq);          // X10 = -X11 T
+        store_d16(Xs + 16 * TLD, TLD, x, li, lq);
+    }
+    if (wave == 1) {
+        v4d t = mm16_nn(Ts + 48 * TLD + 32, TLD, Xs + 32 * TLD + 32, TLD, zero, false, li, lq);   // L32 X22
+        store_d16(W1, 18, t, li, lq);
+    }
+    __syncthreads();
+    if (wave == 1) {
+        v4d x = mm16_nn(Xs + 48 * TLD + 48, TLD, W1, 18, zero, true, li, lq);          // X32 = -X33 T
+        store_d16(Xs + 48 * TLD + 32, TLD, x, li, lq);
+    }
+    __syncthreads();
+    // level 2: blocks I in {2,3}, J in {0,1}:  T[I][J] = sum_{K in {J..1}} L[I][K] X[K][J]
+    {
+        const int I = 2 + (wave >> 1), J = wave & 1;
+        double* Wm = Wk + wave * 16 * 18;
+        v4d t = zero;
+        for (int K = J; K < 2; ++K)
+            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+        store_d16(Wm, 18, t, li, lq);
+    }
+    __syncthreads();
+    {
+        // X[I][J] = - sum_{K in {2..I}} X[I][K] T[K][J];  T[K][J] lives in W[(K-2)*2 + J]
+        const int I = 2 + (wave >> 1), J = wave & 1;
+        v4d x = zero;
+        for (int K = 2; K <= I; ++K)
+            x = mm16_nn(Xs + (16 * I) * TLD + 16 * K, TLD, Wk + ((K - 2) * 2 + J) * 16 * 18, 18, x, true, li, lq);
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
+    }
+    __syncthreads();
+    TILE_STAMP(14);
+    (void)W2; (void)W3;
+}
+
+// 64x64 tile: global (row stride ld) -> LDS (row stride TLD), 256 threads.
+__device__ __forceinline__ void tile_g2s(const double* __restrict__ g, int64_t ld, double* s, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * 256;            // 2048 v2d
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        *reinterpret_cast<v2d*>(s + r * TLD + c) = *reinterpret_cast<const v2d*>(g + (int64_t)r * ld + c);
+    }
+}
+__device__ __forceinline__ void tile_s2g(const double* s, double* __restrict__ g, int64_t ld, int tid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        *reinterpret_cast<v2d*>(g + (int64_t)r * ld + c) = *reinterpret_cast<const v2d*>(s + r * TLD + c);
+    }
+}
+
+struct StepArgs {
+    double* S;            // bsp x bsp Schur block (lower tiles valid); trailing tiles updated in place
+    double* L;            // factor block
+    double* X;            // inverse block (diagonal tile written here)
+    int64_t ld;
+    int j;                // panel index
+    int nt;               // tiles per dimension
+    int* info;
+    int blk;              // block id reported on a non-positive pivot (1-based)
+};
+
+// grid.x = 1 + m (m + 1) / 2,  m = nt - j - 1.
+__global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ts = smem;
+    double* Xs = Ts + TILE_ELEMS;
+    double* As = Xs + TILE_ELEMS;
+    double* Bs = As + TILE_ELEMS;
+    double* Wk = Bs + TILE_ELEMS;               // 4 * 16 * 18
+    double* rinvs = Wk + 4 * 16 * 18;           // 64
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld;
+    const int64_t oj = (int64_t)sa.j * 64;
+
+    int r = 0, c = 0;
+    const int w = blockIdx.x;
+    if (w > 0) {
+        int t = w - 1, rr = 0;
+        while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+        r = sa.j + 1 + rr;
+        c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+    }
+    tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
+    // the C tile this wave will update (rows 16*wave.., MFMA C/D layout), fetched now, used last
+    double* Sg = sa.S + (int64_t)r * 64 * ld + (int64_t)c * 64;
+    v4d cpre[4];
+    if (w > 0) {
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cpre[Jb][q] = Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li];
+    }
+    SideLoad side;
+    side.gA = (w > 0) ? sa.S + (int64_t)r * 64 * ld + oj : nullptr; side.sA = As;
+    side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
+    side.ld = ld; side.stamps = nullptr;
+    __syncthreads();
+    bool bad = false;
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+    if (w == 0) {
+        if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
+        tile_s2g(Ts, sa.L + oj * ld + oj, ld, tid);
+        tile_s2g(Xs, sa.X + oj * ld + oj, ld, tid);
+        return;
+    }
+    // ---- panel rows: Lr = As Xs^T (X lower triangular: column block Jb needs k-blocks 0..Jb)
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    v4d lr[4], lc[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        lr[Jb] = zero;
+        lc[Jb] = zero;
+#pragma unroll
+        for (int Kb = 0; Kb <= Jb; ++Kb) {
+            lr[Jb] = mm16_nt(As + (16 * wave) * TLD + 16 * Kb, TLD, Xs + (16 * Jb) * TLD + 16 * Kb, TLD, lr[Jb],
+                             false, li, lq);
+            if (c != r)
+                lc[Jb] = mm16_nt(Bs + (16 * wave) * TLD + 16 * Kb, TLD, Xs + (16 * Jb) * TLD + 16 * Kb, TLD,
+                                 lc[Jb], false, li, lq);
+        }
+    }
+    __syncthreads();                                   // every wave is done reading As / Bs
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+        if (c != r) store_d16(Bs + (16 * wave) * TLD + 16 * Jb, TLD, lc[Jb], li, lq);
+    }
+    __syncthreads();
+    if (c == sa.j + 1) tile_s2g(As, sa.L + (int64_t)r * 64 * ld + oj, ld, tid);
+    // ---- S[r,c] -= Lr Lc^T ; wave owns rows 16*wave.., on a diagonal tile only Jb <= wave matters
+    const double* Lcs = (c != r) ? Bs : As;
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        if (c == r && Jb > wave) continue;
+        v4d acc = cpre[Jb];
+#pragma unroll
+        for (int Kb = 0; Kb < 4; ++Kb)
+            acc = mm16_nt(As + (16 * wave) * TLD + 16 * Kb, TLD, Lcs + (16 * Jb) * TLD + 16 * Kb, TLD, acc, true,
+                          li, lq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = acc[q];
+    }
+}
+
+constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+
+// Stand-alone tile kernel (tests): S (ld 64) -> L, X.
+__global__ __launch_bounds__(256, 2) void potrf_tile_kernel(const double* S, double* L, double* X, int* info,
+                                                            unsigned long long* stamps) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ts = smem;
+    double* Xs = Ts + TILE_ELEMS;
+    double* Wk = Xs + TILE_ELEMS;
+    double* rinvs = Wk + 4 * 16 * 18;
+    const int tid = threadIdx.x;
+    tile_g2s(S, 64, Ts, tid);
+    __syncthreads();
+    bool bad = false;
+    SideLoad side;
+    side.gA = nullptr; side.gB = nullptr; side.sA = nullptr; side.sB = nullptr; side.ld = 0; side.stamps = stamps;
+    if (stamps && tid == 0) stamps[15] = __builtin_amdgcn_s_memtime();
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+    if (bad && tid == 0) atomicCAS(info, 0, 1);
+    tile_s2g(Ts, L, 64, tid);
+    tile_s2g(Xs, X, 64, tid);
+    if (stamps && tid == 0) stamps[16] = __builtin_amdgcn_s_memtime();
+}
+constexpr size_t POTRF_TILE_LDS = (2 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+
+}  // namespace gmrf

@@ -210,6 +210,7 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
                            int64_t ldb, double beta, double* C, int64_t ldc);
 gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64 /* in: SPD, out: L */,
                                  double* inv64, int32_t* info);
+gmrf_status gmrf_test_tile_timing(double* out, int32_t n);
 gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/out: L */,
                                   double* Linv, int32_t* info);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
