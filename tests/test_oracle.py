@@ -131,3 +131,30 @@ def test_metrics_match_reference_definitions():
     assert O.rmse(p, s) == pytest.approx(np.sqrt(5.0 / 3.0))
     assert O.max_err(p, s) == 2.0
     assert O.rel_err(p, s) == pytest.approx(np.sqrt(5.0) / np.sqrt(6.0))
+
+
+def test_c_restatement_agrees_with_numpy_oracle(pkg):
+    """oracle/bt_oracle.c (dependency-free) against the LAPACK-backed oracle on a small case."""
+    import ctypes as C
+    path = os.path.join(os.path.dirname(os.path.dirname(__file__)), "oracle", "libbt_oracle.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/libbt_oracle.so not built (run __graft_entry__.build())")
+    lib = C.CDLL(path)
+    w = pkg.workloads.random_block_tridiagonal(5, 12, seed=6)
+    N, bs = 5, 12
+    A = w.Q.toarray()
+    D = np.ascontiguousarray(np.stack([A[i * bs:(i + 1) * bs, i * bs:(i + 1) * bs] for i in range(N)]))
+    B = np.ascontiguousarray(np.stack([A[(i + 1) * bs:(i + 2) * bs, i * bs:(i + 1) * bs] for i in range(N - 1)]))
+    Ld = np.zeros_like(D); Cs = np.zeros_like(B)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.bt_factor_dense.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.bt_solve_dense.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    assert lib.bt_factor_dense(N, bs, p(D), p(B), p(Ld), p(Cs)) == 0
+    F = O.tridiagonal_cholesky(w.Q, N)
+    assert np.max(np.abs(Ld - np.stack(F.chos))) < 1e-12 and np.max(np.abs(Cs - np.stack(F.Cs))) < 1e-12
+    for mode, ref in [(0, O.ldiv(F, w.rhs)), (1, O.forward_solve(F, w.rhs)), (2, O.backward_solve(F, w.rhs))]:
+        y = np.zeros(N * bs)
+        lib.bt_solve_dense(N, bs, p(Ld), p(Cs), p(np.ascontiguousarray(w.rhs)), p(y), mode)
+        assert rel(y, ref) < 1e-12
+    D[2, 3, 3] = -5.0
+    assert lib.bt_factor_dense(N, bs, p(D), p(B), p(Ld), p(Cs)) == 3
