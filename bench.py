@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- GMRF posterior solves/sec (mean + samples) on the 256x256 Darcy posterior.
 
-One step = one posterior job on the block-tridiagonal path: numeric factorisation of
-Q_post (values already in HBM, sparsity pattern analysed once before the timed region, like
-the reference re-uses its permutation, scripts/darcy/solve_darcy_gmrf-fem.jl:166-174), the
-posterior mean (forward + backward sweep) and 64 posterior samples per GPU (backward sweep of
-64 right-hand sides).  value = (1 + 64 * n_gpus) * steps / time.
+One step = one pass of the hot path over one batch of synthetic input: B independent 256^2
+Darcy posteriors per GPU (same mesh and sparsity pattern, B coefficient fields -- the per-problem
+loop of scripts/darcy/solve_darcy_gmrf-fem.jl:176-198), each one: numeric factorisation of
+Q_post (values already in HBM; the pattern is analysed once before the timed region, like the
+reference re-uses its permutation, :166-174), the posterior mean (forward + backward sweep) and
+64 posterior samples (backward sweep of 64 right-hand sides).  The B problems advance in lock
+step (problem = one more grid dimension of every kernel): the factorisation is a chain of
+latency-bound launches that fills <= 121 of the 256 CUs, a batch fills the rest.
+value = n_gpus * B * (1 + 64) * steps / time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU; rank 0 factors and broadcasts the factor block-range by block-range
-over RCCL while factoring the next range; every rank then draws its own 64 samples.
+N > 1, default (--mode problems): every rank handles its own batch of problems, no data-path
+collective (weak scaling).  --mode shared-factor: ONE problem; rank 0 factors and broadcasts the
+factor block-range by block-range over RCCL while factoring the next range; every rank draws
+its own 64 samples of the shared posterior.
 """
 from __future__ import annotations
 
@@ -68,9 +74,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="darcy256")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (N > 1)")
-    ap.add_argument("--replicate-factor", action="store_true",
-                    help="N > 1: every rank factors for itself instead of the RCCL broadcast")
+    ap.add_argument("--batch", type=int, default=4, help="independent problems per handle and step")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent batched handles per GPU, each on its own HIP stream and host thread")
+    ap.add_argument("--mode", choices=["problems", "shared-factor"], default="problems")
+    ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -89,13 +97,39 @@ def main():
                                 device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
 
+    import numpy as np
     w = pkg.workloads.make(args.config)
     from importlib import import_module
     post = import_module(g.PKG_NAME + ".posterior")
-    eng = post.HipEngine(pkg, w, device_index=local)
-    job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=args.samples,
-                                group=args.group, replicate_factor=args.replicate_factor)
-    job.prepare()
+    import threading
+    shared = (args.mode == "shared-factor" and world > 1)
+    batch = 1 if shared else args.batch
+    n_streams = 1 if shared else max(1, args.streams)
+    # coefficient fields on the same mesh: same pattern, different values
+    total_problems = batch * n_streams
+    vals, rhss = [w.Q.data], [w.rhs]
+    for p in range(1, min(total_problems, 8)):
+        if args.config.startswith("darcy"):
+            wp = pkg.workloads.darcy(int(args.config[5:]), seed=523802340 + 1000 * rank + p)
+            same = wp.Q.nnz == w.Q.nnz and np.array_equal(wp.Q.indices, w.Q.indices)
+        else:
+            same = False
+        if same:
+            vals.append(wp.Q.data); rhss.append(wp.rhs)
+        else:
+            vals.append(w.Q.data * (1.0 + 0.01 * p)); rhss.append(w.rhs)
+    jobs = []
+    for t in range(n_streams):
+        st_t = torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream()
+        idx = [(t * batch + p) % len(vals) for p in range(batch)]
+        with torch.cuda.stream(st_t):
+            e_t = post.HipEngine(pkg, w, device_index=local, batch=batch, values=np.stack([vals[i] for i in idx]),
+                                 rhs=np.stack([rhss[i] for i in idx]))
+            j_t = post.ShardedPosterior(e_t, dist=dist if shared else None, rank=rank, world=world if shared else 1,
+                                        k_samples=args.samples, group=args.group, replicate_factor=not shared)
+            j_t.prepare()
+        jobs.append((st_t, e_t, j_t))
+    eng, job = jobs[0][1], jobs[0][2]
 
     def sync():
         torch.cuda.synchronize()
@@ -103,12 +137,27 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for s in range(args.warmup):
-        job.step(s)
+    def run_steps(first, count):
+        """`count` steps on every handle; with several handles each one is driven by its own host
+        thread on its own stream (the C ABI releases the GIL) so that their launch chains overlap."""
+        def worker(st_t, j_t):
+            with torch.cuda.stream(st_t):
+                for s in range(count):
+                    j_t.step(first + s)
+                st_t.synchronize()
+        if len(jobs) == 1:
+            worker(jobs[0][0], jobs[0][2])
+            return
+        ths = [threading.Thread(target=worker, args=(st_t, j_t)) for st_t, _, j_t in jobs]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    run_steps(0, args.warmup)
     sync()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        mu, X = job.step(args.warmup + s)
+    run_steps(args.warmup, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -118,22 +167,28 @@ def main():
 
     out = None
     if rank == 0:
-        solves = job.solves_per_step() * args.steps
+        per_step = job.solves_per_step() if shared else world * n_streams * batch * (1 + args.samples)
+        solves = per_step * args.steps
         st = eng.F.stats()
         out = {
             "metric": "GMRF posterior solves/sec (mean+samples), 256^2 Darcy",
             "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}, "
-                                   f"mean + {args.samples} samples per GPU",
-                       "factor_sharing": "replicated" if job.replicate else f"rccl-broadcast/{args.group}-block ranges"},
+            "config": {"workload": f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; "
+                                   f"{n_streams * batch} independent posterior(s) per GPU and step ({n_streams} stream(s) x "
+                                   f"batch {batch}), each factor + mean + {args.samples} samples",
+                       "problems_per_gpu_per_step": n_streams * batch, "streams": n_streams, "batch": batch,
+                       "samples_per_problem": args.samples,
+                       "sharding": "independent problems per rank, no data-path collective" if job.replicate
+                       else f"one shared factor, rccl broadcast in {args.group}-block ranges, samples sharded"},
         }
     # ---- per-kernel roofline + parity + CPU baseline: rank 0, outside the timed region
     if rank == 0 and world == 1:
         import numpy as np
         eng.F.set_profiling(1)
-        job.step(10_000)
+        with torch.cuda.stream(jobs[0][0]):
+            job.step(10_000)
         torch.cuda.synchronize()
         st = eng.F.stats()
         eng.F.set_profiling(0)
@@ -153,7 +208,7 @@ def main():
                                                   ("tflops" if KERNEL_CLASSES[c][1] == "mfma" else "gbps"):
                                                   (work[c] / (ms[c] * 1e-3) / (1e12 if KERNEL_CLASSES[c][1] == "mfma" else 1e9)) if ms[c] > 0 else 0.0}
                           for c in KERNEL_CLASSES}
-        # phase times of the un-instrumented path
+        # phase times of the un-instrumented path (whole batch)
         eng.F.refactor(eng.nz)
         mu = eng.mean()
         s1 = eng.F.stats()
@@ -162,14 +217,25 @@ def main():
         out["phases_ms"] = {"factor": s1["factor_ms"], "mean_2_sweeps": s1["solve_ms"], "samples_1_sweep": s2["sample_ms"]}
         out["factor_tflops"] = st["factor_flops"] / (s1["factor_ms"] * 1e-3) / 1e12
         out["sweep_k1_gbps"] = s1["sweep_bytes"] / (0.5 * s1["solve_ms"] * 1e-3) / 1e9
+        # latency of ONE problem (batch 1) on the same GPU, for reference
+        F1 = pkg.TridiagonalCholeskyFactor(device=local, stream=eng.stream.cuda_stream).factor(w.Q, w.n_blocks)
+        nz1 = eng.nz[0].contiguous(); rhs1 = eng.rhs[0, 0].contiguous()
+        for _ in range(2):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            F1.refactor(nz1); mu1 = pkg.ldiv(F1, rhs1); X1 = F1.sample(args.samples, mean=mu1, seed=1, like=rhs1)
+            torch.cuda.synchronize(); lat = time.perf_counter() - t1
+        out["single_problem"] = {"latency_ms": 1e3 * lat, "solves_per_s": (1 + args.samples) / lat}
         if not args.no_cpu_baseline:
             base, (mu_o, X_o, Z) = cpu_baseline(w, args.samples)
             out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
             out["speedup_vs_cpu"] = out["value"] / base["value"]
-            mu_h = mu.cpu().numpy()
-            Xh = eng.F.sample(args.samples, mean=mu_o, z=Z)
+            mu_h = mu1.cpu().numpy()
+            Xh = F1.sample(args.samples, mean=mu_o, z=Z)
+            cond_eps = 3.4e9 * 2.2e-16 if w.name == "darcy256" else None
             out["parity"] = {"mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
-                             "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o))}
+                             "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o)),
+                             "bound_0.1_cond_eps": 0.1 * cond_eps if cond_eps else None}
+        F1.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -27,7 +27,7 @@ EXPORTS = [
     "gmrf_bt_var_accumulate", "gmrf_bt_logdet", "gmrf_bt_get_block", "gmrf_bt_factor_buffer",
     "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
-    "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize",
+    "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
     "gmrf_test_gemm", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
@@ -108,6 +108,8 @@ def load() -> C.CDLL:
         "gmrf_bt_set_profiling": [vp, i32],
         "gmrf_bt_set_eager": [vp, i32],
         "gmrf_bt_synchronize": [vp],
+        "gmrf_bt_set_batch": [vp, i64],
+        "gmrf_bt_select_problem": [vp, i64],
         "gmrf_csr_create": [i32, vp, i64, i64, vp, vp, vp, i32, i32, P(vp)],
         "gmrf_csr_destroy": [vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],

@@ -127,10 +127,13 @@ class TridiagonalCholeskyFactor:
     lower-triangular L_i, `Cs[i]` = L_{i+1,i}.
     """
 
-    def __init__(self, device: int = 0, stream: int = 0):
+    def __init__(self, device: int = 0, stream: int = 0, batch: int = 1):
         self._h = C.c_void_p()
         self._lib = _cabi.load()
         _cabi.check(self._lib.gmrf_bt_create(device, C.c_void_p(stream), C.byref(self._h)))
+        self.batch = 1
+        if batch != 1:
+            self.set_batch(batch)
         self.N = 0
         self.n_blocks = 0
         self.block_size = 0
@@ -149,8 +152,49 @@ class TridiagonalCholeskyFactor:
         except Exception:
             pass
 
+    # -- batch of independent problems on one sparsity pattern
+    def set_batch(self, batch: int):
+        _cabi.check(self._lib.gmrf_bt_set_batch(self._h, int(batch)))
+        self.batch = int(batch)
+
+    def select_problem(self, p: int):
+        _cabi.check(self._lib.gmrf_bt_select_problem(self._h, int(p)))
+
+    def solve_batch(self, b, mode: int = _cabi.SOLVE_FULL):
+        """b: (B, k, n) C-contiguous NumPy array / torch CUDA tensor (each right-hand side
+        contiguous) -> same shape.  Problem p is solved with factor p."""
+        B, k, n = b.shape
+        if B != self.batch or n != self.N:
+            raise ValueError("expected shape (batch, k, n)")
+        if _is_torch(b):
+            import torch
+            b = b.contiguous()
+            out = torch.empty_like(b)
+        else:
+            b = np.ascontiguousarray(b, dtype=np.float64)
+            out = np.empty_like(b)
+        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(b), _cabi.ptr(out), k, n, mode))
+        return out
+
+    def sample_batch(self, k: int, mean=None, seed: int = 0x5EED, first_id: int = 0, like=None):
+        """(B, k, n) samples: problem p, sample s = mean[p] + L_p^-T z(id = first_id + p*k + s)."""
+        B, n = self.batch, self.N
+        ref = like if like is not None else mean
+        if _is_torch(ref):
+            import torch
+            out = torch.empty((B, k, n), dtype=torch.float64, device=ref.device)
+            if mean is not None:
+                mean = mean.contiguous()
+        else:
+            out = np.empty((B, k, n), dtype=np.float64)
+            if mean is not None:
+                mean = np.ascontiguousarray(mean, dtype=np.float64)
+        _cabi.check(self._lib.gmrf_bt_sample(self._h, seed, first_id, k, _cabi.ptr(mean), None, _cabi.ptr(out), n))
+        return out
+
     # -- factorisation
-    def factor(self, A, N_blocks: int):
+    def factor(self, A, N_blocks: int, values=None):
+        """`values`: (batch, nnz) array of CSC values for a batch of problems on the pattern of A."""
         A = sp.csc_matrix(A)
         if A.shape[0] != A.shape[1]:
             raise ValueError("matrix must be square")
@@ -160,7 +204,9 @@ class TridiagonalCholeskyFactor:
         n = A.shape[0]
         colptr = A.indptr.astype(np.int64)
         rowval = A.indices.astype(np.int64)
-        nz = np.ascontiguousarray(A.data, dtype=np.float64)
+        nz = np.ascontiguousarray(A.data if values is None else values, dtype=np.float64)
+        if nz.size != self.batch * A.nnz:
+            raise ValueError("values must hold batch * nnz entries")
         info = C.c_int32(0)
         st = self._lib.gmrf_bt_factor_csc(self._h, n, int(N_blocks), _cabi.ptr(colptr), _cabi.ptr(rowval),
                                           _cabi.ptr(nz), 0, C.byref(info))

@@ -34,7 +34,9 @@ struct GemmArgs {
     const double* B;
     double* C;
     int64_t lda, ldb, ldc;
-    int64_t strideA, strideB, strideC;   // batch strides (blockIdx.z), in elements
+    int64_t strideA, strideB, strideC;   // inner batch strides (blockIdx.z % nb1), in elements
+    int64_t pA, pB, pC;                  // outer (problem) strides (blockIdx.z / nb1)
+    int nb1;                             // inner batch count (>= 1)
     int M, N, K;
     int tri;
     int lower_only;                      // skip tiles strictly above the block diagonal
@@ -109,9 +111,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     const int bm = blockIdx.y, bn = blockIdx.x;
     if (g.lower_only && bn > bm) return;
     const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
-    const double* __restrict__ A = g.A + (int64_t)blockIdx.z * g.strideA;
-    const double* __restrict__ B = g.B + (int64_t)blockIdx.z * g.strideB;
-    double* __restrict__ C = g.C + (int64_t)blockIdx.z * g.strideC;
+    const int zi = blockIdx.z % g.nb1, zp = blockIdx.z / g.nb1;
+    const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
+    const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
+    double* __restrict__ C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
 
     int kb = 0, ke = g.K;
     if (g.tri & TRI_A_LOWER) ke = min(ke, m0 + GEMM_BM);

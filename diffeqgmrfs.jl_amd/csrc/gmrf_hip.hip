@@ -95,6 +95,9 @@ struct gmrf_handle {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t n = 0, N = 0, bs = 0, bsp = 0, n_pad = 0;
+    int64_t B = 1;                     // independent problems factored / solved in lock step
+    int64_t sel = 0;                   // problem the accessors (get_block, logdet, ...) address
+    int64_t alloc_B = 0, vals_B = 0;
     // symbolic
     int64_t nnz_in = 0, n_entries = 0;
     uint64_t* d_keys = nullptr;
@@ -181,19 +184,20 @@ static void prof_collect(gmrf_handle* h) {
 // ------------------------------------------------------------------------------------ helpers
 static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K, int tri, int lower_only,
                         double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
-                        double beta, double* C, int64_t ldc, int batch = 1, int64_t sA = 0,
-                        int64_t sB = 0, int64_t sC = 0) {
+                        double beta, double* C, int64_t ldc, int64_t pA, int64_t pB, int64_t pC,
+                        int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0) {
     GemmArgs g;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = sA; g.strideB = sB; g.strideC = sC;
+    g.pA = pA; g.pB = pB; g.pC = pC; g.nb1 = batch;
     g.M = M; g.N = N; g.K = K; g.tri = tri; g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta; g.stamps = nullptr;
-    double flops = 2.0 * M * N * (double)K * batch;
+    double flops = 2.0 * M * N * (double)K * batch * (double)h->B;
     if (lower_only) flops *= 0.5 * (1.0 + 64.0 / std::max(M, 64));
     if (tri) flops *= 0.5 * (1.0 + 64.0 / std::max(K, 64));
     ProfScope ps(h, 0, flops);
-    HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch));
+    HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch * (int)h->B));
     return GMRF_OK;
 }
 
@@ -203,14 +207,14 @@ static void free_dev(void* p) {
 
 static gmrf_status alloc_work(gmrf_handle* h);
 static gmrf_status alloc_factor(gmrf_handle* h) {
-    if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->d_L) return GMRF_OK;
+    if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->alloc_B == h->B && h->d_L) return GMRF_OK;
     if (h->external_storage) { g_last_error = "external factor storage does not match the shape"; return GMRF_ERR_BAD_SHAPE; }
     destroy_graphs(h);
     free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
     free_dev(h->d_logdet);
     h->d_L = h->d_C = h->d_Linv = h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
-    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double);
+    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double) * (size_t)h->B;
     HIPCHK(hipMalloc(&h->d_L, blk * h->N));
     HIPCHK(hipMalloc(&h->d_Linv, blk * h->N));
     HIPCHK(hipMalloc(&h->d_C, blk * std::max<int64_t>(h->N - 1, 1)));
@@ -219,17 +223,17 @@ static gmrf_status alloc_factor(gmrf_handle* h) {
 }
 
 static gmrf_status alloc_work(gmrf_handle* h) {
-    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double);
+    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double) * (size_t)h->B;
     HIPCHK(hipMalloc(&h->d_S, blk));
     HIPCHK(hipMalloc(&h->d_B, blk));
     HIPCHK(hipMalloc(&h->d_T, blk));
     HIPCHK(hipMalloc(&h->d_W, blk));
-    HIPCHK(hipMalloc(&h->d_logdet, sizeof(double) * h->N));
+    HIPCHK(hipMalloc(&h->d_logdet, sizeof(double) * h->N * h->B));
     // tiles strictly above the block diagonal of L / Linv are never written: keep them zero
     HIPCHK(hipMemsetAsync(h->d_L, 0, blk * h->N, h->stream));
     HIPCHK(hipMemsetAsync(h->d_Linv, 0, blk * h->N, h->stream));
     HIPCHK(hipMemsetAsync(h->d_C, 0, blk * std::max<int64_t>(h->N - 1, 1), h->stream));
-    h->alloc_N = h->N; h->alloc_bsp = h->bsp;
+    h->alloc_N = h->N; h->alloc_bsp = h->bsp; h->alloc_B = h->B;
     h->stats.factor_bytes = (int64_t)(blk * (3 * h->N - 1));
     return GMRF_OK;
 }
@@ -247,7 +251,7 @@ static gmrf_status set_shape(gmrf_handle* h, int64_t n, int64_t N) {
     h->bsp = 64 * next_pow2((bs + 63) / 64);
     h->n_pad = h->bsp * N;
     h->stats.n = n; h->stats.n_blocks = N; h->stats.block_size = bs; h->stats.block_size_padded = h->bsp;
-    h->stats.factor_flops = (double)N * bs * bs * bs / 3.0 + (double)(N - 1) * 2.0 * bs * bs * bs;
+    h->stats.factor_flops = ((double)N * bs * bs * bs / 3.0 + (double)(N - 1) * 2.0 * bs * bs * bs) * (double)h->B;
     return GMRF_OK;
 }
 
@@ -257,9 +261,9 @@ static gmrf_status ensure_panels(gmrf_handle* h, int64_t kp) {
     h->sweep_graphs.clear();
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
     h->d_P = h->d_Y = h->d_Tp = nullptr;
-    HIPCHK(hipMalloc(&h->d_P, sizeof(double) * kp * h->n_pad));
-    HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * kp * h->n_pad));
-    HIPCHK(hipMalloc(&h->d_Tp, sizeof(double) * kp * h->bsp));
+    HIPCHK(hipMalloc(&h->d_P, sizeof(double) * kp * h->n_pad * h->B));
+    HIPCHK(hipMalloc(&h->d_Y, sizeof(double) * kp * h->n_pad * h->B));
+    HIPCHK(hipMalloc(&h->d_Tp, sizeof(double) * kp * h->bsp * h->B));
     h->kp_cap = kp;
     return GMRF_OK;
 }
@@ -296,9 +300,10 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
     h->nnz_in = nnz_in;
     const size_t ne = std::max<size_t>(keys.size(), 1);
     HIPCHK(hipMalloc(&h->d_keys, ne * sizeof(uint64_t)));
-    HIPCHK(hipMalloc(&h->d_vals, ne * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_vals, ne * sizeof(double) * h->B));
     HIPCHK(hipMalloc(&h->d_src, ne * sizeof(int64_t)));
-    HIPCHK(hipMalloc(&h->d_nz_stage, std::max<int64_t>(nnz_in, 1) * sizeof(double)));
+    HIPCHK(hipMalloc(&h->d_nz_stage, std::max<int64_t>(nnz_in, 1) * sizeof(double) * h->B));
+    h->vals_B = h->B;
     if (!keys.empty()) {
         HIPCHK(hipMemcpy(h->d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
@@ -336,23 +341,31 @@ static gmrf_status analyze_csc(gmrf_handle* h, int64_t n, int64_t N, const int64
     return upload_entries(h, dg, lo, nnz);
 }
 
+// blockIdx.y = problem: nzval of problem p starts at nz + p * nnz
 __global__ void gather_values(const double* __restrict__ nz, const int64_t* __restrict__ src,
-                              int64_t count, double* __restrict__ vals) {
+                              int64_t count, double* __restrict__ vals, int64_t nnz) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) vals[i] = nz[src[i]];
+    if (i < count) vals[(int64_t)blockIdx.y * count + i] = nz[(int64_t)blockIdx.y * nnz + src[i]];
 }
 
 static gmrf_status load_values(gmrf_handle* h, const double* nzval) {
     if (!nzval) return bad_shape("null nzval");
     const double* d_nz = nzval;
+    if (h->vals_B != h->B) {            // batch size changed after the analysis: resize the value buffers
+        free_dev(h->d_vals); free_dev(h->d_nz_stage);
+        h->d_vals = nullptr; h->d_nz_stage = nullptr;
+        HIPCHK(hipMalloc(&h->d_vals, std::max<int64_t>(h->n_entries, 1) * sizeof(double) * h->B));
+        HIPCHK(hipMalloc(&h->d_nz_stage, std::max<int64_t>(h->nnz_in, 1) * sizeof(double) * h->B));
+        h->vals_B = h->B;
+    }
     if (!is_device_ptr(nzval)) {
-        HIPCHK(hipMemcpyAsync(h->d_nz_stage, nzval, sizeof(double) * h->nnz_in, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_nz_stage, nzval, sizeof(double) * h->nnz_in * h->B, hipMemcpyHostToDevice, h->stream));
         d_nz = h->d_nz_stage;
     }
     if (h->n_entries > 0) {
         const int bl = 256;
-        hipLaunchKernelGGL(gather_values, dim3((unsigned)((h->n_entries + bl - 1) / bl)), dim3(bl), 0,
-                           h->stream, d_nz, h->d_src, h->n_entries, h->d_vals);
+        hipLaunchKernelGGL(gather_values, dim3((unsigned)((h->n_entries + bl - 1) / bl), (unsigned)h->B), dim3(bl), 0,
+                           h->stream, d_nz, h->d_src, h->n_entries, h->d_vals, h->nnz_in);
         HIPCHK(hipGetLastError());
     }
     return GMRF_OK;
@@ -367,10 +380,11 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
         sa.info = h->d_info; sa.blk = blk_id;
+        sa.pS = (int64_t)bsp * bsp; sa.pLX = (int64_t)bsp * bsp * h->N; sa.blk_per_problem = (int)h->N;
         const int m = nt - j - 1;
         const double rem = 64.0 * m;
-        ProfScope ps(h, 1, 64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0);
-        hipLaunchKernelGGL(potrf_step, dim3(1 + m * (m + 1) / 2), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+        ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0) * (double)h->B);
+        hipLaunchKernelGGL(potrf_step, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
         HIPCHK(hipGetLastError());
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
@@ -378,11 +392,12 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const int pairs = bsp / (2 * hh);
         const int64_t st = (int64_t)2 * hh * ld + 2 * hh;
         // T21 = L21 * X11
+        const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld, ld, X, ld, 0.0,
-                  T + (int64_t)hh * ld, ld, pairs, st, st, st));
+                  T + (int64_t)hh * ld, ld, pLX, pLX, pW, pairs, st, st, st));
         // X21 = -X22 * T21
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld,
-                  T + (int64_t)hh * ld, ld, 0.0, X + (int64_t)hh * ld, ld, pairs, st, st, st));
+                  T + (int64_t)hh * ld, ld, 0.0, X + (int64_t)hh * ld, ld, pLX, pW, pLX, pairs, st, st, st));
     }
     return GMRF_OK;
 }
@@ -390,20 +405,23 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
 static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
-    const size_t blk_bytes = (size_t)bsp * bsp * sizeof(double);
+    const size_t blk_bytes = (size_t)bsp * bsp * sizeof(double) * (size_t)h->B;
     const int64_t bstride = (int64_t)bsp * bsp;
+    const int64_t pLX = bstride * h->N, pC = bstride * std::max<int64_t>(h->N - 1, 1);
+    const unsigned nb = (unsigned)h->B;
     for (int64_t i = i0; i < i1; ++i) {
         double* L = h->d_L + i * bstride;
         double* X = h->d_Linv + i * bstride;
         HIPCHK(hipMemsetAsync(h->d_S, 0, blk_bytes, h->stream));
         if (h->diag_count[i] > 0) {
-            hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256)), dim3(256), 0,
-                               h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld);
+            hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256), nb), dim3(256), 0,
+                               h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld,
+                               h->n_entries, bstride);
             HIPCHK(hipGetLastError());
         }
         if (h->bsp > h->bs) {
-            hipLaunchKernelGGL(pad_identity, dim3((unsigned)((h->bsp - h->bs + 255) / 256)), dim3(256), 0,
-                               h->stream, h->d_S, ld, (int)h->bs, bsp);
+            hipLaunchKernelGGL(pad_identity, dim3((unsigned)((h->bsp - h->bs + 255) / 256), nb), dim3(256), 0,
+                               h->stream, h->d_S, ld, (int)h->bs, bsp, bstride);
             HIPCHK(hipGetLastError());
         }
         if (i > 0) {
@@ -411,14 +429,15 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
             const double* Xp = h->d_Linv + (i - 1) * bstride;
             HIPCHK(hipMemsetAsync(h->d_B, 0, blk_bytes, h->stream));
             if (h->low_count[i] > 0) {
-                hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256)), dim3(256), 0,
-                                   h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld);
+                hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256), nb), dim3(256), 0,
+                                   h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld,
+                                   h->n_entries, bstride);
                 HIPCHK(hipGetLastError());
             }
             // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74)
-            GCHK(gemm(h, false, false, bsp, bsp, bsp, TRI_B_UPPER, 0, 1.0, h->d_B, ld, Xp, ld, 0.0, C, ld));
+            GCHK(gemm(h, false, false, bsp, bsp, bsp, TRI_B_UPPER, 0, 1.0, h->d_B, ld, Xp, ld, 0.0, C, ld, bstride, pLX, pC));
             // S = D - C C^T             (src/tridiagonal_cholesky.jl:77)
-            GCHK(gemm(h, false, false, bsp, bsp, bsp, 0, 1, -1.0, C, ld, C, ld, 1.0, h->d_S, ld));
+            GCHK(gemm(h, false, false, bsp, bsp, bsp, 0, 1, -1.0, C, ld, C, ld, 1.0, h->d_S, ld, pC, pC, bstride));
         }
         GCHK(potrf_block(h, h->d_S, L, X, h->d_T, (int)(i + 1)));
     }
@@ -450,7 +469,9 @@ static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
     if (info) *info = hinfo;
     if (hinfo != 0) {
         h->factored = false;
-        g_last_error = "matrix is not positive definite; failed block " + std::to_string(hinfo);
+        g_last_error = "matrix is not positive definite; failed block " + std::to_string((hinfo - 1) % h->N + 1) +
+                       " of problem " + std::to_string((hinfo - 1) / h->N);
+        if (info) *info = (hinfo - 1) % (int)h->N + 1;
         return GMRF_ERR_NOT_SPD;
     }
     h->factored = true;
@@ -485,10 +506,13 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
     const int64_t N = h->N;
     SweepArgs s;
     s.ld = ld; s.bs = bsp;
+    const int nprob = (int)h->B;
+    const int64_t pPanel = (int64_t)kp * npad, pT = (int64_t)kp * bsp;
+    const int64_t pLX = bstride * N, pCm = bstride * std::max<int64_t>(N - 1, 1);
     // class 3 (k = 1): algorithmic bytes of the block read; class 2: flops of the panel product
     const int pclass = (kp == 1) ? 3 : 2;
-    const double blk_bytes_c = (kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp;
-    const double blk_bytes_t = (kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp;
+    const double blk_bytes_c = ((kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp) * nprob;
+    const double blk_bytes_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
     for (int64_t step = 0; step < N; ++step) {
         const int64_t i = backward ? (N - 1 - step) : step;
         const double* rhs = Pin + i * bsp;
@@ -501,9 +525,10 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
             s.Bin = rhs; s.ldb = npad;
             s.Out = h->d_Tp; s.ldo = bsp;
             s.sub = 1;
+            s.pMat = pCm; s.pXin = pPanel; s.pBin = pPanel; s.pOut = pT;
             {
                 ProfScope ps(h, pclass, blk_bytes_c);
-                HIPCHK(launch_sweep(h->stream, backward, false, kp, s));
+                HIPCHK(launch_sweep(h->stream, backward, false, kp, s, nprob));
             }
             rhs = h->d_Tp;
         }
@@ -513,9 +538,10 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
         s.Bin = nullptr; s.ldb = 0;
         s.Out = Yout + i * bsp; s.ldo = npad;
         s.sub = 0;
+        s.pMat = pLX; s.pXin = (step > 0) ? pT : pPanel; s.pBin = 0; s.pOut = pPanel;
         {
             ProfScope ps(h, pclass, blk_bytes_t);
-            HIPCHK(launch_sweep(h->stream, backward, true, kp, s));
+            HIPCHK(launch_sweep(h->stream, backward, true, kp, s, nprob));
         }
     }
     return GMRF_OK;
@@ -552,7 +578,7 @@ static int pad_k(int64_t k) { return k == 1 ? 1 : (int)((k + 15) / 16 * 16); }
 
 static gmrf_status launch_pack(gmrf_handle* h, const double* d_src, int64_t ld, int k, int kp) {
     const int64_t total = (int64_t)kp * h->n_pad;
-    hipLaunchKernelGGL(pack_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, d_src, ld,
+    hipLaunchKernelGGL(pack_panel, dim3((unsigned)((total + 255) / 256), (unsigned)h->B), dim3(256), 0, h->stream, d_src, ld,
                        h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, (int)h->N, k, kp);
     HIPCHK(hipGetLastError());
     return GMRF_OK;
@@ -561,8 +587,8 @@ static gmrf_status launch_pack(gmrf_handle* h, const double* d_src, int64_t ld, 
 static gmrf_status launch_unpack(gmrf_handle* h, const double* panel, double* d_dst, int64_t ld, int k,
                                  const double* d_mean) {
     const int64_t total = h->n * (int64_t)k;
-    hipLaunchKernelGGL(unpack_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, panel,
-                       h->n_pad, d_dst, ld, (int)h->bs, (int)h->bsp, h->n, k, d_mean);
+    hipLaunchKernelGGL(unpack_panel, dim3((unsigned)((total + 255) / 256), (unsigned)h->B), dim3(256), 0, h->stream, panel,
+                       h->n_pad, d_dst, ld, (int)h->bs, (int)h->bsp, h->n, k, pad_k(k), d_mean);
     HIPCHK(hipGetLastError());
     return GMRF_OK;
 }
@@ -615,6 +641,29 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_set_batch(gmrf_handle* h, int64_t batch) {
+    if (!h || batch < 1 || batch > 4096) return bad_shape("batch must be in [1, 4096]");
+    if (batch != h->B) {
+        HIPCHK(hipSetDevice(h->device));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        destroy_graphs(h);
+        h->B = batch;
+        h->sel = 0;
+        h->factored = false;
+        free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
+        h->d_P = h->d_Y = h->d_Tp = nullptr; h->kp_cap = 0;
+        free_dev(h->d_mean); h->d_mean = nullptr;
+        if (h->n > 0) (void)set_shape(h, h->n, h->N);      // flop accounting follows the batch
+    }
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_select_problem(gmrf_handle* h, int64_t p) {
+    if (!h || p < 0 || p >= h->B) return bad_shape("problem index out of range");
+    h->sel = p;
     return GMRF_OK;
 }
 
@@ -762,9 +811,9 @@ gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h) {
 gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr, int64_t* bytes) {
     if (!h || !dev_ptr || !bytes) return bad_shape("null pointer");
     if (!h->d_L) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
-    const int64_t blk = h->bsp * h->bsp * (int64_t)sizeof(double);
+    const int64_t blk = h->bsp * h->bsp * (int64_t)sizeof(double) * h->B;
     if (kind == GMRF_BLOCK_L) { *dev_ptr = h->d_L; *bytes = blk * h->N; }
-    else if (kind == GMRF_BLOCK_C) { *dev_ptr = h->d_C; *bytes = blk * (h->N - 1); }
+    else if (kind == GMRF_BLOCK_C) { *dev_ptr = h->d_C; *bytes = blk * std::max<int64_t>(h->N - 1, 1); }
     else if (kind == GMRF_BLOCK_LINV) { *dev_ptr = h->d_Linv; *bytes = blk * h->N; }
     else return bad_shape("bad block kind");
     return GMRF_OK;
@@ -777,9 +826,10 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
     const int64_t bs = h->bs, bsp = h->bsp;
     if (ld < bs) return bad_shape("ld < block_size");
     const double* src;
-    if (kind == GMRF_BLOCK_L) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_L + i * bsp * bsp; }
-    else if (kind == GMRF_BLOCK_LINV) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_Linv + i * bsp * bsp; }
-    else if (kind == GMRF_BLOCK_C) { if (i < 0 || i >= h->N - 1) return bad_shape("block index"); src = h->d_C + i * bsp * bsp; }
+    const int64_t pLX = h->sel * h->N * bsp * bsp, pCs = h->sel * std::max<int64_t>(h->N - 1, 1) * bsp * bsp;
+    if (kind == GMRF_BLOCK_L) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_L + pLX + i * bsp * bsp; }
+    else if (kind == GMRF_BLOCK_LINV) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_Linv + pLX + i * bsp * bsp; }
+    else if (kind == GMRF_BLOCK_C) { if (i < 0 || i >= h->N - 1) return bad_shape("block index"); src = h->d_C + pCs + i * bsp * bsp; }
     else return bad_shape("bad block kind");
     std::vector<double> tmp((size_t)bsp * bsp);
     HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -800,8 +850,10 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
     if (!h->factored) { g_last_error = "solve before factor"; return GMRF_ERR_NO_FACTOR; }
     if (k <= 0 || ld < h->n || mode < 0 || mode > 2) return bad_shape("bad k / ld / mode");
     HIPCHK(hipSetDevice(h->device));
+    if (h->B > 1 && k > KP_CHUNK) return bad_shape("with a batch of problems k is limited to 128 per call");
     const bool b_dev = is_device_ptr(b), y_dev = is_device_ptr(y);
     h->stats.solve_ms = 0.0;
+    const int64_t nb = h->B;            // b / y hold nb consecutive groups of k columns (problem-major)
     for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
         const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
         const int kp = pad_k(kc);
@@ -809,10 +861,10 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
         const double* bsrc = b + c0 * ld;
         double* ydst = y + c0 * ld;
         const double* d_b = bsrc;
-        if (!b_dev || !y_dev) GCHK(ensure_stage(h, (int64_t)kc * h->n));
+        if (!b_dev || !y_dev) GCHK(ensure_stage(h, (int64_t)kc * h->n * nb));
         if (!b_dev) {
             HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), bsrc, ld * sizeof(double),
-                                    h->n * sizeof(double), kc, hipMemcpyHostToDevice, h->stream));
+                                    h->n * sizeof(double), kc * nb, hipMemcpyHostToDevice, h->stream));
             d_b = h->d_stage;
         }
         GCHK(launch_pack(h, d_b, b_dev ? ld : h->n, kc, kp));
@@ -826,7 +878,7 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
         } else {
             GCHK(launch_unpack(h, result, h->d_stage, h->n, kc, nullptr));
             HIPCHK(hipMemcpy2DAsync(ydst, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
-                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+                                    h->n * sizeof(double), kc * nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
         float ms = 0.f;
@@ -834,7 +886,7 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
         h->stats.solve_ms += ms;
         const int nsweeps = (mode == GMRF_SOLVE_FULL) ? 2 : 1;
         h->stats.sweep_ms = ms / nsweeps;
-        h->stats.sweep_bytes = sweep_bytes(h, kc);
+        h->stats.sweep_bytes = sweep_bytes(h, kc) * (double)nb;
         if (h->profiling) prof_collect(h);
     }
     return GMRF_OK;
@@ -843,31 +895,31 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
 static gmrf_status stage_vector(gmrf_handle* h, const double* v, double** d_buf, const double** d_out) {
     if (!v) { *d_out = nullptr; return GMRF_OK; }
     if (is_device_ptr(v)) { *d_out = v; return GMRF_OK; }
-    if (!*d_buf) HIPCHK(hipMalloc(d_buf, sizeof(double) * h->n));
-    HIPCHK(hipMemcpyAsync(*d_buf, v, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
+    if (!*d_buf) HIPCHK(hipMalloc(d_buf, sizeof(double) * h->n * h->B));
+    HIPCHK(hipMemcpyAsync(*d_buf, v, sizeof(double) * h->n * h->B, hipMemcpyHostToDevice, h->stream));
     *d_out = *d_buf;
     return GMRF_OK;
 }
 
 // draws (or loads) z for samples [first_id + c0, +kc) into panel P and runs the backward sweep -> panel Y
 static gmrf_status sample_chunk(gmrf_handle* h, uint64_t seed, int64_t first_id, int kc, const double* z,
-                                int64_t ldz) {
+                                int64_t ldz, int64_t id_stride) {
     const int kp = pad_k(kc);
     GCHK(ensure_panels(h, kp));
     if (z) {
         const double* d_z = z;
         int64_t ldd = ldz;
         if (!is_device_ptr(z)) {
-            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            GCHK(ensure_stage(h, (int64_t)kc * h->n * h->B));
             HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), z, ldz * sizeof(double),
-                                    h->n * sizeof(double), kc, hipMemcpyHostToDevice, h->stream));
+                                    h->n * sizeof(double), kc * h->B, hipMemcpyHostToDevice, h->stream));
             d_z = h->d_stage; ldd = h->n;
         }
         GCHK(launch_pack(h, d_z, ldd, kc, kp));
     } else {
         const int64_t total = (int64_t)kp * h->n_pad;
-        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id);
+        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256), (unsigned)h->B), dim3(256), 0,
+                           h->stream, h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id, id_stride);
         HIPCHK(hipGetLastError());
     }
     return run_sweeps(h, GMRF_SOLVE_BACKWARD, kp);
@@ -878,6 +930,7 @@ gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int6
     if (!h || !out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "sample before factor"; return GMRF_ERR_NO_FACTOR; }
     if (k <= 0 || ld < h->n) return bad_shape("bad k / ld");
+    if (h->B > 1 && k > KP_CHUNK) return bad_shape("with a batch of problems k is limited to 128 per call");
     HIPCHK(hipSetDevice(h->device));
     const double* d_mean = nullptr;
     GCHK(stage_vector(h, mean, &h->d_mean, &d_mean));
@@ -885,14 +938,14 @@ gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int6
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
         const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
-        GCHK(sample_chunk(h, seed, first_id + c0, kc, z ? z + c0 * ld : nullptr, ld));
+        GCHK(sample_chunk(h, seed, first_id + c0, kc, z ? z + c0 * ld : nullptr, ld, k));
         if (out_dev) {
             GCHK(launch_unpack(h, h->d_Y, out + c0 * ld, ld, kc, d_mean));
         } else {
-            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            GCHK(ensure_stage(h, (int64_t)kc * h->n * h->B));
             GCHK(launch_unpack(h, h->d_Y, h->d_stage, h->n, kc, d_mean));
             HIPCHK(hipMemcpy2DAsync(out + c0 * ld, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
-                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+                                    h->n * sizeof(double), kc * h->B, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
     }
@@ -909,6 +962,7 @@ gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int
     if (!h || !z) return bad_shape("null pointer");
     if (h->n <= 0) return bad_shape("no shape set");
     if (k <= 0 || ld < h->n) return bad_shape("bad k / ld");
+    if (h->B > 1 && k > KP_CHUNK) return bad_shape("with a batch of problems k is limited to 128 per call");
     HIPCHK(hipSetDevice(h->device));
     const bool z_dev = is_device_ptr(z);
     for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
@@ -916,16 +970,16 @@ gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int
         const int kp = pad_k(kc);
         GCHK(ensure_panels(h, kp));
         const int64_t total = (int64_t)kp * h->n_pad;
-        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream,
-                           h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id + c0);
+        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256), (unsigned)h->B), dim3(256), 0,
+                           h->stream, h->d_P, h->n_pad, (int)h->bs, (int)h->bsp, kc, kp, seed, first_id + c0, k);
         HIPCHK(hipGetLastError());
         if (z_dev) {
             GCHK(launch_unpack(h, h->d_P, z + c0 * ld, ld, kc, nullptr));
         } else {
-            GCHK(ensure_stage(h, (int64_t)kc * h->n));
+            GCHK(ensure_stage(h, (int64_t)kc * h->n * h->B));
             GCHK(launch_unpack(h, h->d_P, h->d_stage, h->n, kc, nullptr));
             HIPCHK(hipMemcpy2DAsync(z + c0 * ld, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
-                                    h->n * sizeof(double), kc, hipMemcpyDeviceToHost, h->stream));
+                                    h->n * sizeof(double), kc * h->B, hipMemcpyDeviceToHost, h->stream));
         }
         HIPCHK(hipStreamSynchronize(h->stream));
     }
@@ -936,8 +990,8 @@ gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out) {
     if (!h || !out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "logdet before factor"; return GMRF_ERR_NO_FACTOR; }
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N), dim3(256), 0, h->stream, h->d_L,
-                       h->bsp * h->bsp, h->bsp, (int)h->bs, h->d_logdet);
+    hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N), dim3(256), 0, h->stream,
+                       h->d_L + h->sel * h->N * h->bsp * h->bsp, h->bsp * h->bsp, h->bsp, (int)h->bs, h->d_logdet);
     HIPCHK(hipGetLastError());
     std::vector<double> part((size_t)h->N);
     HIPCHK(hipMemcpyAsync(part.data(), h->d_logdet, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
@@ -1064,6 +1118,11 @@ gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k, 
 }
 
 // --------------------------------------------------------------------------------- variances
+static gmrf_status need_single(gmrf_handle* h) {
+    if (h->B != 1) return bad_shape("marginal variances are computed per handle with batch 1");
+    return GMRF_OK;
+}
+
 static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     // S_NN = Linv_N^T Linv_N ;  S_ii = Linv_i^T Linv_i + G^T S_{i+1,i+1} G,  G = C_i Linv_i
     const int bsp = (int)h->bsp;
@@ -1074,12 +1133,12 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     double* Sn = h->d_W;
     for (int64_t i = h->N - 1; i >= 0; --i) {
         const double* X = h->d_Linv + i * bstride;
-        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld));
+        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, 0, 0, 0));
         if (i < h->N - 1) {
             const double* C = h->d_C + i * bstride;
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld));
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld));
-            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld));
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld, 0, 0, 0));
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld, 0, 0, 0));
+            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld, 0, 0, 0));
         }
         hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((h->bs + 255) / 256)), dim3(256), 0, h->stream,
                            Sn, ld, (int)h->bs, d_out + i * h->bs);
@@ -1093,7 +1152,7 @@ static gmrf_status var_accumulate_dev(gmrf_handle* h, int method, int64_t first_
                                       const gmrf_csr* Q, double* d_acc) {
     for (int64_t c0 = 0; c0 < k; c0 += 64) {
         const int kc = (int)std::min<int64_t>(64, k - c0);
-        GCHK(sample_chunk(h, seed, first_id + c0, kc, nullptr, 0));
+        GCHK(sample_chunk(h, seed, first_id + c0, kc, nullptr, 0, 0));
         GCHK(ensure_stage(h, 2 * (int64_t)kc * h->n));
         double* Xc = h->d_stage;
         double* QX = h->d_stage + (int64_t)kc * h->n;
@@ -1118,6 +1177,7 @@ gmrf_status gmrf_bt_var_accumulate(gmrf_handle* h, int32_t method, int64_t first
     if (method != GMRF_VAR_RBMC && method != GMRF_VAR_MC) return bad_shape("accumulate needs RBMC or MC");
     if (method == GMRF_VAR_RBMC && (!Q || Q->n_rows != h->n || !Q->d_diag)) return bad_shape("RBMC needs the square matrix Q");
     if (k <= 0) return bad_shape("k <= 0");
+    GCHK(need_single(h));
     HIPCHK(hipSetDevice(h->device));
     const bool dev = is_device_ptr(acc);
     double* d_acc = acc;
@@ -1136,6 +1196,7 @@ gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint
                                  double* var_out) {
     if (!h || !var_out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "variance before factor"; return GMRF_ERR_NO_FACTOR; }
+    GCHK(need_single(h));
     HIPCHK(hipSetDevice(h->device));
     if (!h->d_acc) HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n));
     const bool dev = is_device_ptr(var_out);
@@ -1184,6 +1245,7 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     GemmArgs g;
     g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = g.strideB = g.strideC = 0;
+    g.pA = g.pB = g.pC = 0; g.nb1 = 1;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta;
     unsigned long long* dst = nullptr;
@@ -1253,7 +1315,7 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
     if (bs % 64 || next_pow2(bs / 64) != bs / 64) return bad_shape("bs must be 64 * 2^p");
     gmrf_handle* h = nullptr;
     GCHK(gmrf_bt_create(device, nullptr, &h));
-    h->N = 1; h->n = bs; h->bs = bs; h->bsp = bs; h->n_pad = bs;
+    h->N = 1; h->n = bs; h->bs = bs; h->bsp = bs; h->n_pad = bs; h->B = 1;
     gmrf_status s = alloc_factor(h);
     if (s == GMRF_OK) {
         hipError_t e = hipMemcpyAsync(h->d_S, S, sizeof(double) * bs * bs, hipMemcpyHostToDevice, h->stream);

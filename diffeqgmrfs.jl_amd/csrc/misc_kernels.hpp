@@ -10,23 +10,26 @@ namespace gmrf {
 // Scatter the stored entries of one sparse block into a zeroed dense row-major block.
 // Replaces `Array(A[rows, cols])` of /root/reference/src/tridiagonal_cholesky.jl:67,73,76.
 // Entries are (row << 32 | col) keys local to the block.
+// blockIdx.y = problem: values at vals + y * pvals, destination block at dst + y * pdst.
 __global__ void scatter_block(const uint64_t* __restrict__ keys, const double* __restrict__ vals,
-                              int64_t first, int64_t count, double* __restrict__ dst, int64_t ld) {
+                              int64_t first, int64_t count, double* __restrict__ dst, int64_t ld,
+                              int64_t pvals, int64_t pdst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint64_t key = keys[first + i];
     const int64_t r = (int64_t)(key >> 32), c = (int64_t)(key & 0xffffffffu);
-    dst[r * ld + c] = vals[first + i];
+    dst[(int64_t)blockIdx.y * pdst + r * ld + c] = vals[(int64_t)blockIdx.y * pvals + first + i];
 }
 
 // Identity on the padding rows [bs, bsp) of a padded diagonal block.
-__global__ void pad_identity(double* __restrict__ dst, int64_t ld, int bs, int bsp) {
+__global__ void pad_identity(double* __restrict__ dst, int64_t ld, int bs, int bsp, int64_t pdst) {
     const int i = bs + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < bsp) dst[(int64_t)i * ld + i] = 1.0;
+    if (i < bsp) dst[(int64_t)blockIdx.y * pdst + (int64_t)i * ld + i] = 1.0;
 }
 
 // ------------------------------------------------------------------------------- panels
 // user matrix (column-major n x k, leading dimension ld) <-> padded panel P[rhs][n_pad]
+// blockIdx.y = problem p: columns [p*k, (p+1)*k) of the user matrix <-> panel p (kp * n_pad doubles)
 __global__ void pack_panel(const double* __restrict__ src, int64_t ld, double* __restrict__ P,
                            int64_t n_pad, int bs, int bsp, int nblk, int k, int kp) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -35,20 +38,20 @@ __global__ void pack_panel(const double* __restrict__ src, int64_t ld, double* _
     const int64_t r = idx / n_pad, j = idx % n_pad;
     const int64_t blk = j / bsp, off = j % bsp;
     double v = 0.0;
-    if (r < k && off < bs) v = src[r * ld + blk * bs + off];
-    P[idx] = v;
+    if (r < k && off < bs) v = src[((int64_t)blockIdx.y * k + r) * ld + blk * bs + off];
+    P[(int64_t)blockIdx.y * total + idx] = v;
 }
 
 __global__ void unpack_panel(const double* __restrict__ P, int64_t n_pad, double* __restrict__ dst,
-                             int64_t ld, int bs, int bsp, int64_t n, int k,
+                             int64_t ld, int bs, int bsp, int64_t n, int k, int kp,
                              const double* __restrict__ mean) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * (int64_t)k) return;
     const int64_t r = idx / n, j = idx % n;
     const int64_t blk = j / bs, off = j % bs;
-    double v = P[r * n_pad + blk * bsp + off];
-    if (mean) v += mean[j];
-    dst[r * ld + j] = v;
+    double v = P[(int64_t)blockIdx.y * kp * n_pad + r * n_pad + blk * bsp + off];
+    if (mean) v += mean[(int64_t)blockIdx.y * n + j];
+    dst[((int64_t)blockIdx.y * k + r) * ld + j] = v;
 }
 
 // ------------------------------------------------------------------------------- RNG
@@ -77,15 +80,17 @@ __device__ __host__ inline double philox_normal(uint64_t seed, uint64_t dof, uin
 }
 
 // Fill the padded panel rows [0,k) with normals of samples first_id.. (padding stays zero).
+// problem p (blockIdx.y) draws the sample ids first_id + p * id_stride + r
 __global__ void fill_normals_panel(double* __restrict__ P, int64_t n_pad, int bs, int bsp,
-                                   int k, int kp, uint64_t seed, int64_t first_id) {
+                                   int k, int kp, uint64_t seed, int64_t first_id, int64_t id_stride) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (int64_t)kp * n_pad) return;
     const int64_t r = idx / n_pad, j = idx % n_pad;
     const int64_t blk = j / bsp, off = j % bsp;
     double v = 0.0;
-    if (r < k && off < bs) v = philox_normal(seed, (uint64_t)(blk * bs + off), (uint64_t)(first_id + r));
-    P[idx] = v;
+    if (r < k && off < bs)
+        v = philox_normal(seed, (uint64_t)(blk * bs + off), (uint64_t)(first_id + (int64_t)blockIdx.y * id_stride + r));
+    P[(int64_t)blockIdx.y * kp * n_pad + idx] = v;
 }
 
 // ------------------------------------------------------------------------------- K6

@@ -322,10 +322,16 @@ struct StepArgs {
     int nt;               // tiles per dimension
     int* info;
     int blk;              // block id reported on a non-positive pivot (1-based)
+    int64_t pS, pLX;      // per-problem strides of S and of L / X (blockIdx.y)
+    int blk_per_problem;  // reported id = blk + blockIdx.y * blk_per_problem
 };
 
 // grid.x = 1 + m (m + 1) / 2,  m = nt - j - 1.
 __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
+    sa.S += (int64_t)blockIdx.y * sa.pS;
+    sa.L += (int64_t)blockIdx.y * sa.pLX;
+    sa.X += (int64_t)blockIdx.y * sa.pLX;
+    sa.blk += (int)blockIdx.y * sa.blk_per_problem;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;

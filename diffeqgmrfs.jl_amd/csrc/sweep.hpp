@@ -26,12 +26,21 @@ struct SweepArgs {
     double* Out; int64_t ldo;
     int bs;
     int sub;
+    int64_t pMat, pXin, pBin, pOut;     // per-problem strides (blockIdx.z)
 };
+
+__device__ __forceinline__ void sweep_select_problem(SweepArgs& s, int p) {
+    s.Mat += (int64_t)p * s.pMat;
+    s.Xin += (int64_t)p * s.pXin;
+    if (s.Bin) s.Bin += (int64_t)p * s.pBin;
+    s.Out += (int64_t)p * s.pOut;
+}
 
 // TRANS = false: out[m] = sum_k Mat[m][k] x[k]   (TRI: Mat lower triangular, k <= m)
 // TRANS = true : out[m] = sum_k Mat[k][m] x[k]   (TRI: Mat lower triangular, k >= m)
 template <bool TRANS, bool TRI>
 __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
     const int m0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -83,6 +92,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
 // One right-hand side, non-transposed: one wave per row, 16-byte loads along the row.
 template <bool TRI>
 __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= s.bs) return;
@@ -113,6 +123,7 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
 // LDS reduction over the 16 row groups.
 template <bool TRI>
 __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
     const int t = threadIdx.x;
     const int c = t & 15, gidx = t >> 4;
     const int col0 = blockIdx.x * 16;
@@ -135,19 +146,19 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
     }
 }
 
-inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s) {
+inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s, int nprob) {
     if (kp == 1) {
         if (!trans) {
-            dim3 grid((s.bs + 3) / 4), block(256);
+            dim3 grid((s.bs + 3) / 4, 1, nprob), block(256);
             if (tri) hipLaunchKernelGGL((sweep_gemv_n<true>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_n<false>), grid, block, 0, st, s);
         } else {
-            dim3 grid(s.bs / 16), block(256);
+            dim3 grid(s.bs / 16, 1, nprob), block(256);
             if (tri) hipLaunchKernelGGL((sweep_gemv_t<true>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_t<false>), grid, block, 0, st, s);
         }
     } else {
-        dim3 grid(s.bs / 16, kp / 16), block(256);
+        dim3 grid(s.bs / 16, kp / 16, nprob), block(256);
         if (!trans && !tri) hipLaunchKernelGGL((sweep_mm<false, false>), grid, block, 0, st, s);
         else if (!trans && tri) hipLaunchKernelGGL((sweep_mm<false, true>), grid, block, 0, st, s);
         else if (trans && !tri) hipLaunchKernelGGL((sweep_mm<true, false>), grid, block, 0, st, s);

@@ -36,17 +36,25 @@ class HipEngine:
     """libgmrf_hip.so behind the driver protocol; factor storage lives in torch tensors so that
     torch.distributed can broadcast it in place."""
 
-    def __init__(self, pkg, workload, device_index: int = 0):
+    def __init__(self, pkg, workload, device_index: int = 0, batch: int = 1, values=None, rhs=None):
+        """`values` (batch, nnz) / `rhs` (batch, n): one row per independent problem on the
+        workload's sparsity pattern (default: the workload itself, repeated)."""
         import torch
         self.torch = torch
         self.pkg = pkg
         self.w = workload
+        self.batch = batch
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
         self.stream = torch.cuda.current_stream(self.dev)
-        self.F = pkg.TridiagonalCholeskyFactor(device=device_index, stream=self.stream.cuda_stream)
-        self.nz = torch.from_numpy(np.ascontiguousarray(workload.Q.data)).to(self.dev)
-        self.rhs = torch.from_numpy(np.ascontiguousarray(workload.rhs)).to(self.dev)
+        self.F = pkg.TridiagonalCholeskyFactor(device=device_index, stream=self.stream.cuda_stream, batch=batch)
+        if values is None:
+            values = np.tile(np.ascontiguousarray(workload.Q.data), (batch, 1))
+        if rhs is None:
+            rhs = np.tile(np.ascontiguousarray(workload.rhs), (batch, 1))
+        self.values_host = np.ascontiguousarray(values, dtype=np.float64).reshape(batch, -1)
+        self.nz = torch.from_numpy(self.values_host).to(self.dev)
+        self.rhs = torch.from_numpy(np.ascontiguousarray(rhs, dtype=np.float64).reshape(batch, 1, -1)).to(self.dev)
         self.buffers = None
         self._analysed = False
 
@@ -68,7 +76,7 @@ class HipEngine:
         if shared_storage:
             self._attach_storage()
         if is_root or not shared_storage:
-            self.F.factor(self.w.Q, self.w.n_blocks)      # analyse + first numeric factor
+            self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)   # analyse + first numeric factor
             self._analysed = True
         elif not shared_storage:
             self.F.adopt_shape(self.w.n, self.w.n_blocks)
@@ -98,10 +106,12 @@ class HipEngine:
         return out
 
     def mean(self):
-        return self.pkg.ldiv(self.F, self.rhs)
+        """(batch, n) posterior means."""
+        return self.F.solve_batch(self.rhs)[:, 0, :]
 
     def sample(self, k: int, mean, seed: int, first_id: int):
-        return self.F.sample(k, mean=mean, seed=seed, first_id=first_id, like=self.rhs)
+        """(batch, k, n) samples; problem p draws the ids first_id + p*k + s."""
+        return self.F.sample_batch(k, mean=mean, seed=seed, first_id=first_id, like=self.rhs)
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.dev)
@@ -143,9 +153,16 @@ class ShardedPosterior:
         """factor (+ broadcast) -> mean -> this rank's k samples.  Returns (mean, samples)."""
         self._factor_and_share()
         mu = self.e.mean()
-        first = (step_index * self.world + self.rank) * self.k
+        nb = getattr(self.e, "batch", 1)
+        first = (step_index * self.world + self.rank) * self.k * nb
         X = self.e.sample(self.k, mu, self.seed, first)
         return mu, X
 
     def solves_per_step(self) -> int:
+        """Posterior solves of one step over all ranks.  Shared factor (broadcast): one mean and
+        k samples per rank.  Replicated / independent problems: every rank handles its own batch
+        of problems, each with its own mean and k samples."""
+        nb = getattr(self.e, "batch", 1)
+        if self.replicate:
+            return self.world * nb * (1 + self.k)
         return 1 + self.k * self.world

@@ -182,6 +182,15 @@ gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks
 gmrf_status gmrf_bt_factor_step_async(gmrf_handle* h, int64_t i0, int64_t i1);
 gmrf_status gmrf_bt_factor_end(gmrf_handle* h, int32_t* info);
 
+/* Batch of B independent problems that share ONE sparsity pattern (the reference's loop over
+ * data-set problems, scripts/darcy/solve_darcy_gmrf-fem.jl:176-198): they are factored and
+ * solved in lock step, problem = one more grid dimension of every kernel.  With B > 1:
+ * nzval holds B value arrays one after the other; b / y / z / out hold B consecutive groups of
+ * k columns (problem-major); mean holds B vectors; sample ids are first_id + p*k + s.
+ * Accessors (get_block, logdet) address the problem chosen by gmrf_bt_select_problem. */
+gmrf_status gmrf_bt_set_batch(gmrf_handle* h, int64_t batch);
+gmrf_status gmrf_bt_select_problem(gmrf_handle* h, int64_t p);
+
 gmrf_status gmrf_bt_stats(gmrf_handle* h, gmrf_stats* out);
 gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
 /* 0: replay captured HIP graphs (default); 1: plain stream launches. */

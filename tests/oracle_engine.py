@@ -52,6 +52,8 @@ class OracleEngine:
             out.append(self.C[c0:c1])
         return out
 
+    batch = 1
+
     def mean(self):
         return O.ldiv(self.F, self.w.rhs)
 

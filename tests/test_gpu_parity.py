@@ -261,3 +261,38 @@ def test_full_size_properties_darcy256(pkg):
     ld = F.logdet()
     F.refactor(4.0 * w.Q.data)
     assert abs(F.logdet() - (ld + w.n * np.log(4.0))) < 1e-9 * abs(ld)
+
+
+def test_batch_of_problems_matches_one_by_one(pkg):
+    """B independent problems on one pattern, factored / solved / sampled in lock step, equal
+    the same problems handled one at a time (bitwise: same kernels, same order of operations)."""
+    w = pkg.workloads.make("darcy32")
+    B, k = 3, 16
+    rng = np.random.default_rng(4)
+    vals = np.stack([w.Q.data * (1.0 + 0.3 * p) for p in range(B)])
+    rhs = np.stack([w.rhs * (p + 1.0) for p in range(B)])
+    Fb = pkg.TridiagonalCholeskyFactor(batch=B).factor(w.Q, w.n_blocks, values=vals)
+    mu_b = Fb.solve_batch(rhs[:, None, :])[:, 0, :]
+    X_b = Fb.sample_batch(k, mean=mu_b, seed=11, first_id=100)
+    Bm = rng.standard_normal((B, k, w.n))
+    Y_b = Fb.solve_batch(Bm, pkg._cabi.SOLVE_BACKWARD)
+    for p in range(B):
+        Qp = w.Q.copy(); Qp.data = vals[p]
+        F1 = pkg.tridiagonal_cholesky(Qp, w.n_blocks)
+        mu1 = pkg.ldiv(F1, rhs[p])
+        assert np.array_equal(mu_b[p], mu1)
+        X1 = F1.sample(k, mean=mu1, seed=11, first_id=100 + p * k)
+        assert np.array_equal(X_b[p].T, X1)
+        assert np.array_equal(Y_b[p].T, pkg.backward_solve(F1, Bm[p].T))
+        Fb.select_problem(p)
+        assert np.array_equal(Fb.chos[2], F1.chos[2]) and abs(Fb.logdet() - F1.logdet()) == 0.0
+        Fo = O.tridiagonal_cholesky(Qp, w.n_blocks)
+        assert rel(mu_b[p], O.ldiv(Fo, rhs[p])) < solve_tol(w)
+    # a non-SPD member of the batch is reported with its block index
+    bad = vals.copy()
+    Qb = w.Q.tocsc()
+    d = np.flatnonzero((Qb.indices == 700) & (np.repeat(np.arange(w.n), np.diff(Qb.indptr)) == 700))[0]
+    bad[1, d] = -1e20
+    with pytest.raises(pkg.NotPositiveDefinite) as e:
+        Fb.refactor(bad)
+    assert e.value.info == 700 // w.block_size + 1
