@@ -106,6 +106,8 @@ struct gmrf_handle {
     double* d_nz_stage = nullptr;      // staging for host nzval
     std::vector<int64_t> diag_first, diag_count, low_first, low_count;
     bool analyzed = false;
+    int64_t cmin = 0, rmax = 0;        // lower blocks B_i are zero left of column cmin and below row rmax (64-aligned)
+    bool c_dirty = false;              // C must be re-zeroed (new pattern)
     // factor storage
     double *d_L = nullptr, *d_C = nullptr, *d_Linv = nullptr;
     bool external_storage = false;
@@ -293,6 +295,17 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
         h->low_first[i] = (int64_t)keys.size(); h->low_count[i] = (int64_t)lo[i].size();
         for (auto& e : lo[i]) { keys.push_back(e.key); src.push_back(e.src); }
     }
+    // zero structure shared by all lower blocks: first non-zero column, last non-zero row
+    int64_t cmin = h->bsp, rmax = 0;
+    for (int64_t i = 1; i < N; ++i)
+        for (auto& e : lo[i]) {
+            const int64_t r = (int64_t)(e.key >> 32), c = (int64_t)(e.key & 0xffffffffu);
+            cmin = std::min(cmin, c); rmax = std::max(rmax, r + 1);
+        }
+    if (rmax == 0) { cmin = 0; rmax = 64; }
+    h->cmin = (cmin / 64) * 64;
+    h->rmax = std::min<int64_t>(h->bsp, (rmax + 63) / 64 * 64);
+    h->c_dirty = true;
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     h->d_keys = nullptr; h->d_vals = nullptr; h->d_src = nullptr; h->d_nz_stage = nullptr;
@@ -384,7 +397,15 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const int m = nt - j - 1;
         const double rem = 64.0 * m;
         ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0) * (double)h->B);
-        hipLaunchKernelGGL(potrf_step, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+        if (h->B == 1 || m == 0) {
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
+                               h->stream, sa);
+        } else {
+            // batch: factor the B diagonal tiles once, then update without the redundant tile work
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+            hipLaunchKernelGGL(potrf_step<true>, dim3(m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
+                               h->stream, sa);
+        }
         HIPCHK(hipGetLastError());
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
@@ -434,10 +455,14 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                                    h->n_entries, bstride);
                 HIPCHK(hipGetLastError());
             }
-            // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74)
-            GCHK(gemm(h, false, false, bsp, bsp, bsp, TRI_B_UPPER, 0, 1.0, h->d_B, ld, Xp, ld, 0.0, C, ld, bstride, pLX, pC));
+            // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74).  B is zero left of column
+            // cmin and below row rmax, hence C is zero there too and only the rest is computed.
+            const int cm = (int)h->cmin, rm = (int)h->rmax;
+            GCHK(gemm(h, false, false, rm, bsp - cm, bsp - cm, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
+                      Xp + (int64_t)cm * ld + cm, ld, 0.0, C + cm, ld, bstride, pLX, pC));
             // S = D - C C^T             (src/tridiagonal_cholesky.jl:77)
-            GCHK(gemm(h, false, false, bsp, bsp, bsp, 0, 1, -1.0, C, ld, C, ld, 1.0, h->d_S, ld, pC, pC, bstride));
+            GCHK(gemm(h, false, false, rm, rm, bsp - cm, 0, 1, -1.0, C + cm, ld, C + cm, ld, 1.0, h->d_S, ld, pC, pC,
+                      bstride));
         }
         GCHK(potrf_block(h, h->d_S, L, X, h->d_T, (int)(i + 1)));
     }
@@ -481,6 +506,10 @@ static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
 static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* info) {
     if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
     GCHK(alloc_factor(h));
+    if (h->c_dirty) {
+        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * h->bsp * h->bsp * std::max<int64_t>(h->N - 1, 1) * h->B, h->stream));
+        h->c_dirty = false;
+    }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     GCHK(load_values(h, nzval));
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
@@ -619,7 +648,8 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipMemset(h->d_info, 0, sizeof(int)));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(gemm_init());
     *out = h;
     return GMRF_OK;
@@ -709,6 +739,10 @@ gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks
     if (colptr) GCHK(analyze_csc(h, n, n_blocks, colptr, rowval, index_base));
     if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
     GCHK(alloc_factor(h));
+    if (h->c_dirty) {
+        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * h->bsp * h->bsp * std::max<int64_t>(h->N - 1, 1) * h->B, h->stream));
+        h->c_dirty = false;
+    }
     GCHK(load_values(h, nzval));
     HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
     h->factored = false;
