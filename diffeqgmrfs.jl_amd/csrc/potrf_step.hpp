@@ -20,9 +20,14 @@
 
 #include "gemm_f64.hpp"
 
+#ifndef GMRF_TILE_EXACT_DIV
+#define GMRF_TILE_EXACT_DIV 0
+#endif
+
 namespace gmrf {
 
-constexpr int TLD = 66;                 // LDS row stride (doubles) of a 64x64 tile
+constexpr int TLD = 68;                 // LDS row stride (doubles) of a 64x64 tile: 16-byte aligned rows,
+                                        // ds_read_b128 of MFMA operand pairs conflict free (stride = 4 mod 8)
 constexpr int TILE_ELEMS = 64 * TLD;
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
@@ -106,9 +111,8 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = Ts[r * TLD + c0 + c];
-    double* pivs = lcol + 16 * 64;          // 16 pivots
     double up[16];                          // multiplicands of the previous step (LDS broadcast)
-    double wprev = 0.0;
+    double lprev = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) up[c] = 0.0;
 #pragma unroll
@@ -116,32 +120,33 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
         const int j = c0 + jj;
         const double p = bcast_lane(a[jj], j);
         if (!(p > 0.0)) bad = true;
-        const double pinv = rcp_nr(p);
-        const double u = a[jj];
-        const double w = u * pinv;
-        lcol[jj * 64 + r] = u;
-        pivs[jj] = p;
+#if GMRF_TILE_EXACT_DIV
+        const double sq = sqrt(p);
+        const double l = a[jj] / sq;
+        if (r == j) rinvs[j] = 1.0 / sq;
+#else
+        const double rinv = rsqrt_nr(p);
+        const double l = a[jj] * rinv;       // lane j: p * rinv = sqrt(p)
+        if (r == j) rinvs[j] = rinv;
+#endif
+        a[jj] = l;
+        lcol[jj * 64 + r] = l;
         if (jj < 15) {
-            const double uc1 = bcast_lane(u, j + 1);
-            a[jj + 1] = fma(-w, uc1, a[jj + 1]);
+            const double lc1 = bcast_lane(l, j + 1);
+            a[jj + 1] = fma(-l, lc1, a[jj + 1]);
         }
         // rank-1 updates of the PREVIOUS step on columns jj+1..15: their multiplicands were
         // requested from LDS one step ago, so the read latency hides behind the work above
 #pragma unroll
-        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-wprev, up[cc], a[cc]);
+        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-lprev, up[cc], a[cc]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cc = jj + 2; cc < 16; ++cc) up[cc] = lcol[jj * 64 + c0 + cc];
-        wprev = w;
+        lprev = l;
         __builtin_amdgcn_sched_barrier(0);
     }
-    // scale: L[r][j] = u[r][j] / sqrt(p_j); lane c0+c owns pivot c (its u[r][c] is p_c -> sqrt(p_c))
-    const double pown = pivs[(r - c0) & 15];
-    const double rown = rsqrt_nr(pown);
-    if (r >= c0 && r < c0 + 16) rinvs[r] = rown;
-    __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0): the rinvs written above are read below
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Ts[r * TLD + c0 + c] = a[c] * rinvs[c0 + c];
+    for (int c = 0; c < 16; ++c) Ts[r * TLD + c0 + c] = a[c];
 }
 
 // One wave: X_kk = L_kk^-1 for the 16x16 diagonal block at c0 (lane c < 16 owns column c).
@@ -166,9 +171,10 @@ __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, dou
 // Trailing sub-tile (I, J) of the tile: T[I][J] -= P_I P_J^T with the panel at columns c0..c0+15.
 __device__ __forceinline__ void subtile_update(double* Ts, int I, int J, int c0, int li, int lq) {
     double* ct = Ts + (16 * I) * TLD + 16 * J;
-    v4d acc = load_d16(ct, TLD, li, lq);
-    acc = mm16_nt(Ts + (16 * I) * TLD + c0, TLD, Ts + (16 * J) * TLD + c0, TLD, acc, true, li, lq);
-    store_d16(ct, TLD, acc, li, lq);
+    const v4d cur = load_d16(ct, TLD, li, lq);
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    acc = mm16_nt(Ts + (16 * I) * TLD + c0, TLD, Ts + (16 * J) * TLD + c0, TLD, acc, false, li, lq);
+    store_d16(ct, TLD, cur - acc, li, lq);
 }
 
 // Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
@@ -246,53 +252,32 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
             if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
         }
     }
-    // --- inverse assembly.  wave 3: last diagonal inverse; wave 0: T = L10 X00 of pair 0
-    double* W0 = Wk;
-    double* W1 = Wk + 16 * 18;
-    double* W2 = Wk + 2 * 16 * 18;
-    double* W3 = Wk + 3 * 16 * 18;
+    // --- inverse of the tile by block forward substitution over the four 16-row blocks:
+    //        X[I][J] = -X[I][I] * sum_{K=J..I-1} L[I][K] X[K][J],      I = 1, 2, 3,  J < I.
+    // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
+    // eps * cond(16x16 block); the cheaper recursive doubling X21 = -X22 (L21 X11) multiplies two
+    // computed inverses and was measured 20-100x less accurate for cond(tile) >= 1e5.
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
     if (wave == 3) inv16(Ts, rinvs, Xs, 48, lane);
-    if (wave == 0) {
-        v4d t = mm16_nn(Ts + 16 * TLD, TLD, Xs, TLD, zero, false, li, lq);             // L10 X00
-        store_d16(W0, 18, t, li, lq);
-    }
-    __syncthreads();
-    if (wave == 0) {
-        v4d x = mm16_nn(Xs + 16 * TLD + 16, TLD, W0, 18, zero, true, li, lq);          // X10 = -X11 T
-        store_d16(Xs + 16 * TLD, TLD, x, li, lq);
-    }
-    if (wave == 1) {
-        v4d t = mm16_nn(Ts + 48 * TLD + 32, TLD, Xs + 32 * TLD + 32, TLD, zero, false, li, lq);   // L32 X22
-        store_d16(W1, 18, t, li, lq);
-    }
-    __syncthreads();
-    if (wave == 1) {
-        v4d x = mm16_nn(Xs + 48 * TLD + 48, TLD, W1, 18, zero, true, li, lq);          // X32 = -X33 T
-        store_d16(Xs + 48 * TLD + 32, TLD, x, li, lq);
-    }
-    __syncthreads();
-    // level 2: blocks I in {2,3}, J in {0,1}:  T[I][J] = sum_{K in {J..1}} L[I][K] X[K][J]
-    {
-        const int I = 2 + (wave >> 1), J = wave & 1;
+#pragma unroll
+    for (int I = 1; I < 4; ++I) {
+        // wave J < I owns block (I, J)
+        const int J = wave;
         double* Wm = Wk + wave * 16 * 18;
-        v4d t = zero;
-        for (int K = J; K < 2; ++K)
-            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
-        store_d16(Wm, 18, t, li, lq);
+        if (J < I) {
+            v4d t = zero;
+            for (int K = J; K < I; ++K)
+                t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+            store_d16(Wm, 18, t, li, lq);
+        }
+        __syncthreads();            // also orders wave 3's inv16(48) before its use at I = 3
+        if (J < I) {
+            v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Wm, 18, zero, true, li, lq);
+            store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    {
-        // X[I][J] = - sum_{K in {2..I}} X[I][K] T[K][J];  T[K][J] lives in W[(K-2)*2 + J]
-        const int I = 2 + (wave >> 1), J = wave & 1;
-        v4d x = zero;
-        for (int K = 2; K <= I; ++K)
-            x = mm16_nn(Xs + (16 * I) * TLD + 16 * K, TLD, Wk + ((K - 2) * 2 + J) * 16 * 18, 18, x, true, li, lq);
-        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
-    }
-    __syncthreads();
     TILE_STAMP(14);
-    (void)W2; (void)W3;
 }
 
 // 64x64 tile: global (row stride ld) -> LDS (row stride TLD), 256 threads.
@@ -388,20 +373,30 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
         tile_s2g(Xs, sa.X + oj * ld + oj, ld, tid);
         return;
     }
-    // ---- panel rows: Lr = As Xs^T (X lower triangular: column block Jb needs k-blocks 0..Jb)
+    // ---- panel rows: Lr = As Xs^T, Lc = Bs Xs^T.  k runs outermost in groups of 8: a lane fetches
+    // two consecutive k of its operand row with ONE ds_read_b128 (every LDS instruction issued
+    // beside fp64 MFMAs costs ~26 cycles of MFMA issue, tools/mb3.hip) and feeds them to two MFMAs
+    // (k-slot permutation as in gemm_f64.hpp).  X is lower triangular: column block Jb needs the
+    // k groups 0 .. 2 Jb + 1 only.
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
     v4d lr[4], lc[4];
 #pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb) {
-        lr[Jb] = zero;
-        lc[Jb] = zero;
+    for (int Jb = 0; Jb < 4; ++Jb) { lr[Jb] = zero; lc[Jb] = zero; }
 #pragma unroll
-        for (int Kb = 0; Kb <= Jb; ++Kb) {
-            lr[Jb] = mm16_nt(As + (16 * wave) * TLD + 16 * Kb, TLD, Xs + (16 * Jb) * TLD + 16 * Kb, TLD, lr[Jb],
-                             false, li, lq);
-            if (c != r)
-                lc[Jb] = mm16_nt(Bs + (16 * wave) * TLD + 16 * Kb, TLD, Xs + (16 * Jb) * TLD + 16 * Kb, TLD,
-                                 lc[Jb], false, li, lq);
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+        v2d bv = av;
+        if (c != r) bv = *reinterpret_cast<const v2d*>(Bs + (16 * wave + li) * TLD + k);
+#pragma unroll
+        for (int Jb = kg / 2; Jb < 4; ++Jb) {
+            const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+            if (c != r) {
+                lc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.x, xv.x, lc[Jb], 0, 0, 0);
+                lc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.y, xv.y, lc[Jb], 0, 0, 0);
+            }
         }
     }
     __syncthreads();                                   // every wave is done reading As / Bs
@@ -414,16 +409,33 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     if (c == sa.j + 1) tile_s2g(As, sa.L + (int64_t)r * 64 * ld + oj, ld, tid);
     // ---- S[r,c] -= Lr Lc^T ; wave owns rows 16*wave.., on a diagonal tile only Jb <= wave matters
     const double* Lcs = (c != r) ? Bs : As;
+    const int jb_end = (c == r) ? wave + 1 : 4;
+    // The product is accumulated from zero and subtracted ONCE (one rounding at the magnitude of
+    // S) -- an fma chain that starts from S rounds 64 times at that magnitude, which is what
+    // LAPACK's dsyrk does not do and what cost two digits on ill-conditioned Schur complements.
+    v4d pacc[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) pacc[Jb] = zero;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb < jb_end) {
+                const v2d bv = *reinterpret_cast<const v2d*>(Lcs + (16 * Jb + li) * TLD + k);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
+            }
+        }
+    }
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
-        if (c == r && Jb > wave) continue;
-        v4d acc = cpre[Jb];
+        if (Jb < jb_end) {
 #pragma unroll
-        for (int Kb = 0; Kb < 4; ++Kb)
-            acc = mm16_nt(As + (16 * wave) * TLD + 16 * Kb, TLD, Lcs + (16 * Jb) * TLD + 16 * Kb, TLD, acc, true,
-                          li, lq);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = acc[q];
+            for (int q = 0; q < 4; ++q)
+                Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
+        }
     }
 }
 

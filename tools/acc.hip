@@ -26,12 +26,15 @@ int main() {
     hipLaunchKernelGGL(k, dim3(n / 256), dim3(256), 0, 0, dp, dout, n);
     hipMemcpy(o.data(), dout, 6 * n * 8, hipMemcpyDeviceToHost);
     double m[6] = {0, 0, 0, 0, 0, 0};
+    long double sg[6] = {0, 0, 0, 0, 0, 0}, sq2 = 0, sq2b = 0;
     for (int i = 0; i < n; ++i) {
         long double ry = 1.0L / (long double)p[i], rr = 1.0L / sqrtl((long double)p[i]);
-        for (int j = 0; j < 3; ++j) { double e = fabs((double)(((long double)o[i * 6 + j] - ry) / ry)); if (e > m[j]) m[j] = e; }
-        for (int j = 3; j < 6; ++j) { double e = fabs((double)(((long double)o[i * 6 + j] - rr) / rr)); if (e > m[j]) m[j] = e; }
+        for (int j = 0; j < 3; ++j) { long double es = ((long double)o[i * 6 + j] - ry) / ry; sg[j] += es; double e = fabs((double)es); if (e > m[j]) m[j] = e; }
+        for (int j = 3; j < 6; ++j) { long double es = ((long double)o[i * 6 + j] - rr) / rr; sg[j] += es; double e = fabs((double)es); if (e > m[j]) m[j] = e; }
+        { long double s0 = (long double)(p[i] * o[i * 6 + 5]); long double st = sqrtl((long double)p[i]); sq2 += (s0 - st) / st; long double sl = (long double)sqrt(p[i]); sq2b += (sl - st) / st; }
     }
     printf("rcp: seed %.3e  1NR %.3e  2NR %.3e   (eps = %.3e)\n", m[0], m[1], m[2], 2.22e-16);
     printf("rsq: seed %.3e  1NR %.3e  2NR %.3e\n", m[3], m[4], m[5]);
+    printf("mean signed rel err: rcp 2NR %.3Le | rsq 2NR %.3Le | p*rsq(p) as sqrt %.3Le | host sqrt %.3Le\n", sg[2] / n, sg[5] / n, sq2 / n, sq2b / n);
     return 0;
 }
