@@ -1342,6 +1342,7 @@ gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
     if (!out || n < 18) return bad_shape("need 18 outputs");
     out[0] = g_tile_us;
     for (int i = 0; i < 17; ++i) out[1 + i] = (double)(g_tile_stamps[i] - g_tile_stamps[15]);
+    if (n >= 24) for (int i = 0; i < 3; ++i) out[18 + i] = (double)(g_tile_stamps[20 + i] - g_tile_stamps[15]);
     return GMRF_OK;
 }
 

@@ -36,14 +36,15 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
     return __hiloint2double(hi, lo);
 }
 
-// 1/sqrt(p) to fp64 accuracy: hardware seed + two Newton steps.
+// 1/sqrt(p) to fp64 accuracy.  The hardware seed has 24 good bits (tools/acc.hip); ONE third-order
+// (Halley) step  y (1 + e/2 + 3 e^2/8),  e = 1 - p y^2,  leaves a truncation error of 5 e^3 / 16
+// ~ 1e-23 and is two dependent fp64 operations shorter than two Newton steps -- this routine sits
+// on the per-column dependent chain of the tile factorisation.
 __device__ __forceinline__ double rsqrt_nr(double p) {
-    double y = __builtin_amdgcn_rsq(p);
-    double e = fma(-p * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    e = fma(-p * y, y, 1.0);
-    y = fma(0.5 * y, e, y);
-    return y;
+    const double y = __builtin_amdgcn_rsq(p);
+    const double e = fma(-p * y, y, 1.0);
+    const double c = fma(0.375, e, 0.5);
+    return fma(y * e, c, y);
 }
 
 // acc += sign * A(16x16) * B(16x16)^T  with A at a[i*lda + k], B at b[j*ldb + k]   ("NT")
@@ -105,48 +106,68 @@ __device__ __forceinline__ double rcp_nr(double p) {
 //   * the pivot and the one multiplicand the next column needs travel lane -> SGPR by
 //     v_readlane; the other multiplicands of a step are re-read from an LDS copy of the column
 //     as wave-uniform operands (one ds_read_b128 per two rank-1 updates).
-__device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double* lcol, int c0, int lane,
-                                               bool& bad) {
+__device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double* lcol_in, int c0, int lane,
+                                               bool& bad, unsigned long long* dbg = nullptr) {
     const int r = lane;
+    // Make the LDS base opaque to the compiler: with a known constant address it materialises
+    // every broadcast read address with an s_add + v_mov pair; with a VGPR base the constant part
+    // goes into the instruction's offset field.
+    double* lcol = lcol_in;
+    asm volatile("" : "+v"(lcol));
     double a[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) a[c] = Ts[r * TLD + c0 + c];
+    if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memtime();
     double up[16];                          // multiplicands of the previous step (LDS broadcast)
     double lprev = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) up[c] = 0.0;
+    double* rv = lcol + 16 * 64;            // rinv of the 16 pivots of this panel (wave-uniform values)
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = c0 + jj;
+        // A wave issues in order: work that does not depend on the pivot chain only overlaps the
+        // chain's latency (~16-20 cycles per dependent fp64 op, tools/mb4.hip) if it sits BETWEEN the
+        // chain's instructions in program order.  The rank-1 updates of the PREVIOUS step (their
+        // multiplicands were requested from LDS one step ago) are therefore dealt into four slots
+        // between the chain operations; sched_barrier keeps the compiler from regrouping them.
+#define GMRF_DELAYED_SLOT(S)                                                                        \
+        _Pragma("unroll") for (int cc = jj + 1 + (S); cc < 16; cc += 4) a[cc] = fma(-lprev, up[cc], a[cc]); \
+        __builtin_amdgcn_sched_barrier(0);
         const double p = bcast_lane(a[jj], j);
         if (!(p > 0.0)) bad = true;
-#if GMRF_TILE_EXACT_DIV
-        const double sq = sqrt(p);
-        const double l = a[jj] / sq;
-        if (r == j) rinvs[j] = 1.0 / sq;
-#else
-        const double rinv = rsqrt_nr(p);
+        const double y = __builtin_amdgcn_rsq(p);
+        __builtin_amdgcn_sched_barrier(0);
+        GMRF_DELAYED_SLOT(1)
+        const double e = fma(-p * y, y, 1.0);
+        __builtin_amdgcn_sched_barrier(0);
+        GMRF_DELAYED_SLOT(2)
+        const double cf = fma(0.375, e, 0.5);
+        const double rinv = fma(y * e, cf, y);
+        __builtin_amdgcn_sched_barrier(0);
+        GMRF_DELAYED_SLOT(3)
         const double l = a[jj] * rinv;       // lane j: p * rinv = sqrt(p)
-        if (r == j) rinvs[j] = rinv;
-#endif
+        rv[jj] = rinv;                       // same value from every lane: no branch
         a[jj] = l;
         lcol[jj * 64 + r] = l;
+        __builtin_amdgcn_sched_barrier(0);
+        GMRF_DELAYED_SLOT(0)                 // includes column jj + 1, needed by the update below
         if (jj < 15) {
             const double lc1 = bcast_lane(l, j + 1);
             a[jj + 1] = fma(-l, lc1, a[jj + 1]);
         }
-        // rank-1 updates of the PREVIOUS step on columns jj+1..15: their multiplicands were
-        // requested from LDS one step ago, so the read latency hides behind the work above
-#pragma unroll
-        for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-lprev, up[cc], a[cc]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cc = jj + 2; cc < 16; ++cc) up[cc] = lcol[jj * 64 + c0 + cc];
         lprev = l;
         __builtin_amdgcn_sched_barrier(0);
+#undef GMRF_DELAYED_SLOT
     }
+    if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int c = 0; c < 16; ++c) Ts[r * TLD + c0 + c] = a[c];
+    if (lane < 16) rinvs[c0 + lane] = rv[lane];
+    if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 }
 
 // One wave: X_kk = L_kk^-1 for the 16x16 diagonal block at c0 (lane c < 16 owns column c).
@@ -217,7 +238,7 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         const int c0 = 16 * kb;
         TILE_STAMP(1 + 3 * kb);
         if (wave == 0) {
-            panel_factor16(Ts, rinvs, Wk, c0, lane, bad);
+            panel_factor16(Ts, rinvs, Wk, c0, lane, bad, (side.stamps && kb == 0) ? side.stamps + 20 : nullptr);
             TILE_STAMP(2 + 3 * kb);
         } else if (kb == 0) {
             if (side.gA) side_load_tile(side.gA, side.ld, side.sA, tid - 64);

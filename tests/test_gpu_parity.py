@@ -325,11 +325,12 @@ def test_config_elliptic_long_chain_properties(pkg):
 
 
 def test_large_block_size_4096(pkg):
-    """Block size of BASELINE config[4] (bs = 4096, 64 tiles per block) on a short chain."""
-    w = pkg.workloads.burgers(4096, 3)
+    """Block size of BASELINE config[4] (bs = 4096, 64 tiles per block, six doubling levels of the
+    block inverse) on a short, well-conditioned chain."""
+    w = pkg.workloads.random_block_tridiagonal(3, 4096, seed=8, density=0.002)
     F = pkg.tridiagonal_cholesky(w.Q, 3)
     mu = pkg.ldiv(F, w.rhs)
     qn = abs(w.Q).sum(axis=1).max()
     assert np.linalg.norm(w.Q @ mu - w.rhs) / (qn * np.linalg.norm(mu) + np.linalg.norm(w.rhs)) < 1e-14
     import scipy.sparse.linalg as spla
-    assert rel(mu, spla.splu(w.Q.tocsc()).solve(w.rhs)) < 1e-8
+    assert rel(mu, spla.splu(w.Q.tocsc()).solve(w.rhs)) < 1e-12

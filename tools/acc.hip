@@ -14,6 +14,7 @@ __global__ void k(const double* p, double* out, int n) {
     double f = fma(-x * r0, r0, 1.0); double r1 = fma(0.5 * r0, f, r0);
     f = fma(-x * r1, r1, 1.0); double r2 = fma(0.5 * r1, f, r1);
     out[i * 6 + 0] = y0; out[i * 6 + 1] = y1; out[i * 6 + 2] = y2;
+    { double e = fma(-x * r0, r0, 1.0); double c = fma(0.375, e, 0.5); r1 = fma(r0 * e, c, r0); }   // Halley
     out[i * 6 + 3] = r0; out[i * 6 + 4] = r1; out[i * 6 + 5] = r2;
 }
 int main() {
@@ -34,7 +35,7 @@ int main() {
         { long double s0 = (long double)(p[i] * o[i * 6 + 5]); long double st = sqrtl((long double)p[i]); sq2 += (s0 - st) / st; long double sl = (long double)sqrt(p[i]); sq2b += (sl - st) / st; }
     }
     printf("rcp: seed %.3e  1NR %.3e  2NR %.3e   (eps = %.3e)\n", m[0], m[1], m[2], 2.22e-16);
-    printf("rsq: seed %.3e  1NR %.3e  2NR %.3e\n", m[3], m[4], m[5]);
+    printf("rsq: seed %.3e  1 Halley %.3e  2NR %.3e\n", m[3], m[4], m[5]);
     printf("mean signed rel err: rcp 2NR %.3Le | rsq 2NR %.3Le | p*rsq(p) as sqrt %.3Le | host sqrt %.3Le\n", sg[2] / n, sg[5] / n, sq2 / n, sq2b / n);
     return 0;
 }
