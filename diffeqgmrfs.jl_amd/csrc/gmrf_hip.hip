@@ -125,6 +125,7 @@ struct gmrf_handle {
     double* d_acc = nullptr;           // variance accumulator (n)
     // graphs
     bool eager = false;
+    bool split_step = false;           // use the three-launch panel step also for batch 1 (experiment)
     hipGraphExec_t factor_graph = nullptr;
     int64_t factor_graph_i0 = -1, factor_graph_i1 = -1;
     std::map<int64_t, hipGraphExec_t> sweep_graphs;   // key = mode * 4096 + kp
@@ -397,14 +398,14 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const int m = nt - j - 1;
         const double rem = 64.0 * m;
         ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0) * (double)h->B);
-        if (h->B == 1 || m == 0) {
+        if ((h->B == 1 && !h->split_step) || m == 0) {
             hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
                                h->stream, sa);
         } else {
             // batch: factor the B diagonal tiles once, then update without the redundant tile work
             hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
-            hipLaunchKernelGGL(potrf_step<true>, dim3(m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
-                               h->stream, sa);
+            hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+            hipLaunchKernelGGL(potrf_update, dim3(m * (m + 1) / 2, (unsigned)h->B), dim3(256), 0, h->stream, sa);
         }
         HIPCHK(hipGetLastError());
     }
@@ -706,7 +707,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
 
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (!h) return bad_shape("null handle");
-    h->eager = eager != 0;
+    if (((eager & 2) != 0) != h->split_step) { destroy_graphs(h); h->split_step = (eager & 2) != 0; }
+    h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
 

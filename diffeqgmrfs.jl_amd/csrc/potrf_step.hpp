@@ -460,6 +460,76 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Split form of the panel step for batches of problems (throughput regime): after the tile launch
+// (potrf_step<false> with grid.x = 1) the panel and the trailing update run as two small kernels
+// that feed the MFMAs straight from global memory / L2 -- no LDS, no barriers, ~100 VGPRs, so
+// several workgroups are resident per CU and one's loads overlap another's MFMAs.
+//   potrf_panel : L[r,j] = S[r,j] X_jj^T                 grid (m, B)
+//   potrf_update: S[r,c] -= L[r,j] L[c,j]^T  (j < c <= r) grid (m(m+1)/2, B)
+// A lane fetches two consecutive k of its operand row (16 B) and feeds them to two MFMAs (k-slot
+// permutation as in gemm_f64.hpp); each wave owns a 16-row strip of the 64x64 tile.
+__global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
+    sa.S += (int64_t)blockIdx.y * sa.pS;
+    sa.L += (int64_t)blockIdx.y * sa.pLX;
+    sa.X += (int64_t)blockIdx.y * sa.pLX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
+    const int64_t R0 = (int64_t)(sa.j + 1 + blockIdx.x) * 64 + 16 * wave;
+    v2d a[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg)
+        a[kg] = *reinterpret_cast<const v2d*>(sa.S + (R0 + li) * ld + oj + 8 * kg + 2 * lq);
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kg = 0; kg < 2 * Jb + 2; ++kg) {          // X lower triangular
+            const v2d x = *reinterpret_cast<const v2d*>(sa.X + (oj + 16 * Jb + li) * ld + oj + 8 * kg + 2 * lq);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, x.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, x.y, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sa.L[(R0 + lq + 4 * q) * ld + oj + 16 * Jb + li] = acc[q];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
+    sa.S += (int64_t)blockIdx.y * sa.pS;
+    sa.L += (int64_t)blockIdx.y * sa.pLX;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
+    int t = blockIdx.x, rr = 0;
+    while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+    const int r = sa.j + 1 + rr, c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+    const int64_t R0 = (int64_t)r * 64 + 16 * wave, C0 = (int64_t)c * 64;
+    const int jb_end = (c == r) ? wave + 1 : 4;
+    v2d a[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg)
+        a[kg] = *reinterpret_cast<const v2d*>(sa.L + (R0 + li) * ld + oj + 8 * kg + 2 * lq);
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        if (Jb < jb_end) {
+            double* cg = sa.S + R0 * ld + C0 + 16 * Jb;
+            v4d cur;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = cg[(int64_t)(lq + 4 * q) * ld + li];
+            v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};         // product from zero, one subtraction (rounding)
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const v2d b = *reinterpret_cast<const v2d*>(sa.L + (C0 + 16 * Jb + li) * ld + oj + 8 * kg + 2 * lq);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cg[(int64_t)(lq + 4 * q) * ld + li] = cur[q] - acc[q];
+        }
+    }
+}
+
 constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
 
 // Stand-alone tile kernel (tests): S (ld 64) -> L, X.
