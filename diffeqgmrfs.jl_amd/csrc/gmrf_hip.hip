@@ -650,7 +650,6 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(gemm_init());
     *out = h;
     return GMRF_OK;
