@@ -56,10 +56,27 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
 
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
     const double* __restrict__ xrow = s.Xin + (int64_t)(r0 + li) * s.ldx;
+    // Operands come straight from global memory (each wave has its own K range, nothing to share
+    // through LDS).  Loads are issued a whole chunk of 8 k-groups ahead of the MFMAs that consume
+    // them, otherwise every pair of MFMAs waits a full memory latency.
+    constexpr int CH = 8;
     if (!TRANS) {
         const double* __restrict__ mrow = s.Mat + (int64_t)(m0 + li) * s.ld;
-#pragma unroll 4
-        for (int k = k_lo; k < k_hi; k += 8) {
+        int k = k_lo;
+        for (; k + 8 * CH <= k_hi; k += 8 * CH) {
+            v2d a[CH], b[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                a[u] = *reinterpret_cast<const v2d*>(xrow + k + 8 * u + 2 * lq);
+                b[u] = *reinterpret_cast<const v2d*>(mrow + k + 8 * u + 2 * lq);
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, acc, 0, 0, 0);
+            }
+        }
+        for (; k < k_hi; k += 8) {
             const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
             const v2d b = *reinterpret_cast<const v2d*>(mrow + k + 2 * lq);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc, 0, 0, 0);
@@ -67,8 +84,23 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
         }
     } else {
         const double* __restrict__ mcol = s.Mat + m0 + li;
-#pragma unroll 4
-        for (int k = k_lo; k < k_hi; k += 8) {
+        int k = k_lo;
+        for (; k + 8 * CH <= k_hi; k += 8 * CH) {
+            v2d a[CH];
+            double b0[CH], b1[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                a[u] = *reinterpret_cast<const v2d*>(xrow + k + 8 * u + 2 * lq);
+                b0[u] = mcol[(int64_t)(k + 8 * u + 2 * lq) * s.ld];
+                b1[u] = mcol[(int64_t)(k + 8 * u + 2 * lq + 1) * s.ld];
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b0[u], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b1[u], acc, 0, 0, 0);
+            }
+        }
+        for (; k < k_hi; k += 8) {
             const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
             const double b0 = mcol[(int64_t)(k + 2 * lq) * s.ld];
             const double b1 = mcol[(int64_t)(k + 2 * lq + 1) * s.ld];
@@ -101,7 +133,22 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
     const double* __restrict__ x = s.Xin;
     double sum0 = 0.0, sum1 = 0.0;
     const int ke2 = ke & ~1;
-    for (int k = lane * 2; k < ke2; k += 128) {
+    // all loads of a chunk of 8 strides are issued before the first fma consumes one
+    int k = lane * 2;
+    for (; k + 7 * 128 < ke2; k += 8 * 128) {
+        v2d mv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
+            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            sum0 = fma(mv[u].x, xv[u].x, sum0);
+            sum1 = fma(mv[u].y, xv[u].y, sum1);
+        }
+    }
+    for (; k < ke2; k += 128) {
         const v2d mv = *reinterpret_cast<const v2d*>(mrow + k);
         const v2d xv = *reinterpret_cast<const v2d*>(x + k);
         sum0 = fma(mv.x, xv.x, sum0);
@@ -131,7 +178,7 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
     const double* __restrict__ x = s.Xin;
     const double* __restrict__ mp = s.Mat + col0 + c;
     double sum = 0.0;
-#pragma unroll 8
+#pragma unroll 16
     for (int k = kb + gidx; k < s.bs; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
     __shared__ double red[16][17];
     red[gidx][c] = sum;
