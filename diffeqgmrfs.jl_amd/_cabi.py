@@ -29,7 +29,7 @@ EXPORTS = [
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
-    "gmrf_test_gemm", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
+    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
 ]
 
@@ -114,6 +114,7 @@ def load() -> C.CDLL:
         "gmrf_csr_destroy": [vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],
+        "gmrf_test_gemm_rate": [i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, P(dbl)],
         "gmrf_test_potrf_tile": [i32, vp, vp, P(i32)],
         "gmrf_test_potrf_block": [i32, i64, vp, vp, P(i32)],
         "gmrf_test_tile_timing": [vp, i32],

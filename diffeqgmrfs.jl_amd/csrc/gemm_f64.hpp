@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace gmrf {
 
@@ -39,7 +40,7 @@ struct GemmArgs {
     int nb1;                             // inner batch count (>= 1)
     int M, N, K;
     int tri;
-    int lower_only;                      // skip tiles strictly above the block diagonal
+    int lower_only;                      // skip tiles strictly above the block diagonal (launcher: 1 = triangular grid, 2 = early exit)
     double alpha, beta;
     unsigned long long* stamps;          // diagnostic (tests): s_memtime / s_memrealtime of block 0
 };
@@ -83,6 +84,40 @@ __device__ __forceinline__ void gemm_store_tile(double* sm, int t, const v2d (&r
     }
 }
 
+// Tile order over a 1-D grid (both kernels).  Workgroup ids go round-robin over the 8 XCDs, so
+// with a multiple of 8 problems id % 8 picks the problem group: every XCD works on whole
+// problems and their operand panels are shared in ITS L2.  Inside a group the tiles with the
+// longest K range (triangular operands) are issued first and the short ones fill the tail.
+template <int BT>
+__device__ __forceinline__ void gemm_tile_order(const GemmArgs& g, int& bm, int& bn, int& z) {
+    const int nx = g.N / BT, ny = g.M / BT;
+    const int tpp = g.lower_only == 1 ? nx * (nx + 1) / 2 : nx * ny;
+    const int nz = (int)gridDim.x / tpp;
+    const int groups = (nz % 8 == 0) ? 8 : 1;
+    const int xg = (int)blockIdx.x % groups, q = (int)blockIdx.x / groups, nzg = nz / groups;
+    int zq;
+    if (g.lower_only == 1) {
+        const int tile = q % tpp;
+        zq = q / tpp;
+        bm = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+        while (bm * (bm + 1) / 2 > tile) --bm;
+        while ((bm + 1) * (bm + 2) / 2 <= tile) ++bm;
+        bn = tile - bm * (bm + 1) / 2;
+    } else {
+        const bool cls_n = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) || !(g.tri & (TRI_A_LOWER | TRI_A_UPPER));
+        const bool desc = cls_n ? (g.tri & TRI_B_UPPER) != 0 : (g.tri & TRI_A_LOWER) != 0;
+        const int ncls = cls_n ? nx : ny, other = cls_n ? ny : nx;
+        int c = q / (other * nzg);
+        const int rem = q % (other * nzg);
+        const int o = rem % other;
+        zq = rem / other;
+        if (desc) c = ncls - 1 - c;
+        bn = cls_n ? c : o;
+        bm = cls_n ? o : c;
+    }
+    z = xg + groups * zq;
+}
+
 // K is stepped by BK (16 or 32) through a double-buffered LDS image [row][k] with row stride
 // BK + 4 doubles.  A lane fetches TWO consecutive k (one ds_read_b128, conflict free at this
 // stride for the 4 x 16-lane groups of that instruction) and feeds them to two MFMAs: MFMA 1
@@ -108,10 +143,11 @@ __device__ __forceinline__ GemmFrag gemm_read_frag(const double* as, const doubl
 template <bool A_T, bool B_N, int BK>
 __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     constexpr int LD = BK + 4;
-    const int bm = blockIdx.y, bn = blockIdx.x;
-    if (g.lower_only && bn > bm) return;
+    int bm, bn, z;
+    gemm_tile_order<GEMM_BM>(g, bm, bn, z);
+    if (g.lower_only == 2 && bn > bm) return;
     const int m0 = bm * GEMM_BM, n0 = bn * GEMM_BN;
-    const int zi = blockIdx.z % g.nb1, zp = blockIdx.z / g.nb1;
+    const int zi = z % g.nb1, zp = z / g.nb1;
     const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
     const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
     double* __restrict__ C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
@@ -182,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         if (!(g.tri & 1024)) __syncthreads();
     }
 
-    if (g.stamps && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+    if (g.stamps && blockIdx.x == 0 && t == 0) {
         g.stamps[0] = __builtin_amdgcn_s_memtime() - c0;
         g.stamps[1] = __builtin_amdgcn_s_memrealtime() - r0;
     }
@@ -203,6 +239,178 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
             }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 output tile per workgroup: 4 waves, each a 64 x 64 quadrant = 4 x 4 MFMA tiles
+// (128 accumulator VGPRs).  Every LDS / global instruction issued beside the fp64 MFMA stream
+// costs ~26 cycles of MFMA issue (measured, tools/mb4.hip), so the lever is instructions per
+// MFMA: an 8-wide k group takes 8 ds_read_b128 for 32 MFMAs here against 4 for 8 in the 64 x 64
+// kernel, and the staging traffic per MFMA halves as well.  K steps by 16, double buffered.
+//
+//   A is stored [m][k]  -> LDS [128][20] (k contiguous, same fragment scheme as above).
+//   B_N = false: B stored [n][k] -> LDS [128][20], tile j of a wave = columns 16 j + (lane & 15).
+//   B_N = true : B stored [k][n] -> LDS [16][128] as it lies in memory (straight b128 copies,
+//                no transposing ds_write_b64).  A lane reads the two neighbouring columns
+//                2 li, 2 li + 1 of row k = 8 kg + 2 lq + p: .x feeds the MFMA of the even
+//                columns of a 32-column group, .y the odd ones -- the output tiles 2 jp and
+//                2 jp + 1 interleave and are written back as one 16-byte store per lane.
+//                The four 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) each cover
+//                one full 256-byte row image (rows 2 lq apart, 2 * 128 doubles = 0 mod 256 B).
+// Used when M, N are multiples of 128, A is not transposed and the launch has enough tiles.
+constexpr int GEMM_BIG = 128;
+constexpr int GEMM_BIG_BK = 16;
+constexpr int GEMM_BIG_LDK = GEMM_BIG_BK + 4;
+
+template <bool B_N>
+constexpr size_t gemm_big_lds_bytes() {
+    return (size_t)2 * (GEMM_BIG * GEMM_BIG_LDK + (B_N ? GEMM_BIG_BK * GEMM_BIG : GEMM_BIG * GEMM_BIG_LDK)) * sizeof(double);
+}
+
+template <bool B_N>
+__global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
+    constexpr int BT = GEMM_BIG, BK = GEMM_BIG_BK, LDK = GEMM_BIG_LDK;
+    constexpr int A_STAGE = BT * LDK;
+    constexpr int B_STAGE = B_N ? BK * BT : BT * LDK;
+    int bm, bn, z;
+    gemm_tile_order<BT>(g, bm, bn, z);
+    const int m0 = bm * BT, n0 = bn * BT;
+    const int zi = z % g.nb1, zp = z / g.nb1;
+    const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
+    const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
+    double* __restrict__ C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+
+    int kb = 0, ke = g.K;
+    if (g.tri & TRI_A_LOWER) ke = min(ke, m0 + BT);
+    if (g.tri & TRI_A_UPPER) kb = max(kb, m0);
+    if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
+    if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + BT);
+
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double* As0 = gsm;                      // [2][A_STAGE]
+    double* Bs0 = gsm + 2 * A_STAGE;        // [2][B_STAGE]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    const int li = lane & 15, lq = lane >> 4;
+
+    v4d acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    // staging: [row][k] operands -- 8 threads per row, 32 rows per pass, 4 passes;
+    //          [k][n] operand   -- one wave per k row (64 lanes x 16 B), 4 rows per wave.
+    const int sr = t >> 3, sk = (t & 7) * 2;
+    const double* ap = A + (int64_t)(m0 + sr) * g.lda + sk;
+    const double* bp = B_N ? B + (int64_t)w * g.ldb + n0 + 2 * lane : B + (int64_t)(n0 + sr) * g.ldb + sk;
+    const int64_t a_step = 32 * g.lda, b_step = B_N ? 4 * g.ldb : 32 * g.ldb;
+    double* a_st = As0 + sr * LDK + sk;
+    double* b_st = B_N ? Bs0 + w * BT + 2 * lane : Bs0 + sr * LDK + sk;
+    constexpr int A_ST_STEP = 32 * LDK, B_ST_STEP = B_N ? 4 * BT : 32 * LDK;
+
+    const int nkt = (ke > kb) ? (ke - kb) / BK : 0;
+    v2d ra[4], rb[4];
+    auto load_stage = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const v2d*>(ap + k0 + i * a_step);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            rb[i] = *reinterpret_cast<const v2d*>(B_N ? bp + (int64_t)k0 * g.ldb + i * b_step : bp + k0 + i * b_step);
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(a_st + buf * A_STAGE + i * A_ST_STEP) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<v2d*>(b_st + buf * B_STAGE + i * B_ST_STEP) = rb[i];
+    };
+    if (nkt > 0) {
+        load_stage(kb);
+        store_stage(0);
+    }
+    __syncthreads();
+
+    const int a_frag = (wm + li) * LDK + 2 * lq;
+    const int b_frag = B_N ? (2 * lq) * BT + wn + 2 * li : (wn + li) * LDK + 2 * lq;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1 < nkt);
+        if (more) load_stage(kb + (kt + 1) * BK);
+        const double* as = As0 + cur * A_STAGE + a_frag;
+        const double* bs = Bs0 + cur * B_STAGE + b_frag;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            v2d fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *reinterpret_cast<const v2d*>(as + i * 16 * LDK + kg * 8);
+            if (B_N) {
+                // fb[2 jp + p] = columns (2 li, 2 li + 1) of group jp at k parity p
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        fb[2 * jp + p] = *reinterpret_cast<const v2d*>(bs + (kg * 8 + p) * BT + jp * 32);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *reinterpret_cast<const v2d*>(bs + j * 16 * LDK + kg * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double av = p ? fa[i].y : fa[i].x;
+                        double bv;
+                        if (B_N) bv = (j & 1) ? fb[2 * (j >> 1) + p].y : fb[2 * (j >> 1) + p].x;
+                        else bv = p ? fb[j].y : fb[j].x;
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm + i * 16 + lq + 4 * r;
+            double* crow = C + (int64_t)row * g.ldc + n0 + wn;
+            if (B_N) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    v2d* c = reinterpret_cast<v2d*>(crow + jp * 32 + 2 * li);
+                    v2d v = (v2d){alpha * acc[i][2 * jp][r], alpha * acc[i][2 * jp + 1][r]};
+                    if (beta != 0.0) { const v2d o = *c; v.x += beta * o.x; v.y += beta * o.y; }
+                    *c = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    double* c = crow + j * 16 + li;
+                    double v = alpha * acc[i][j][r];
+                    if (beta != 0.0) v += beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
+// Launches with at least this many 128 x 128 tiles take the big kernel (tests move it).
+inline int& gemm_big_min_tiles() {
+    static int v = [] {
+        const char* e = getenv("GMRF_GEMM_BIG_MIN_TILES");   // tuning aid
+        return e ? atoi(e) : 256;
+    }();
+    return v;
+}
+
 template <int BK>
 constexpr size_t gemm_lds_bytes() { return (size_t)4 * 64 * (BK + 4) * sizeof(double); }
 
@@ -215,18 +423,38 @@ inline hipError_t gemm_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
     GMRF_GEMM_ATTR(false, false) GMRF_GEMM_ATTR(false, true) GMRF_GEMM_ATTR(true, false) GMRF_GEMM_ATTR(true, true)
 #undef GMRF_GEMM_ATTR
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_f64_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)gemm_big_lds_bytes<false>());
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_f64_big<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)gemm_big_lds_bytes<true>());
     return e;
 }
 
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
 inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, int batch) {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
-    dim3 grid(g.N / GEMM_BN, g.M / GEMM_BM, batch), block(256);
+    const int64_t sx = g.N / GEMM_BN, sy = g.M / GEMM_BM;
+    const bool tri_grid = g.lower_only && g.M == g.N;
+    GemmArgs gs = g;
+    gs.lower_only = tri_grid ? 1 : (g.lower_only ? 2 : 0);   // 2: rectangular grid, tiles above the diagonal exit
+    dim3 grid((unsigned)((tri_grid ? sx * (sx + 1) / 2 : sx * sy) * batch)), block(256);
+    if (!a_t && g.M % GEMM_BIG == 0 && g.N % GEMM_BIG == 0 && g.K % GEMM_BIG_BK == 0 && !(g.tri & ~15) && !g.stamps) {
+        const int64_t tiles = (int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch;
+        if (tiles >= gemm_big_min_tiles() && (!g.lower_only || g.M == g.N)) {
+            const int64_t nx = g.N / GEMM_BIG, ny = g.M / GEMM_BIG;
+            dim3 bgrid((unsigned)((g.lower_only ? nx * (nx + 1) / 2 : nx * ny) * batch));
+            if (b_n) hipLaunchKernelGGL(gemm_f64_big<true>, bgrid, block, gemm_big_lds_bytes<true>(), st, g);
+            else hipLaunchKernelGGL(gemm_f64_big<false>, bgrid, block, gemm_big_lds_bytes<false>(), st, g);
+            return hipGetLastError();
+        }
+    }
     const bool wide = (g.K % 32 == 0);
 #define GMRF_GEMM_LAUNCH(AT, BN)                                                                 \
     do {                                                                                         \
-        if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>(), st, g); \
-        else hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 16>), grid, block, gemm_lds_bytes<16>(), st, g);      \
+        if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>(), st, gs); \
+        else hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 16>), grid, block, gemm_lds_bytes<16>(), st, gs);     \
     } while (0)
     if (!a_t && !b_n) GMRF_GEMM_LAUNCH(false, false);
     else if (!a_t && b_n) GMRF_GEMM_LAUNCH(false, true);

@@ -1281,18 +1281,68 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = g.strideB = g.strideC = 0;
     g.pA = g.pB = g.pC = 0; g.nb1 = 1;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
+    // tri_flags bit 2048: take the 128 x 128 kernel whatever the tile count
+    const bool force_big = (tri_flags & 2048) != 0;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~2048; g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta;
     unsigned long long* dst = nullptr;
     HIPCHK(hipMalloc(&dst, 16));
-    g.stamps = dst;
+    HIPCHK(hipMemset(dst, 0, 16));
+    g.stamps = force_big ? nullptr : dst;
     HIPCHK(gemm_init());
+    const int saved = gemm_big_min_tiles();
+    gemm_big_min_tiles() = force_big ? 1 : (1 << 30);
     // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
-    HIPCHK(launch_gemm(nullptr, transA != 0, transB == 0, g, 1));
+    hipError_t le = launch_gemm(nullptr, transA != 0, transB == 0, g, 1);
+    gemm_big_min_tiles() = saved;
+    HIPCHK(le);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(g_tile_stamps, dst, 16, hipMemcpyDeviceToHost));
     hipFree(dst);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K, int32_t transB, int32_t tri_flags,
+                                int32_t lower_only, int32_t batch, int32_t big, int32_t reps, double* ms_per_launch) {
+    if (M % 64 || N % 64 || K % 16 || batch < 1 || reps < 1) return bad_shape("gemm rate sizes");
+    HIPCHK(hipSetDevice(device));
+    const int64_t ld = std::max(std::max(M, N), K);
+    const int64_t pm = ld * ld;
+    double *dA, *dB, *dC;
+    HIPCHK(hipMalloc(&dA, sizeof(double) * pm * batch));
+    HIPCHK(hipMalloc(&dB, sizeof(double) * pm * batch));
+    HIPCHK(hipMalloc(&dC, sizeof(double) * pm * batch));
+    const int64_t tot = pm * batch;
+    hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dA, tot, 1 << 30,
+                       1 << 30, 1, 1, 1ull, 0, 0);
+    hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, nullptr, dB, tot, 1 << 30,
+                       1 << 30, 1, 1, 2ull, 0, 0);
+    HIPCHK(hipMemset(dC, 0, sizeof(double) * pm * batch));
+    GemmArgs g;
+    g.A = dA; g.B = dB; g.C = dC; g.lda = g.ldb = g.ldc = ld;
+    g.strideA = g.strideB = g.strideC = 0;
+    g.pA = g.pB = g.pC = pm; g.nb1 = 1;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
+    g.alpha = 1.0; g.beta = 0.0; g.stamps = nullptr;
+    HIPCHK(gemm_init());
+    const int saved = gemm_big_min_tiles();
+    gemm_big_min_tiles() = big ? 1 : (1 << 30);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    hipError_t le = hipSuccess;
+    for (int r = 0; r < 3 && le == hipSuccess; ++r) le = launch_gemm(nullptr, false, transB == 0, g, batch);
+    HIPCHK(hipEventRecord(e0, nullptr));
+    for (int r = 0; r < reps && le == hipSuccess; ++r) le = launch_gemm(nullptr, false, transB == 0, g, batch);
+    HIPCHK(hipEventRecord(e1, nullptr));
+    gemm_big_min_tiles() = saved;
+    HIPCHK(le);
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_launch = ms / reps;
+    hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(dA); hipFree(dB); hipFree(dC);
     return GMRF_OK;
 }

@@ -62,6 +62,38 @@ def test_gemm_lower_only_leaves_upper_tiles(lib, pkg):
                 assert np.array_equal(out[blk], c0[blk])
 
 
+BIG = 2048   # gmrf_test_gemm: take the 128 x 128 kernel
+
+
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("tri", [0, 1, 4, 8])
+def test_gemm_big_tile_kernel(lib, pkg, tb, tri):
+    M, N, K = (256, 256, 256) if tri else (256, 384, 208)
+    out, ref, _ = _gemm(lib, pkg, M, N, K, 0, tb, tri=tri | BIG, alpha=-0.75, beta=1.0, seed=40 + tri + tb)
+    assert np.max(np.abs(out - ref)) < 1e-12 * 256
+
+
+def test_gemm_big_matches_small_bitwise(lib, pkg):
+    # same k order per output element in both kernels (k ascending inside each MFMA slot chain)
+    a, ref, _ = _gemm(lib, pkg, 256, 256, 128, 0, 1, tri=BIG, seed=77)
+    b, _, _ = _gemm(lib, pkg, 256, 256, 128, 0, 1, tri=0, seed=77)
+    assert np.max(np.abs(a - b)) < 1e-13 * 128
+    c, _, _ = _gemm(lib, pkg, 256, 256, 128, 0, 0, tri=BIG, seed=78)
+    d, _, _ = _gemm(lib, pkg, 256, 256, 128, 0, 0, tri=0, seed=78)
+    assert np.max(np.abs(c - d)) < 1e-13 * 128
+
+
+def test_gemm_big_lower_only(lib, pkg):
+    out, ref, c0 = _gemm(lib, pkg, 384, 384, 64, 0, 0, tri=BIG, lower=1, alpha=-1.0, beta=1.0, seed=6)
+    for bm in range(3):
+        for bn in range(3):
+            blk = (slice(bm * 128, bm * 128 + 128), slice(bn * 128, bn * 128 + 128))
+            if bn <= bm:
+                assert np.max(np.abs(out[blk] - ref[blk])) < 1e-11
+            else:
+                assert np.array_equal(out[blk], c0[blk])
+
+
 def _spd(n, seed, cond_boost=0.0):
     rng = np.random.default_rng(seed)
     G = rng.standard_normal((n, n))
