@@ -4,7 +4,7 @@
 // calls Julia's LinearAlgebra makes for /root/reference/src/tridiagonal_cholesky.jl:74,77
 // (C = B L^-T, D - C C^T) and the level-3 parts of dpotrf / dtrtri on one block.
 //
-//   C[m][n] = beta * C[m][n] + alpha * sum_k a(m,k) * b(k,n)
+//   C[m][n] = beta * D[m][n] + alpha * sum_k a(m,k) * b(k,n)         (D = C unless given)
 //   a(m,k) = A_T ? A[k*lda + m] : A[m*lda + k]        (A_T: A is stored K x M)
 //   b(k,n) = B_N ? B[k*ldb + n] : B[n*ldb + k]        (B_N: B is stored K x N, else N x K)
 //
@@ -42,6 +42,8 @@ struct GemmArgs {
     int tri;
     int lower_only;                      // skip tiles strictly above the block diagonal (launcher: 1 = triangular grid, 2 = early exit)
     double alpha, beta;
+    const double* D;                     // addend: C = beta * D + alpha * A B  (nullptr: D = C, in place)
+    int64_t ldd, pD;                     // its row stride and problem stride
     unsigned long long* stamps;          // diagnostic (tests): s_memtime / s_memrealtime of block 0
 };
 
@@ -150,7 +152,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     const int zi = z % g.nb1, zp = z / g.nb1;
     const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
     const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
-    double* __restrict__ C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+    double* C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+    const double* Dm = g.D ? g.D + (int64_t)zp * g.pD : C;
+    const int64_t ldd = g.D ? g.ldd : g.ldc;
 
     int kb = 0, ke = g.K;
     if (g.tri & TRI_A_LOWER) ke = min(ke, m0 + GEMM_BM);
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
                 const int col = n0 + wn + j * 16 + li;
                 double* c = C + (int64_t)row * g.ldc + col;
                 double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * (*c);
+                if (beta != 0.0) v += beta * Dm[(int64_t)row * ldd + col];
                 *c = v;
             }
 }
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
     const int zi = z % g.nb1, zp = z / g.nb1;
     const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
     const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
-    double* __restrict__ C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+    double* C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+    const double* Dm = g.D ? g.D + (int64_t)zp * g.pD : C;
+    const int64_t ldd = g.D ? g.ldd : g.ldc;
 
     int kb = 0, ke = g.K;
     if (g.tri & TRI_A_LOWER) ke = min(ke, m0 + BT);
@@ -382,21 +388,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + wm + i * 16 + lq + 4 * r;
             double* crow = C + (int64_t)row * g.ldc + n0 + wn;
+            const double* drow = Dm + (int64_t)row * ldd + n0 + wn;
             if (B_N) {
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) {
-                    v2d* c = reinterpret_cast<v2d*>(crow + jp * 32 + 2 * li);
                     v2d v = (v2d){alpha * acc[i][2 * jp][r], alpha * acc[i][2 * jp + 1][r]};
-                    if (beta != 0.0) { const v2d o = *c; v.x += beta * o.x; v.y += beta * o.y; }
-                    *c = v;
+                    if (beta != 0.0) {
+                        const v2d o = *reinterpret_cast<const v2d*>(drow + jp * 32 + 2 * li);
+                        v.x += beta * o.x; v.y += beta * o.y;
+                    }
+                    *reinterpret_cast<v2d*>(crow + jp * 32 + 2 * li) = v;
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    double* c = crow + j * 16 + li;
                     double v = alpha * acc[i][j][r];
-                    if (beta != 0.0) v += beta * (*c);
-                    *c = v;
+                    if (beta != 0.0) v += beta * drow[j * 16 + li];
+                    crow[j * 16 + li] = v;
                 }
             }
         }

@@ -126,6 +126,7 @@ struct gmrf_handle {
     // graphs
     bool eager = false;
     bool split_step = false;           // use the three-launch panel step also for batch 1 (experiment)
+    bool sweep_no_gemm = false;        // keep 64-multiples of right-hand sides on sweep_mm (comparison)
     hipGraphExec_t factor_graph = nullptr;
     int64_t factor_graph_i0 = -1, factor_graph_i1 = -1;
     std::map<int64_t, hipGraphExec_t> sweep_graphs;   // key = mode * 4096 + kp
@@ -188,8 +189,10 @@ static void prof_collect(gmrf_handle* h) {
 static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K, int tri, int lower_only,
                         double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int64_t pA, int64_t pB, int64_t pC,
-                        int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0) {
+                        int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0, const double* D = nullptr,
+                        int64_t ldd = 0, int64_t pD = 0, int pclass = 0, double pwork = -1.0) {
     GemmArgs g;
+    g.D = D; g.ldd = ldd; g.pD = pD;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = sA; g.strideB = sB; g.strideC = sC;
@@ -199,7 +202,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     double flops = 2.0 * M * N * (double)K * batch * (double)h->B;
     if (lower_only) flops *= 0.5 * (1.0 + 64.0 / std::max(M, 64));
     if (tri) flops *= 0.5 * (1.0 + 64.0 / std::max(K, 64));
-    ProfScope ps(h, 0, flops);
+    ProfScope ps(h, pclass, pwork >= 0.0 ? pwork : flops);
     HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch * (int)h->B));
     return GMRF_OK;
 }
@@ -541,6 +544,9 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
     const int64_t pLX = bstride * N, pCm = bstride * std::max<int64_t>(N - 1, 1);
     // class 3 (k = 1): algorithmic bytes of the block read; class 2: flops of the panel product
     const int pclass = (kp == 1) ? 3 : 2;
+    // 64-multiples of right-hand sides go through the GEMM kernel (panel = the [m][k] operand) when
+    // the batch gives it enough 64 x 64 tiles; a lone problem stays on sweep_mm (256 workgroups)
+    const bool via_gemm = (kp % 64 == 0) && !h->sweep_no_gemm && (int64_t)nprob * (bsp / 64) * (kp / 64) >= 128;
     const double blk_bytes_c = ((kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp) * nprob;
     const double blk_bytes_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
     for (int64_t step = 0; step < N; ++step) {
@@ -556,7 +562,11 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
             s.Out = h->d_Tp; s.ldo = bsp;
             s.sub = 1;
             s.pMat = pCm; s.pXin = pPanel; s.pBin = pPanel; s.pOut = pT;
-            {
+            if (via_gemm) {
+                // T[r][m] = P[r][m] - sum_k y[r][k] c(k,m): the panel is the [m][k] operand, the block the other
+                GCHK(gemm(h, false, backward, kp, bsp, bsp, 0, 0, -1.0, s.Xin, npad, s.Mat, ld, 1.0, h->d_Tp, bsp, pPanel,
+                          pCm, pT, 1, 0, 0, 0, rhs, npad, pPanel, pclass, blk_bytes_c));
+            } else {
                 ProfScope ps(h, pclass, blk_bytes_c);
                 HIPCHK(launch_sweep(h->stream, backward, false, kp, s, nprob));
             }
@@ -569,7 +579,11 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const d
         s.Out = Yout + i * bsp; s.ldo = npad;
         s.sub = 0;
         s.pMat = pLX; s.pXin = (step > 0) ? pT : pPanel; s.pBin = 0; s.pOut = pPanel;
-        {
+        if (via_gemm) {
+            // forward: Linv stored [m][k], zero for k > m; backward: Linv^T, stored [k][m], zero for k < m
+            GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, s.Xin, s.ldx, s.Mat,
+                      ld, 0.0, s.Out, npad, s.pXin, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_t));
+        } else {
             ProfScope ps(h, pclass, blk_bytes_t);
             HIPCHK(launch_sweep(h->stream, backward, true, kp, s, nprob));
         }
@@ -707,6 +721,7 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (!h) return bad_shape("null handle");
     if (((eager & 2) != 0) != h->split_step) { destroy_graphs(h); h->split_step = (eager & 2) != 0; }
+    if (((eager & 4) != 0) != h->sweep_no_gemm) { destroy_graphs(h); h->sweep_no_gemm = (eager & 4) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -1281,6 +1296,7 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.strideA = g.strideB = g.strideC = 0;
     g.pA = g.pB = g.pC = 0; g.nb1 = 1;
+    g.D = nullptr; g.ldd = 0; g.pD = 0;
     // tri_flags bit 2048: take the 128 x 128 kernel whatever the tile count
     const bool force_big = (tri_flags & 2048) != 0;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~2048; g.lower_only = lower_only;
@@ -1324,6 +1340,7 @@ gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K,
     g.A = dA; g.B = dB; g.C = dC; g.lda = g.ldb = g.ldc = ld;
     g.strideA = g.strideB = g.strideC = 0;
     g.pA = g.pB = g.pC = pm; g.nb1 = 1;
+    g.D = nullptr; g.ldd = 0; g.pD = 0;
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
     g.alpha = 1.0; g.beta = 0.0; g.stamps = nullptr;
     HIPCHK(gemm_init());

@@ -66,7 +66,7 @@ def test_mean_and_half_solves(case, pkg):
     assert pkg.ldiv_(y, F, w.rhs) is y and rel(y, mu) == 0.0
 
 
-@pytest.mark.parametrize("k", [2, 16, 33, 64])
+@pytest.mark.parametrize("k", [2, 16, 33, 64, 128])
 def test_matrix_right_hand_sides(case, pkg, k):
     w, F, Fo = case
     B = np.random.default_rng(k).standard_normal((w.n, k))
@@ -153,6 +153,22 @@ def test_eager_and_graph_paths_agree_bitwise(pkg):
     F.refactor(w.Q.data)
     b = pkg.ldiv(F, w.rhs)
     assert np.array_equal(a, b)
+
+
+def test_panel_sweeps_through_gemm_match_sweep_kernel(pkg):
+    # 64-multiples of right-hand sides run the sweeps on the GEMM kernel; bit 2 of set_eager keeps
+    # them on sweep_mm.  Same products, different summation order.
+    w = pkg.workloads.make("darcy64")
+    nb = 32                                     # enough problems for the GEMM route (128 tiles)
+    F = pkg.TridiagonalCholeskyFactor(batch=nb).factor(w.Q, w.n_blocks, values=np.tile(w.Q.data, (nb, 1)))
+    B = np.random.default_rng(5).standard_normal((nb, 64, w.n))
+    a = [F.solve_batch(B, m) for m in (pkg._cabi.SOLVE_FULL, pkg._cabi.SOLVE_FORWARD, pkg._cabi.SOLVE_BACKWARD)]
+    F.set_eager(4)
+    b = [F.solve_batch(B, m) for m in (pkg._cabi.SOLVE_FULL, pkg._cabi.SOLVE_FORWARD, pkg._cabi.SOLVE_BACKWARD)]
+    for x, y in zip(a, b):
+        assert rel(x, y) < 1e-12 and not np.array_equal(x, y)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    assert rel(a[0][7].T, O.ldiv(Fo, B[7].T)) < solve_tol(w)
 
 
 def test_extract_blocks_route_and_padding(pkg):
