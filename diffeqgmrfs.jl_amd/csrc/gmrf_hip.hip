@@ -393,24 +393,45 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
     const int nt = bsp / 64;
+    // Batches: two-level blocking.  Inside a 256-column panel the 64-column steps update only the
+    // panel's own columns; the rest of the trailing block gets ONE rank-256 update per panel from
+    // the GEMM kernel (a quarter of the read-modify-write traffic of four rank-64 updates, and
+    // one rounding at |S| instead of four).  A lone problem keeps the fused one-launch step.
+    const bool fused = (h->B == 1 && !h->split_step);
+    const int pw = (!fused && nt >= 8) ? 4 : nt;           // panel width in tiles
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
         sa.info = h->d_info; sa.blk = blk_id;
         sa.pS = (int64_t)bsp * bsp; sa.pLX = (int64_t)bsp * bsp * h->N; sa.blk_per_problem = (int)h->N;
         const int m = nt - j - 1;
+        const int cend = std::min(nt, (j / pw + 1) * pw);  // first column tile outside this panel
+        sa.cend = cend;
+        int utiles = 0;
+        for (int c = j + 1; c < cend; ++c) utiles += nt - c;
         const double rem = 64.0 * m;
-        ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + rem * (rem + 1.0) * 64.0) * (double)h->B);
-        if ((h->B == 1 && !h->split_step) || m == 0) {
-            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
-                               h->stream, sa);
-        } else {
-            // batch: factor the B diagonal tiles once, then update without the redundant tile work
-            hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
-            hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
-            hipLaunchKernelGGL(potrf_update, dim3(m * (m + 1) / 2, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+        {
+            ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + 2.0 * 64.0 * 64.0 * 64.0 * utiles) * (double)h->B);
+            if (fused || m == 0) {
+                hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
+                                   h->stream, sa);
+            } else {
+                // factor the B diagonal tiles once, then panel and update without the redundant tile work
+                hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+                hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+                if (utiles > 0)
+                    hipLaunchKernelGGL(potrf_update, dim3(utiles, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+            }
+            HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipGetLastError());
+        if (j + 1 == cend && cend < nt) {
+            // S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the finished panel P
+            const int j0 = cend - pw, mr = nt - cend;
+            const double* Lp = L + (int64_t)cend * 64 * ld + (int64_t)j0 * 64;
+            double* Sr = S + (int64_t)cend * 64 * ld + (int64_t)cend * 64;
+            GCHK(gemm(h, false, false, mr * 64, mr * 64, pw * 64, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, Sr, ld, sa.pLX, sa.pLX,
+                      sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 1, 2.0 * 64.0 * 64.0 * (pw * 64.0) * (mr * (mr + 1) / 2) * (double)h->B));
+        }
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
     for (int hh = 64; hh < bsp; hh *= 2) {

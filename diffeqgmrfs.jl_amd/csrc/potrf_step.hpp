@@ -330,6 +330,7 @@ struct StepArgs {
     int blk;              // block id reported on a non-positive pivot (1-based)
     int64_t pS, pLX;      // per-problem strides of S and of L / X (blockIdx.y)
     int blk_per_problem;  // reported id = blk + blockIdx.y * blk_per_problem
+    int cend;             // potrf_update: column tiles j+1 .. cend-1 only (nt: the whole trailing block)
 };
 
 // grid.x = 1 + m (m + 1) / 2,  m = nt - j - 1.
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
 // that feed the MFMAs straight from global memory / L2 -- no LDS, no barriers, ~100 VGPRs, so
 // several workgroups are resident per CU and one's loads overlap another's MFMAs.
 //   potrf_panel : L[r,j] = S[r,j] X_jj^T                 grid (m, B)
-//   potrf_update: S[r,c] -= L[r,j] L[c,j]^T  (j < c <= r) grid (m(m+1)/2, B)
+//   potrf_update: S[r,c] -= L[r,j] L[c,j]^T  (j < c <= r, c < cend)  grid (sum_c (nt - c), B)
 // A lane fetches two consecutive k of its operand row (16 B) and feeds them to two MFMAs (k-slot
 // permutation as in gemm_f64.hpp); each wave owns a 16-row strip of the 64x64 tile.
 __global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
@@ -501,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
-    int t = blockIdx.x, rr = 0;
-    while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
-    const int r = sa.j + 1 + rr, c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+    int t = blockIdx.x, c = sa.j + 1;            // column by column: column c has nt - c row tiles
+    while (t >= sa.nt - c) { t -= sa.nt - c; ++c; }
+    const int r = c + t;
     const int64_t R0 = (int64_t)r * 64 + 16 * wave, C0 = (int64_t)c * 64;
     const int jb_end = (c == r) ? wave + 1 : 4;
     v2d a[8];

@@ -328,6 +328,32 @@ def test_config_burgers512x64_against_oracle(pkg):
     assert abs(F.logdet() - O.logdet(Fo)) < 1e-10 * abs(O.logdet(Fo))
 
 
+def test_two_level_panel_factor_of_batches(pkg):
+    """Batches factor a block in 256-column panels (rank-256 trailing updates on the GEMM kernel).
+    burgers512x64 (8 tiles per block) as a batch of two: against the oracle, and bitwise against a
+    single problem driven through the same three-launch / two-level path (set_eager bit 1)."""
+    w = pkg.workloads.make("burgers512x64")
+    vals = np.stack([w.Q.data, w.Q.data * 1.25])
+    rhs = np.stack([w.rhs, w.rhs * 2.0])
+    Fb = pkg.TridiagonalCholeskyFactor(batch=2).factor(w.Q, w.n_blocks, values=vals)
+    mu_b = Fb.solve_batch(rhs[:, None, :])[:, 0, :]
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    assert rel(mu_b[0], O.ldiv(Fo, w.rhs)) < solve_tol(w)
+    assert rel(mu_b[1], O.ldiv(Fo, w.rhs) * (2.0 / 1.25)) < solve_tol(w)
+    qn = abs(w.Q).sum(axis=1).max()
+    assert np.linalg.norm(w.Q @ mu_b[0] - w.rhs) / (qn * np.linalg.norm(mu_b[0]) + np.linalg.norm(w.rhs)) < 1e-14
+    Fb.select_problem(0)
+    assert np.max(np.abs(np.tril(Fb.chos[63]) - Fo.chos[63])) / np.max(np.abs(Fo.chos[63])) < TOL_FACTOR
+    assert abs(Fb.logdet() - O.logdet(Fo)) < 1e-10 * abs(O.logdet(Fo))
+    F1 = pkg.TridiagonalCholeskyFactor()
+    F1.set_eager(2)
+    F1.factor(w.Q, w.n_blocks)
+    assert np.array_equal(F1.chos[63], Fb.chos[63]) and np.array_equal(pkg.ldiv(F1, w.rhs), mu_b[0])
+    F1.set_eager(0)                      # fused one-launch step: same factor up to rounding
+    F1.refactor(w.Q.data)
+    assert 0 < np.max(np.abs(F1.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
+
+
 def test_config_elliptic_long_chain_properties(pkg):
     """BASELINE config[3] family (elliptic, bs = 2 node rows) with a long chain: 128 x 128 nodes ->
     64 blocks of 256; size-independent properties and the oracle."""
