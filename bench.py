@@ -40,6 +40,8 @@ KERNEL_CLASSES = {
     2: ("sweep_mm", "mfma"),
     3: ("sweep_gemv", "hbm"),
     4: ("csr_spmm", "hbm"),
+    6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile kernel, B stored [n][k]
+    7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile kernel, B stored [k][n]
 }
 
 

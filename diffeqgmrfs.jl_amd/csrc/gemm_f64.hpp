@@ -440,6 +440,13 @@ inline hipError_t gemm_init() {
     return e;
 }
 
+// Which kernel a launch takes (also used for the per-kernel statistics).
+inline bool gemm_uses_big(bool a_t, const GemmArgs& g, int batch) {
+    if (a_t || g.M % GEMM_BIG || g.N % GEMM_BIG || g.K % GEMM_BIG_BK || (g.tri & ~15) || g.stamps) return false;
+    if (g.lower_only && g.M != g.N) return false;
+    return (int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch >= gemm_big_min_tiles();
+}
+
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
 inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, int batch) {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
@@ -448,15 +455,12 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
     GemmArgs gs = g;
     gs.lower_only = tri_grid ? 1 : (g.lower_only ? 2 : 0);   // 2: rectangular grid, tiles above the diagonal exit
     dim3 grid((unsigned)((tri_grid ? sx * (sx + 1) / 2 : sx * sy) * batch)), block(256);
-    if (!a_t && g.M % GEMM_BIG == 0 && g.N % GEMM_BIG == 0 && g.K % GEMM_BIG_BK == 0 && !(g.tri & ~15) && !g.stamps) {
-        const int64_t tiles = (int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch;
-        if (tiles >= gemm_big_min_tiles() && (!g.lower_only || g.M == g.N)) {
-            const int64_t nx = g.N / GEMM_BIG, ny = g.M / GEMM_BIG;
-            dim3 bgrid((unsigned)((g.lower_only ? nx * (nx + 1) / 2 : nx * ny) * batch));
-            if (b_n) hipLaunchKernelGGL(gemm_f64_big<true>, bgrid, block, gemm_big_lds_bytes<true>(), st, g);
-            else hipLaunchKernelGGL(gemm_f64_big<false>, bgrid, block, gemm_big_lds_bytes<false>(), st, g);
-            return hipGetLastError();
-        }
+    if (gemm_uses_big(a_t, g, batch)) {
+        const int64_t nx = g.N / GEMM_BIG, ny = g.M / GEMM_BIG;
+        dim3 bgrid((unsigned)((g.lower_only ? nx * (nx + 1) / 2 : nx * ny) * batch));
+        if (b_n) hipLaunchKernelGGL(gemm_f64_big<true>, bgrid, block, gemm_big_lds_bytes<true>(), st, g);
+        else hipLaunchKernelGGL(gemm_f64_big<false>, bgrid, block, gemm_big_lds_bytes<false>(), st, g);
+        return hipGetLastError();
     }
     const bool wide = (g.K % 32 == 0);
 #define GMRF_GEMM_LAUNCH(AT, BN)                                                                 \

@@ -71,9 +71,11 @@ typedef struct {
     int64_t n, n_blocks, block_size, block_size_padded;
     int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
     /* per-kernel-class accounting, filled when profiling is on (gmrf_bt_set_profiling):
-     * class 0 dense MFMA f64 GEMM, 1 potrf panel step (tile Cholesky + inverse + update),
-     * 2 MFMA sweep (k >= 2 right-hand sides), 3 GEMV sweep (k = 1), 4 CSR SpMM, 5 other.
-     * work = algorithmic flops (classes 0-2) or algorithmic bytes (classes 3-5). */
+     * class 0 dense MFMA f64 GEMM (64 x 64 tile kernel), 1 potrf panel step (tile Cholesky +
+     * inverse + panel + rank-64 update), 2 MFMA sweep (k >= 2 right-hand sides), 3 GEMV sweep
+     * (k = 1), 4 CSR SpMM, 5 other, 6 / 7 the 128 x 128 tile GEMM kernel gemm_f64_big<false> /
+     * <true> whatever the caller (G1, G2, rank-256 trailing updates, doubling assembly).
+     * work = algorithmic flops (classes 0-2, 6, 7) or algorithmic bytes (classes 3-5). */
     double kernel_ms[8];
     double kernel_work[8];
     int64_t kernel_launches[8];
