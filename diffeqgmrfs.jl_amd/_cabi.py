@@ -28,6 +28,7 @@ EXPORTS = [
     "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
+    "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
@@ -111,6 +112,9 @@ def load() -> C.CDLL:
         "gmrf_bt_set_batch": [vp, i64],
         "gmrf_bt_select_problem": [vp, i64],
         "gmrf_csr_create": [i32, vp, i64, i64, vp, vp, vp, i32, i32, P(vp)],
+        "gmrf_bt_export_size": [vp, P(i64)],
+        "gmrf_bt_export_factor": [vp, vp, i64],
+        "gmrf_bt_import_factor": [vp, vp, i64],
         "gmrf_csr_destroy": [vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],

@@ -337,6 +337,21 @@ class TridiagonalCholeskyFactor:
         _cabi.check(self._lib.gmrf_bt_factor_buffer(self._h, kind, C.byref(p), C.byref(nbytes)))
         return int(p.value or 0), int(nbytes.value)
 
+    def export_factor(self) -> np.ndarray:
+        """Flat host image (uint8) of the selected problem's factor: header + L, C, Linv blocks."""
+        nbytes = C.c_int64(0)
+        _cabi.check(self._lib.gmrf_bt_export_size(self._h, C.byref(nbytes)))
+        buf = np.empty(nbytes.value, dtype=np.uint8)
+        _cabi.check(self._lib.gmrf_bt_export_factor(self._h, _cabi.ptr(buf), nbytes.value))
+        return buf
+
+    def import_factor(self, image: np.ndarray):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        _cabi.check(self._lib.gmrf_bt_import_factor(self._h, _cabi.ptr(image), image.size))
+        hdr = image[:64].view(np.int64)
+        self._set_shape(int(hdr[2]), int(hdr[3]))
+        return self
+
     def adopt_shape(self, n: int, n_blocks: int):
         _cabi.check(self._lib.gmrf_bt_adopt_shape(self._h, n, n_blocks))
         self._set_shape(n, n_blocks)

@@ -919,6 +919,73 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
     return GMRF_OK;
 }
 
+// Flat image of one problem's factor: int64 header[8] = {magic, version, n, N, bs, 1, 0, 0}, then
+// column-major bs x bs blocks: L_1..L_N, C_1..C_{N-1}, Linv_1..Linv_N  (SURVEY 8b export/import).
+static const int64_t EXPORT_MAGIC = 0x46524d47;   // "GMRF"
+
+gmrf_status gmrf_bt_export_size(gmrf_handle* h, int64_t* bytes) {
+    if (!h || !bytes) return bad_shape("null pointer");
+    if (h->N <= 0) { g_last_error = "no shape"; return GMRF_ERR_NO_FACTOR; }
+    *bytes = 64 + (int64_t)sizeof(double) * h->bs * h->bs * (3 * h->N - 1);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_export_factor(gmrf_handle* h, void* buf, int64_t bytes) {
+    if (!h || !buf) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "no factor"; return GMRF_ERR_NO_FACTOR; }
+    if (is_device_ptr(buf)) return bad_shape("export buffer must be host memory");
+    int64_t need = 0;
+    GCHK(gmrf_bt_export_size(h, &need));
+    if (bytes < need) return bad_shape("export buffer too small");
+    int64_t* hdr = (int64_t*)buf;
+    hdr[0] = EXPORT_MAGIC; hdr[1] = 1; hdr[2] = h->n; hdr[3] = h->N; hdr[4] = h->bs; hdr[5] = 1; hdr[6] = hdr[7] = 0;
+    double* out = (double*)((char*)buf + 64);
+    const int64_t be = h->bs * h->bs;
+    for (int64_t i = 0; i < h->N; ++i) GCHK(gmrf_bt_get_block(h, GMRF_BLOCK_L, i, out + i * be, h->bs));
+    out += h->N * be;
+    for (int64_t i = 0; i + 1 < h->N; ++i) GCHK(gmrf_bt_get_block(h, GMRF_BLOCK_C, i, out + i * be, h->bs));
+    out += (h->N - 1) * be;
+    for (int64_t i = 0; i < h->N; ++i) GCHK(gmrf_bt_get_block(h, GMRF_BLOCK_LINV, i, out + i * be, h->bs));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes) {
+    if (!h || !buf) return bad_shape("null pointer");
+    if (is_device_ptr(buf)) return bad_shape("import buffer must be host memory");
+    if (bytes < 64) return bad_shape("import buffer too small");
+    const int64_t* hdr = (const int64_t*)buf;
+    if (hdr[0] != EXPORT_MAGIC || hdr[1] != 1 || hdr[5] != 1) return bad_shape("not a factor image");
+    const int64_t n = hdr[2], N = hdr[3], bs = hdr[4];
+    if (N <= 0 || bs <= 0 || n != N * bs) return bad_shape("bad shape in factor image");
+    if (bytes < 64 + (int64_t)sizeof(double) * bs * bs * (3 * N - 1)) return bad_shape("factor image truncated");
+    HIPCHK(hipSetDevice(h->device));
+    if (h->n != n || h->N != N || !h->d_L) {
+        if (h->B != 1) return bad_shape("a batched handle imports into an existing shape only");
+        GCHK(set_shape(h, n, N));
+        GCHK(alloc_factor(h));
+    }
+    const int64_t bsp = h->bsp, be = bs * bs;
+    const int64_t pLX = h->sel * N * bsp * bsp, pCs = h->sel * std::max<int64_t>(N - 1, 1) * bsp * bsp;
+    std::vector<double> tmp((size_t)bsp * bsp);
+    auto put = [&](const double* src, double* dst, bool unit_pad) -> gmrf_status {
+        std::fill(tmp.begin(), tmp.end(), 0.0);
+        for (int64_t r = 0; r < bs; ++r)
+            for (int64_t c = 0; c < bs; ++c) tmp[(size_t)r * bsp + c] = src[c * bs + r];   // column-major -> row-major
+        if (unit_pad)
+            for (int64_t r = bs; r < bsp; ++r) tmp[(size_t)r * bsp + r] = 1.0;
+        HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        return GMRF_OK;
+    };
+    const double* in = (const double*)((const char*)buf + 64);
+    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_L + pLX + i * bsp * bsp, true));
+    in += N * be;
+    for (int64_t i = 0; i + 1 < N; ++i) GCHK(put(in + i * be, h->d_C + pCs + i * bsp * bsp, false));
+    in += (N - 1) * be;
+    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_Linv + pLX + i * bsp * bsp, true));
+    h->factored = true;
+    return GMRF_OK;
+}
+
 gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k, int64_t ld, int32_t mode) {
     if (!h || !b || !y) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "solve before factor"; return GMRF_ERR_NO_FACTOR; }

@@ -302,6 +302,21 @@ def laplace_kappa_grid_variances(nx: int, ny: int, kappa2: float) -> np.ndarray:
     return var.ravel()
 
 
+def ar1_chain_kron_identity(n_blocks: int, bs: int, phi: float = 0.5) -> Workload:
+    """AR(1) chain (x) I_bs: bs independent scalar chains x_t = phi x_{t-1} + eps with a unit-variance
+    start, written in block form D_1..D_{N-1} = (1 + phi^2) I except D_1 = I, D_N = I, B_i = -phi I
+    (SURVEY.md section 8c known-answer case (ii)).  Closed form: L_i = I for i < N,
+    L_N = sqrt(1 - phi^2) I, C_i = -phi I, logdet = bs log(1 - phi^2)."""
+    d = np.full(n_blocks, 1.0 + phi * phi)
+    d[0] = 1.0
+    d[-1] = 1.0
+    T = sp.diags([np.full(n_blocks - 1, -phi), d, np.full(n_blocks - 1, -phi)], [-1, 0, 1])
+    Q = sp.kron(T, sp.identity(bs)).tocsc()
+    Q.sort_indices()
+    rng = np.random.Generator(np.random.PCG64(11))
+    return Workload(f"ar1_{n_blocks}x{bs}", Q, rng.standard_normal(n_blocks * bs), n_blocks, {"phi": phi})
+
+
 def random_block_tridiagonal(n_blocks: int, bs: int, seed: int = 0, density: float = 0.2,
                              shift: float = 2.0) -> Workload:
     """Random sparse SPD block-tridiagonal matrix (strictly block diagonally dominant)."""

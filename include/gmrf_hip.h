@@ -157,6 +157,15 @@ gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out);
 gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* out,
                               int64_t ld);
 
+/* Flat host image of the selected problem's factor (SURVEY 8b `gmrf_bt_export_factor` /
+ * `_import_factor`; what a Julia caller materialises `F.chos` / `F.Cs` from in one call, and the
+ * unit a checkpoint or a host-side broadcast moves).  Layout: int64 header[8] = {0x46524d47,
+ * version 1, n, N, bs, 1, 0, 0}, then column-major bs x bs blocks L_1..L_N, C_1..C_{N-1},
+ * Linv_1..Linv_N.  Import re-creates the device factor (no numeric work). */
+gmrf_status gmrf_bt_export_size(gmrf_handle* h, int64_t* bytes);
+gmrf_status gmrf_bt_export_factor(gmrf_handle* h, void* host_buf, int64_t bytes);
+gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* host_buf, int64_t bytes);
+
 /* Device buffers of the factor, the unit of the RCCL broadcast: kind L / C / LINV gives
  * the base pointer and byte count of that contiguous array of padded row-major blocks. */
 gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr,

@@ -215,6 +215,55 @@ def test_degenerate_shapes(pkg):
     assert rel(pkg.ldiv(F2, w2.rhs), O.ldiv(O.tridiagonal_cholesky(w2.Q, 40), w2.rhs)) < 1e-12
 
 
+def test_export_import_factor_round_trip(pkg):
+    w = pkg.workloads.random_block_tridiagonal(5, 40, seed=9)      # bs 40: padded to 64 inside
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    img = F.export_factor()
+    hdr = img[:64].view(np.int64)
+    assert tuple(hdr[:6]) == (0x46524D47, 1, w.n, w.n_blocks, 40, 1)
+    blocks = img[64:].view(np.float64).reshape(3 * w.n_blocks - 1, 40, 40)
+    assert np.array_equal(blocks[1].T, F.chos[1]) and np.array_equal(blocks[w.n_blocks + 2].T, F.Cs[2])
+    G = pkg.TridiagonalCholeskyFactor().import_factor(img)
+    assert np.array_equal(pkg.ldiv(G, w.rhs), pkg.ldiv(F, w.rhs)) and G.logdet() == F.logdet()
+    assert np.array_equal(G.sample(3, seed=5), F.sample(3, seed=5))
+    with pytest.raises(pkg.GmrfError):
+        pkg.TridiagonalCholeskyFactor().import_factor(img[:-8])
+
+
+def test_known_answer_closed_forms(pkg):
+    """SURVEY 8c known-answer cases on the device: (i) 5-point kappa^2 I + Delta_h grid -- mean
+    against a dense solve, exact marginal variances against the sine-transform closed form;
+    (ii) AR(1) chain (x) I -- identity / -phi I factor blocks and the closed-form log-determinant."""
+    nx, ny, k2 = 64, 24, 0.5
+    w = pkg.workloads.laplace_kappa_grid(nx, ny, k2)
+    F = pkg.tridiagonal_cholesky(w.Q, ny)
+    assert rel(pkg.ldiv(F, w.rhs), np.linalg.solve(w.Q.toarray(), w.rhs)) < 1e-13
+    v = F.marginal_var("exact")
+    assert np.max(np.abs(v - pkg.workloads.laplace_kappa_grid_variances(nx, ny, k2))) < 1e-13
+    phi, N, bs = 0.6, 9, 64
+    w = pkg.workloads.ar1_chain_kron_identity(N, bs, phi)
+    F = pkg.tridiagonal_cholesky(w.Q, N)
+    for i in (0, 4, N - 1):
+        want = np.eye(bs) * (np.sqrt(1.0 - phi * phi) if i == N - 1 else 1.0)
+        assert np.max(np.abs(F.chos[i] - want)) < 1e-15
+    assert np.max(np.abs(F.Cs[3] + phi * np.eye(bs))) < 1e-15
+    assert abs(F.logdet() - bs * np.log(1.0 - phi * phi)) < 1e-12
+
+
+def test_sample_covariance_matches_inverse(pkg):
+    """statistical test of device-Philox samples, k = 16384 at n = 96:
+    every entry of the sample covariance within 6 standard errors of (Q^-1)_ij."""
+    w = pkg.workloads.random_block_tridiagonal(6, 16, seed=21)
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    k = 16384
+    X = F.sample(k, seed=77)                          # n x k, zero mean
+    S = np.linalg.inv(w.Q.toarray())
+    Chat = X @ X.T / k
+    se = np.sqrt((np.outer(np.diag(S), np.diag(S)) + S * S) / k)
+    assert np.max(np.abs(Chat - S) / se) < 6.0
+    assert np.max(np.abs(X.mean(axis=1)) / np.sqrt(np.diag(S) / k)) < 6.0
+
+
 def test_torch_device_resident_io(pkg):
     import torch
     w = pkg.workloads.make("darcy32")

@@ -52,6 +52,22 @@ def test_closed_form_laplace_grid(pkg):
     assert rel(O.ldiv(F, w.rhs), np.linalg.solve(w.Q.toarray(), w.rhs)) < 1e-13
 
 
+def test_closed_form_ar1_chain(pkg):
+    # AR(1) chain (x) I has L_i = I (last: sqrt(1 - phi^2) I) and C_i = -phi I
+    phi, N, bs = 0.6, 7, 5
+    w = pkg.workloads.ar1_chain_kron_identity(N, bs, phi)
+    F = O.tridiagonal_cholesky(w.Q, N)
+    for i in range(N):
+        want = np.eye(bs) * (np.sqrt(1.0 - phi * phi) if i == N - 1 else 1.0)
+        assert np.max(np.abs(F.chos[i] - want)) < 1e-15
+    for c in F.Cs:
+        assert np.max(np.abs(c + phi * np.eye(bs))) < 1e-15
+    assert abs(O.logdet(F) - bs * np.log(1.0 - phi * phi)) < 1e-13
+    # stationary variance of the last state 1/(1 - phi^2), of the first ... the same chain reversed
+    v = O.marginal_variances_exact(F)
+    assert np.allclose(v, np.diag(np.linalg.inv(w.Q.toarray())), rtol=1e-13)
+
+
 def test_degenerate_block_sizes(pkg):
     # bs = 1: scalar tridiagonal (Thomas); N = 1: plain dense Cholesky
     n = 40
