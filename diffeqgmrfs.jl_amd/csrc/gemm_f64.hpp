@@ -17,6 +17,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <array>
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace gmrf {
 
@@ -410,15 +415,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
         }
 }
 
-// Launches with at least this many 128 x 128 tiles take the big kernel (tests move it).
-inline int& gemm_big_min_tiles() {
-    static int v = [] {
-        const char* e = getenv("GMRF_GEMM_BIG_MIN_TILES");   // tuning aid
-        return e ? atoi(e) : 256;
-    }();
-    return v;
-}
-
 template <int BK>
 constexpr size_t gemm_lds_bytes() { return (size_t)4 * 64 * (BK + 4) * sizeof(double); }
 
@@ -440,11 +436,81 @@ inline hipError_t gemm_init() {
     return e;
 }
 
+// Kernel choice.  0 (default): whichever kernel the makespan model below predicts faster;
+// 1: always the 128 x 128 kernel where it applies; 2: never (tests and tools move it).
+inline int& gemm_big_policy() {
+    static int v = [] {
+        const char* e = getenv("GMRF_GEMM_BIG_POLICY");   // tuning aid
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
+
+// Predicted duration (us) of a launch: the tiles of one XCD group, in the order gemm_tile_order
+// issues them, are list-scheduled on the group's workgroup slots (2 per CU).  A tile costs its
+// number of K steps times a per-step time measured on MI355X (tools/gemm_rate.py): 4.0 us per
+// 16-wide step of the 128 x 128 kernel with two workgroups per CU, 2.5 us with one; 2.47 / 1.6 us
+// per 32-wide step of the 64 x 64 kernel.  What decides is quantisation: 21 lower tiles x 32
+// problems are 2 rounds of big tiles (382 us) but 4.9 rounds of small ones (298 us).
+inline double gemm_estimate_us(bool big, const GemmArgs& g, int batch) {
+    const int BT = big ? GEMM_BIG : GEMM_BM;
+    const int BK = big ? GEMM_BIG_BK : (g.K % 32 == 0 ? 32 : 16);
+    const int nx = g.N / BT, ny = g.M / BT;
+    const bool tri_grid = g.lower_only && g.M == g.N;
+    const int tpp = tri_grid ? nx * (nx + 1) / 2 : nx * ny;
+    const int groups = (batch % 8 == 0) ? 8 : 1, nzg = batch / groups;
+    const bool alone = (int64_t)tpp * batch <= 256;            // one workgroup per CU
+    const double step = big ? (alone ? 2.5 : 4.0) : (BK == 32 ? (alone ? 1.6 : 2.47) : (alone ? 0.9 : 1.35));
+    const int slots = 512 / groups;
+    std::vector<double> freeat((size_t)slots, 0.0);              // min-heap of slot release times
+    auto cmp = [](double a, double b) { return a > b; };
+    double makespan = 0.0;
+    auto place = [&](int nk) {
+        std::pop_heap(freeat.begin(), freeat.end(), cmp);
+        const double end = freeat.back() + 1.0 + nk * step;
+        freeat.back() = end;
+        std::push_heap(freeat.begin(), freeat.end(), cmp);
+        makespan = std::max(makespan, end);
+    };
+    if (tri_grid) {
+        for (int q = 0; q < tpp * nzg; ++q) place(g.K / BK);
+    } else {
+        const bool cls_n = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) || !(g.tri & (TRI_A_LOWER | TRI_A_UPPER));
+        const bool desc = cls_n ? (g.tri & TRI_B_UPPER) != 0 : (g.tri & TRI_A_LOWER) != 0;
+        const int ncls = cls_n ? nx : ny, other = cls_n ? ny : nx;
+        for (int c0 = 0; c0 < ncls; ++c0) {
+            const int c = desc ? ncls - 1 - c0 : c0;
+            for (int o = 0; o < other; ++o) {
+                const int bn = cls_n ? c : o, bm = cls_n ? o : c;
+                int kb = 0, ke = g.K;
+                if (g.tri & TRI_A_LOWER) ke = std::min(ke, (bm + 1) * BT);
+                if (g.tri & TRI_A_UPPER) kb = std::max(kb, bm * BT);
+                if (g.tri & TRI_B_LOWER) kb = std::max(kb, bn * BT);
+                if (g.tri & TRI_B_UPPER) ke = std::min(ke, (bn + 1) * BT);
+                const int nk = (g.lower_only && bn > bm) ? 0 : std::max(0, ke - kb) / BK;
+                for (int z = 0; z < nzg; ++z) place(nk);
+            }
+        }
+    }
+    return makespan;
+}
+
 // Which kernel a launch takes (also used for the per-kernel statistics).
 inline bool gemm_uses_big(bool a_t, const GemmArgs& g, int batch) {
     if (a_t || g.M % GEMM_BIG || g.N % GEMM_BIG || g.K % GEMM_BIG_BK || (g.tri & ~15) || g.stamps) return false;
     if (g.lower_only && g.M != g.N) return false;
-    return (int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch >= gemm_big_min_tiles();
+    const int policy = gemm_big_policy();
+    if (policy == 1) return true;
+    if (policy == 2) return false;
+    if ((int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch < 64) return false;
+    // the choice depends on the shape only: remember it (launchers run on several host threads)
+    static std::mutex mu;
+    static std::map<std::array<int, 6>, bool> memo;
+    const std::array<int, 6> key = {g.M, g.N, g.K, g.tri, g.lower_only, batch};
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(key);
+    if (it == memo.end()) it = memo.emplace(key, gemm_estimate_us(true, g, batch) < gemm_estimate_us(false, g, batch)).first;
+    return it->second;
 }
 
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.

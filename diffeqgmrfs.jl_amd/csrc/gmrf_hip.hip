@@ -1397,11 +1397,11 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     HIPCHK(hipMemset(dst, 0, 16));
     g.stamps = force_big ? nullptr : dst;
     HIPCHK(gemm_init());
-    const int saved = gemm_big_min_tiles();
-    gemm_big_min_tiles() = force_big ? 1 : (1 << 30);
+    const int saved = gemm_big_policy();
+    gemm_big_policy() = force_big ? 1 : 2;
     // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
     hipError_t le = launch_gemm(nullptr, transA != 0, transB == 0, g, 1);
-    gemm_big_min_tiles() = saved;
+    gemm_big_policy() = saved;
     HIPCHK(le);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));
@@ -1435,8 +1435,8 @@ gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K,
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
     g.alpha = 1.0; g.beta = 0.0; g.stamps = nullptr;
     HIPCHK(gemm_init());
-    const int saved = gemm_big_min_tiles();
-    gemm_big_min_tiles() = big ? 1 : (1 << 30);
+    const int saved = gemm_big_policy();
+    gemm_big_policy() = big == 1 ? 1 : (big == 0 ? 2 : 0);       // big = 2: the model's choice
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     hipError_t le = hipSuccess;
@@ -1444,7 +1444,7 @@ gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K,
     HIPCHK(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps && le == hipSuccess; ++r) le = launch_gemm(nullptr, false, transB == 0, g, batch);
     HIPCHK(hipEventRecord(e1, nullptr));
-    gemm_big_min_tiles() = saved;
+    gemm_big_policy() = saved;
     HIPCHK(le);
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;

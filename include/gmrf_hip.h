@@ -229,8 +229,8 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
                            int32_t transB, int32_t tri_flags, int32_t lower_only,
                            double alpha, const double* A, int64_t lda, const double* B,
                            int64_t ldb, double beta, double* C, int64_t ldc);
-/* Device-resident timing of one GEMM shape (zero operands): batch problems, big = 1 takes the
- * 128 x 128 kernel, 0 the 64 x 64 one. */
+/* Device-resident timing of one GEMM shape (random operands): batch problems, big = 1 takes the
+ * 128 x 128 kernel, 0 the 64 x 64 one, 2 the launcher's own choice. */
 gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K, int32_t transB,
                                 int32_t tri_flags, int32_t lower_only, int32_t batch,
                                 int32_t big, int32_t reps, double* ms_per_launch);
