@@ -399,8 +399,10 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // Batches: two-level blocking.  Inside a 256-column panel the 64-column steps update only the
     // panel's own columns; the rest of the trailing block gets ONE rank-256 update per panel from
     // the GEMM kernel (a quarter of the read-modify-write traffic of four rank-64 updates, and
-    // one rounding at |S| instead of four).  A lone problem keeps the fused one-launch step.
-    const bool fused = (h->B == 1 && !h->split_step);
+    // one rounding at |S| instead of four).  A lone problem with blocks up to 1024 keeps the fused
+    // one-launch step (43 ms against 48 ms on darcy256); beyond that the fused step's redundant
+    // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
+    const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
     const int pw = (!fused && nt >= 8) ? 4 : nt;           // panel width in tiles
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
