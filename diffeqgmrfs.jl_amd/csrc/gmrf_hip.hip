@@ -108,6 +108,10 @@ struct gmrf_handle {
     bool analyzed = false;
     int64_t cmin = 0, rmax = 0;        // lower blocks B_i are zero left of column cmin and below row rmax (64-aligned)
     bool c_dirty = false;              // C must be re-zeroed (new pattern)
+    int* d_lo_rowptr = nullptr;        // [N][bsp + 1] row-wise view of the lower blocks' entry lists
+    int64_t lo_row_max = 0;            // most entries in one row of a lower block
+    bool sparse_b = false;             // lower blocks are sparse enough for C = B X^T by spmm_bxt
+    bool dense_g1 = false;             // force the dense GEMM for C = B X^T (comparison)
     // factor storage
     double *d_L = nullptr, *d_C = nullptr, *d_Linv = nullptr;
     bool external_storage = false;
@@ -300,7 +304,9 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
         h->diag_first[i] = (int64_t)keys.size(); h->diag_count[i] = (int64_t)dg[i].size();
         for (auto& e : dg[i]) { keys.push_back(e.key); src.push_back(e.src); }
         h->low_first[i] = (int64_t)keys.size(); h->low_count[i] = (int64_t)lo[i].size();
-        for (auto& e : lo[i]) { keys.push_back(e.key); src.push_back(e.src); }
+        std::vector<HostEntry> byrow(lo[i]);           // row by row (key = row << 32 | col): spmm_bxt walks rows
+        std::stable_sort(byrow.begin(), byrow.end(), [](const HostEntry& x, const HostEntry& y) { return x.key < y.key; });
+        for (auto& e : byrow) { keys.push_back(e.key); src.push_back(e.src); }
     }
     // zero structure shared by all lower blocks: first non-zero column, last non-zero row
     int64_t cmin = h->bsp, rmax = 0;
@@ -327,6 +333,28 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
     if (!keys.empty()) {
         HIPCHK(hipMemcpy(h->d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    }
+    // row pointers into the lower blocks' entry lists for the sparse C = B X^T (spmm_bxt)
+    free_dev(h->d_lo_rowptr);
+    h->d_lo_rowptr = nullptr;
+    {
+        const int64_t bsp = h->bsp;
+        std::vector<int> rowptr((size_t)(N * (bsp + 1)), 0);
+        int64_t max_row = 0;
+        for (int64_t i = 1; i < N; ++i) {
+            int* rp = rowptr.data() + i * (bsp + 1);
+            const int64_t first = h->low_first[i], cnt = h->low_count[i];
+            for (int64_t k = 0; k < cnt; ++k) rp[(keys[first + k] >> 32) + 1]++;
+            for (int64_t r = 0; r < bsp; ++r) max_row = std::max<int64_t>(max_row, rp[r + 1]);
+            rp[0] = (int)first;
+            for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
+        }
+        HIPCHK(hipMalloc(&h->d_lo_rowptr, rowptr.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(h->d_lo_rowptr, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        // dense GEMM: 2 bs^3 flop at ~50 TF/s; sparse: one pass over C.  Rows of up to 32 entries go
+        // the sparse way, anything denser keeps the GEMM.
+        h->lo_row_max = max_row;
+        h->sparse_b = keys.size() < ((size_t)1 << 31) && max_row <= 32 && h->bsp >= 64;
     }
     h->analyzed = true;
     h->factored = false;
@@ -478,18 +506,35 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
         if (i > 0) {
             double* C = h->d_C + (i - 1) * bstride;
             const double* Xp = h->d_Linv + (i - 1) * bstride;
-            HIPCHK(hipMemsetAsync(h->d_B, 0, blk_bytes, h->stream));
-            if (h->low_count[i] > 0) {
-                hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256), nb), dim3(256), 0,
-                                   h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld,
-                                   h->n_entries, bstride);
-                HIPCHK(hipGetLastError());
+            const bool sparse_g1 = h->sparse_b && !h->dense_g1;
+            if (!sparse_g1) {          // dense image of B for the GEMM route
+                HIPCHK(hipMemsetAsync(h->d_B, 0, blk_bytes, h->stream));
+                if (h->low_count[i] > 0) {
+                    hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256), nb), dim3(256), 0,
+                                       h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld,
+                                       h->n_entries, bstride);
+                    HIPCHK(hipGetLastError());
+                }
             }
             // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74).  B is zero left of column
             // cmin and below row rmax, hence C is zero there too and only the rest is computed.
             const int cm = (int)h->cmin, rm = (int)h->rmax;
-            GCHK(gemm(h, false, false, rm, bsp - cm, bsp - cm, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
-                      Xp + (int64_t)cm * ld + cm, ld, 0.0, C + cm, ld, bstride, pLX, pC));
+            if (sparse_g1) {
+                BxtArgs ba;
+                ba.rowptr = h->d_lo_rowptr + i * (h->bsp + 1); ba.keys = h->d_keys;
+                ba.vals = h->d_vals; ba.n_entries = h->n_entries;
+                ba.X = Xp; ba.C = C; ba.ld = ld; ba.pX = pLX; ba.pC = pC; ba.cm = cm; ba.rm = rm;
+                const int W = bsp - cm;
+                const dim3 grid((unsigned)(W / 64), (unsigned)((rm + 255) / 256), nb);
+                ProfScope ps(h, 5, 8.0 * ((double)rm * W + 0.5 * (double)W * W) * (double)h->B);
+                if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
+                else if (h->lo_row_max <= 16) hipLaunchKernelGGL(spmm_bxt<16>, grid, dim3(256), 0, h->stream, ba);
+                else hipLaunchKernelGGL(spmm_bxt<32>, grid, dim3(256), 0, h->stream, ba);
+                HIPCHK(hipGetLastError());
+            } else {
+                GCHK(gemm(h, false, false, rm, bsp - cm, bsp - cm, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
+                          Xp + (int64_t)cm * ld + cm, ld, 0.0, C + cm, ld, bstride, pLX, pC));
+            }
             // S = D - C C^T             (src/tridiagonal_cholesky.jl:77)
             GCHK(gemm(h, false, false, rm, rm, bsp - cm, 0, 1, -1.0, C + cm, ld, C + cm, ld, 1.0, h->d_S, ld, pC, pC,
                       bstride));
@@ -701,6 +746,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
+    free_dev(h->d_lo_rowptr);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
     free_dev(h->d_info); free_dev(h->d_logdet);
@@ -748,6 +794,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (!h) return bad_shape("null handle");
     if (((eager & 2) != 0) != h->split_step) { destroy_graphs(h); h->split_step = (eager & 2) != 0; }
     if (((eager & 4) != 0) != h->sweep_no_gemm) { destroy_graphs(h); h->sweep_no_gemm = (eager & 4) != 0; }
+    if (((eager & 8) != 0) != h->dense_g1) { destroy_graphs(h); h->dense_g1 = (eager & 8) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }

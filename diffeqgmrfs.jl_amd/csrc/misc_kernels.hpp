@@ -93,6 +93,79 @@ __global__ void fill_normals_panel(double* __restrict__ P, int64_t n_pad, int bs
     P[(int64_t)blockIdx.y * kp * n_pad + idx] = v;
 }
 
+// ------------------------------------------------------------------------------- K7
+// C = B * X^T with the lower block B kept SPARSE (src/tridiagonal_cholesky.jl:74 forms
+// `A[block_idcs, prev_block_idcs] / L'`; a FEM / finite-difference coupling block has a handful of
+// entries per row -- darcy256: 3 574 in 1024 x 1024 -- so the product is 2 nnz bs flop instead of
+// 2 bs^3 and the kernel is bound by writing C):
+//   C[r][c] = sum_{(r,j) in B} B[r][j] X[c][j]          X lower triangular, zeros stored above
+// A thread owns one row r of B: it loads the row's (at most KM) entries once into registers, then
+// walks 64 columns c; for entry t the 64 lanes of a wave (consecutive r) read X[c][j_t(r)], which
+// for a stencil coupling are consecutive addresses of one row of X.  No LDS, every load of the c
+// loop is independent.  The lower blocks' entry lists are stored row by row (rowptr).
+// grid ((bsp - cm) / 64, ceil(rm / 256), problems).
+struct BxtArgs {
+    const int* rowptr;        // [bsp + 1], local row -> range in keys / vals
+    const uint64_t* keys;     // row << 32 | col
+    const double* vals;       // [problems][n_entries]
+    int64_t n_entries;
+    const double* X;          // previous block's inverse
+    double* C;
+    int64_t ld, pX, pC;
+    int cm, rm;
+};
+
+template <int KM>
+__global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
+    const int r = (int)blockIdx.y * 256 + (int)threadIdx.x;
+    const int c0 = a.cm + (int)blockIdx.x * 64;
+    const double* __restrict__ X = a.X + (int64_t)blockIdx.z * a.pX;
+    double* __restrict__ C = a.C + (int64_t)blockIdx.z * a.pC;
+    const double* __restrict__ vals = a.vals + (int64_t)blockIdx.z * a.n_entries;
+    int k0 = 0, len = 0;
+    if (r < a.rm) { k0 = a.rowptr[r]; len = a.rowptr[r + 1] - k0; }
+    int jt[KM];
+    double vt[KM];
+#pragma unroll
+    for (int t = 0; t < KM; ++t) {
+        const bool ok = t < len;
+        jt[t] = ok ? (int)(a.keys[k0 + t] & 0xffffffffu) : 0;
+        vt[t] = ok ? vals[k0 + t] : 0.0;
+    }
+    int lm = len;                                  // longest row of the wave bounds the entry loop
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) lm = max(lm, __shfl_xor(lm, off));
+    lm = __builtin_amdgcn_readfirstlane(lm);
+    // 16 columns at a time; the 256 x 16 results turn through LDS so that they leave as full
+    // 128-byte lines (stores of 8 or 16 bytes a line apart cost one L2 transaction each and made
+    // this kernel slower than the dense GEMM it replaces)
+    __shared__ double ls[256 * 17];
+    const int tid = (int)threadIdx.x;
+    const int wr = tid >> 4, wc = tid & 15;        // write-out: 16 lanes per row, 16 rows per pass
+    const int rbase = (int)blockIdx.y * 256;
+    for (int c = c0; c < c0 + 64; c += 16) {
+        const double* xr = X + (int64_t)c * a.ld;
+        double acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+#pragma unroll
+        for (int t = 0; t < KM; ++t)
+            if (t < lm) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc[u] = fma(vt[t], xr[(int64_t)u * a.ld + jt[t]], acc[u]);
+            }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) ls[tid * 17 + u] = acc[u];
+        __syncthreads();
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int rr = p * 16 + wr;
+            if (rbase + rr < a.rm) C[(int64_t)(rbase + rr) * a.ld + c + wc] = ls[rr * 17 + wc];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------- K6
 // CSR SpMV/SpMM  Y = S X, X and Y stored one right-hand side after the other (strides
 // ldx/ldy).  Replaces SparseArrays' `Q * x` (scripts/solve_burger.jl:157-158,166,177 and the

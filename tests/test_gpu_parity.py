@@ -215,6 +215,28 @@ def test_degenerate_shapes(pkg):
     assert rel(pkg.ldiv(F2, w2.rhs), O.ldiv(O.tridiagonal_cholesky(w2.Q, 40), w2.rhs)) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["darcy64", "burgers64x8"])
+def test_sparse_and_dense_coupling_product_agree(pkg, name):
+    """C = B X^T: the sparse kernel (spmm_bxt, default for FEM coupling blocks) against the dense
+    GEMM route (set_eager bit 3), and both against the oracle."""
+    w = pkg.workloads.make(name)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Fs = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Fd = pkg.TridiagonalCholeskyFactor()
+    Fd.set_eager(8)
+    Fd.factor(w.Q, w.n_blocks)
+    for i in (0, w.n_blocks // 2, w.n_blocks - 2):
+        scale = np.max(np.abs(Fo.Cs[i]))
+        assert np.max(np.abs(Fs.Cs[i] - Fo.Cs[i])) / scale < TOL_FACTOR
+        assert np.max(np.abs(Fd.Cs[i] - Fo.Cs[i])) / scale < TOL_FACTOR
+        assert np.max(np.abs(Fd.Cs[i] - Fs.Cs[i])) / scale < 1e-13
+    assert rel(pkg.ldiv(Fs, w.rhs), pkg.ldiv(Fd, w.rhs)) < solve_tol(w)
+    # a block-dense coupling (more than 32 entries per row) takes the GEMM route by itself
+    wd = pkg.workloads.random_block_tridiagonal(3, 128, seed=2, density=0.6)
+    F = pkg.tridiagonal_cholesky(wd.Q, wd.n_blocks)
+    assert rel(pkg.ldiv(F, wd.rhs), O.ldiv(O.tridiagonal_cholesky(wd.Q, wd.n_blocks), wd.rhs)) < 1e-12
+
+
 def test_export_import_factor_round_trip(pkg):
     w = pkg.workloads.random_block_tridiagonal(5, 40, seed=9)      # bs 40: padded to 64 inside
     F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
