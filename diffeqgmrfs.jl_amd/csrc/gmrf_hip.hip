@@ -262,6 +262,7 @@ static gmrf_status set_shape(gmrf_handle* h, int64_t n, int64_t N) {
     }
     h->n = n; h->N = N; h->bs = bs;
     h->bsp = 64 * next_pow2((bs + 63) / 64);
+    if (!h->analyzed) { h->cmin = 0; h->rmax = h->bsp; }      // no pattern known (adopted / imported factor): all of C
     h->n_pad = h->bsp * N;
     h->stats.n = n; h->stats.n_blocks = N; h->stats.block_size = bs; h->stats.block_size_padded = h->bsp;
     h->stats.factor_flops = ((double)N * bs * bs * bs / 3.0 + (double)(N - 1) * 2.0 * bs * bs * bs) * (double)h->B;
@@ -604,57 +605,60 @@ static double sweep_bytes(const gmrf_handle* h, int64_t k) {
     return 8.0 * (N * bs * (bs + 1) / 2.0 + (N - 1) * bs * bs) + 16.0 * (double)h->n * (double)k;
 }
 
-static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, const double* Pin, double* Yout) {
+static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double* Pin, double* Yout) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp, npad = h->n_pad;
     const int64_t N = h->N;
     SweepArgs s;
-    s.ld = ld; s.bs = bsp;
+    s.ld = ld;
     const int nprob = (int)h->B;
-    const int64_t pPanel = (int64_t)kp * npad, pT = (int64_t)kp * bsp;
+    const int64_t pPanel = (int64_t)kp * npad;
     const int64_t pLX = bstride * N, pCm = bstride * std::max<int64_t>(N - 1, 1);
+    // C_i is zero left of column cmin and below row rmax (symbolic phase): only that sub-block is
+    // applied.  forward: rows m < rm take sums over k >= cm; backward (C^T): outputs k >= cm take
+    // sums over m < rm.
+    const int cm = (int)h->cmin, rm = (int)h->rmax, wc = bsp - cm;
     // class 3 (k = 1): algorithmic bytes of the block read; class 2: flops of the panel product
     const int pclass = (kp == 1) ? 3 : 2;
+    const double blk_bytes_c = ((kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp) * nprob;
+    const double blk_bytes_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
     // 64-multiples of right-hand sides go through the GEMM kernel (panel = the [m][k] operand) when
     // the batch gives it enough 64 x 64 tiles; a lone problem stays on sweep_mm (256 workgroups)
     const bool via_gemm = (kp % 64 == 0) && !h->sweep_no_gemm && (int64_t)nprob * (bsp / 64) * (kp / 64) >= 128;
-    const double blk_bytes_c = ((kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp) * nprob;
-    const double blk_bytes_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
     for (int64_t step = 0; step < N; ++step) {
         const int64_t i = backward ? (N - 1 - step) : step;
-        const double* rhs = Pin + i * bsp;
+        double* rhs = Pin + i * bsp;               // the input panel is consumed: P_i becomes P_i - C y_prev
         if (step > 0) {
-            // T = P_i - C y_prev      forward: C_{i-1} y_{i-1};  backward: C_i^T x_{i+1}
+            // forward: P_i -= C_{i-1} y_{i-1};  backward: P_i -= C_i^T x_{i+1}      (in place)
             const int64_t ci = backward ? i : (i - 1);
             const int64_t prev = backward ? (i + 1) : (i - 1);
-            s.Mat = h->d_C + ci * bstride;
-            s.Xin = Yout + prev * bsp; s.ldx = npad;
-            s.Bin = rhs; s.ldb = npad;
-            s.Out = h->d_Tp; s.ldo = bsp;
-            s.sub = 1;
-            s.pMat = pCm; s.pXin = pPanel; s.pBin = pPanel; s.pOut = pT;
+            const double* Cs = h->d_C + ci * bstride + cm;            // columns cm .. of rows 0 .. rm
+            const double* xin = Yout + prev * bsp + (backward ? 0 : cm);
+            double* out = rhs + (backward ? cm : 0);
+            const int rows = backward ? wc : rm, kdim = backward ? rm : wc;
             if (via_gemm) {
                 // T[r][m] = P[r][m] - sum_k y[r][k] c(k,m): the panel is the [m][k] operand, the block the other
-                GCHK(gemm(h, false, backward, kp, bsp, bsp, 0, 0, -1.0, s.Xin, npad, s.Mat, ld, 1.0, h->d_Tp, bsp, pPanel,
-                          pCm, pT, 1, 0, 0, 0, rhs, npad, pPanel, pclass, blk_bytes_c));
+                GCHK(gemm(h, false, backward, kp, rows, kdim, 0, 0, -1.0, xin, npad, Cs, ld, 1.0, out, npad, pPanel, pCm,
+                          pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_c));
             } else {
+                s.Mat = Cs; s.Xin = xin; s.ldx = npad; s.Bin = out; s.ldb = npad; s.Out = out; s.ldo = npad;
+                s.rows = rows; s.kdim = kdim; s.sub = 1;
+                s.pMat = pCm; s.pXin = pPanel; s.pBin = pPanel; s.pOut = pPanel;
                 ProfScope ps(h, pclass, blk_bytes_c);
                 HIPCHK(launch_sweep(h->stream, backward, false, kp, s, nprob));
             }
-            rhs = h->d_Tp;
         }
         // y_i = Linv_i T   /   x_i = Linv_i^T T
-        s.Mat = h->d_Linv + i * bstride;
-        s.Xin = rhs; s.ldx = (step > 0) ? bsp : npad;
-        s.Bin = nullptr; s.ldb = 0;
-        s.Out = Yout + i * bsp; s.ldo = npad;
-        s.sub = 0;
-        s.pMat = pLX; s.pXin = (step > 0) ? pT : pPanel; s.pBin = 0; s.pOut = pPanel;
+        const double* X = h->d_Linv + i * bstride;
+        double* yout = Yout + i * bsp;
         if (via_gemm) {
             // forward: Linv stored [m][k], zero for k > m; backward: Linv^T, stored [k][m], zero for k < m
-            GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, s.Xin, s.ldx, s.Mat,
-                      ld, 0.0, s.Out, npad, s.pXin, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_t));
+            GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs, npad, X, ld, 0.0,
+                      yout, npad, pPanel, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_t));
         } else {
+            s.Mat = X; s.Xin = rhs; s.ldx = npad; s.Bin = nullptr; s.ldb = 0; s.Out = yout; s.ldo = npad;
+            s.rows = bsp; s.kdim = bsp; s.sub = 0;
+            s.pMat = pLX; s.pXin = pPanel; s.pBin = 0; s.pOut = pPanel;
             ProfScope ps(h, pclass, blk_bytes_t);
             HIPCHK(launch_sweep(h->stream, backward, true, kp, s, nprob));
         }

@@ -20,11 +20,12 @@
 namespace gmrf {
 
 struct SweepArgs {
-    const double* Mat; int64_t ld;      // bs x bs row-major block (C_i or Linv_i)
+    const double* Mat; int64_t ld;      // row-major block (C_i, Linv_i) or a sub-block of it
     const double* Xin; int64_t ldx;     // input vectors, one per rhs, stride ldx between rhs
     const double* Bin; int64_t ldb;     // optional addend (Out = Bin - Mat*X when sub != 0)
-    double* Out; int64_t ldo;
-    int bs;
+    double* Out; int64_t ldo;           // Out may be Bin (in place): an output reads only its own addend
+    int rows;                           // outputs per right-hand side
+    int kdim;                           // length of the sums (TRI: rows == kdim)
     int sub;
     int64_t pMat, pXin, pBin, pOut;     // per-problem strides (blockIdx.z)
 };
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
     const int m0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    int kb = 0, ke = s.bs;
+    int kb = 0, ke = s.kdim;
     if (TRI) {
         if (!TRANS) ke = m0 + 16; else kb = m0;
     }
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
     sweep_select_problem(s, blockIdx.z);
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= s.bs) return;
-    const int ke = TRI ? (row + 1) : s.bs;
+    if (row >= s.rows) return;
+    const int ke = TRI ? (row + 1) : s.kdim;
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
     const double* __restrict__ x = s.Xin;
     double sum0 = 0.0, sum1 = 0.0;
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
     const double* __restrict__ mp = s.Mat + col0 + c;
     double sum = 0.0;
 #pragma unroll 16
-    for (int k = kb + gidx; k < s.bs; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
+    for (int k = kb + gidx; k < s.kdim; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
     __shared__ double red[16][17];
     red[gidx][c] = sum;
     __syncthreads();
@@ -196,16 +197,16 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
 inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s, int nprob) {
     if (kp == 1) {
         if (!trans) {
-            dim3 grid((s.bs + 3) / 4, 1, nprob), block(256);
+            dim3 grid((s.rows + 3) / 4, 1, nprob), block(256);
             if (tri) hipLaunchKernelGGL((sweep_gemv_n<true>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_n<false>), grid, block, 0, st, s);
         } else {
-            dim3 grid(s.bs / 16, 1, nprob), block(256);
+            dim3 grid(s.rows / 16, 1, nprob), block(256);
             if (tri) hipLaunchKernelGGL((sweep_gemv_t<true>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_t<false>), grid, block, 0, st, s);
         }
     } else {
-        dim3 grid(s.bs / 16, kp / 16, nprob), block(256);
+        dim3 grid(s.rows / 16, kp / 16, nprob), block(256);
         if (!trans && !tri) hipLaunchKernelGGL((sweep_mm<false, false>), grid, block, 0, st, s);
         else if (!trans && tri) hipLaunchKernelGGL((sweep_mm<false, true>), grid, block, 0, st, s);
         else if (trans && !tri) hipLaunchKernelGGL((sweep_mm<true, false>), grid, block, 0, st, s);
