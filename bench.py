@@ -34,14 +34,17 @@ sys.path.insert(0, ROOT)
 PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X datasheet fp64 matrix peak; 77.7 measured (tools/mb2.hip)
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3-6.5 TB/s achievable)
 
-KERNEL_CLASSES = {
-    0: ("gemm_f64_mfma", "mfma"),
-    1: ("potrf_step", "mfma"),
+KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_stats)
+    0: ("gemm_f64_mfma", "mfma"),           # 64 x 64 tile GEMM
+    6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
+    7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
+    1: ("potrf_step<false>", "mfma"),       # tile Cholesky + inverse (latency-bound, B workgroups)
+    8: ("potrf_panel", "mfma"),
+    9: ("potrf_update", "mfma"),
     2: ("sweep_mm", "mfma"),
     3: ("sweep_gemv", "hbm"),
+    10: ("spmm_bxt", "hbm"),
     4: ("csr_spmm", "hbm"),
-    6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile kernel, B stored [n][k]
-    7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile kernel, B stored [k][n]
 }
 
 

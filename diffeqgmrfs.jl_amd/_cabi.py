@@ -45,7 +45,7 @@ class Stats(C.Structure):
         ("factor_flops", C.c_double), ("sweep_bytes", C.c_double), ("sweep_ms", C.c_double),
         ("n", C.c_int64), ("n_blocks", C.c_int64), ("block_size", C.c_int64),
         ("block_size_padded", C.c_int64), ("factor_bytes", C.c_int64),
-        ("kernel_ms", C.c_double * 8), ("kernel_work", C.c_double * 8), ("kernel_launches", C.c_int64 * 8),
+        ("kernel_ms", C.c_double * 16), ("kernel_work", C.c_double * 16), ("kernel_launches", C.c_int64 * 16),
     ]
 
 

@@ -443,28 +443,36 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         sa.cend = cend;
         int utiles = 0;
         for (int c = j + 1; c < cend; ++c) utiles += nt - c;
-        const double rem = 64.0 * m;
-        {
-            ProfScope ps(h, 1, (64.0 * 64.0 * 64.0 / 3.0 + rem * 64.0 * 64.0 + 2.0 * 64.0 * 64.0 * 64.0 * utiles) * (double)h->B);
-            if (fused || m == 0) {
-                hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
-                                   h->stream, sa);
-            } else {
-                // factor the B diagonal tiles once, then panel and update without the redundant tile work
+        const double rem = 64.0 * m, nb = (double)h->B;
+        const double f_tile = 64.0 * 64.0 * 64.0 / 3.0 * nb, f_panel = rem * 64.0 * 64.0 * nb;
+        const double f_upd = 2.0 * 64.0 * 64.0 * 64.0 * utiles * nb;
+        if (fused || m == 0) {
+            ProfScope ps(h, 1, f_tile + f_panel + f_upd);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
+                               h->stream, sa);
+        } else {
+            // factor the B diagonal tiles once, then panel and update without the redundant tile work
+            {
+                ProfScope ps(h, 1, f_tile);
                 hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
-                hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
-                if (utiles > 0)
-                    hipLaunchKernelGGL(potrf_update, dim3(utiles, (unsigned)h->B), dim3(256), 0, h->stream, sa);
             }
-            HIPCHK(hipGetLastError());
+            {
+                ProfScope ps(h, 8, f_panel);
+                hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+            }
+            if (utiles > 0) {
+                ProfScope ps(h, 9, f_upd);
+                hipLaunchKernelGGL(potrf_update, dim3(utiles, (unsigned)h->B), dim3(256), 0, h->stream, sa);
+            }
         }
+        HIPCHK(hipGetLastError());
         if (j + 1 == cend && cend < nt) {
             // S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the finished panel P
             const int j0 = cend - pw, mr = nt - cend;
             const double* Lp = L + (int64_t)cend * 64 * ld + (int64_t)j0 * 64;
             double* Sr = S + (int64_t)cend * 64 * ld + (int64_t)cend * 64;
             GCHK(gemm(h, false, false, mr * 64, mr * 64, pw * 64, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, Sr, ld, sa.pLX, sa.pLX,
-                      sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 1, 2.0 * 64.0 * 64.0 * (pw * 64.0) * (mr * (mr + 1) / 2) * (double)h->B));
+                      sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * 64.0 * 64.0 * (pw * 64.0) * (mr * (mr + 1) / 2) * (double)h->B));
         }
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
@@ -527,7 +535,7 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 ba.X = Xp; ba.C = C; ba.ld = ld; ba.pX = pLX; ba.pC = pC; ba.cm = cm; ba.rm = rm;
                 const int W = bsp - cm;
                 const dim3 grid((unsigned)(W / 64), (unsigned)((rm + 255) / 256), nb);
-                ProfScope ps(h, 5, 8.0 * ((double)rm * W + 0.5 * (double)W * W) * (double)h->B);
+                ProfScope ps(h, 10, 8.0 * ((double)rm * W + 0.5 * (double)W * W) * (double)h->B);
                 if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
                 else if (h->lo_row_max <= 16) hipLaunchKernelGGL(spmm_bxt<16>, grid, dim3(256), 0, h->stream, ba);
                 else hipLaunchKernelGGL(spmm_bxt<32>, grid, dim3(256), 0, h->stream, ba);
@@ -639,7 +647,7 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
             if (via_gemm) {
                 // T[r][m] = P[r][m] - sum_k y[r][k] c(k,m): the panel is the [m][k] operand, the block the other
                 GCHK(gemm(h, false, backward, kp, rows, kdim, 0, 0, -1.0, xin, npad, Cs, ld, 1.0, out, npad, pPanel, pCm,
-                          pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_c));
+                          pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
             } else {
                 s.Mat = Cs; s.Xin = xin; s.ldx = npad; s.Bin = out; s.ldb = npad; s.Out = out; s.ldo = npad;
                 s.rows = rows; s.kdim = kdim; s.sub = 1;
@@ -654,7 +662,7 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
         if (via_gemm) {
             // forward: Linv stored [m][k], zero for k > m; backward: Linv^T, stored [k][m], zero for k < m
             GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs, npad, X, ld, 0.0,
-                      yout, npad, pPanel, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, pclass, blk_bytes_t));
+                      yout, npad, pPanel, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
         } else {
             s.Mat = X; s.Xin = rhs; s.ldx = npad; s.Bin = nullptr; s.ldb = 0; s.Out = yout; s.ldo = npad;
             s.rows = bsp; s.kdim = bsp; s.sub = 0;
@@ -790,7 +798,7 @@ gmrf_status gmrf_bt_select_problem(gmrf_handle* h, int64_t p) {
 gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
     if (!h) return bad_shape("null handle");
     h->profiling = level;
-    for (int i = 0; i < 8; ++i) { h->stats.kernel_ms[i] = h->stats.kernel_work[i] = 0; h->stats.kernel_launches[i] = 0; }
+    for (int i = 0; i < GMRF_KERNEL_CLASSES; ++i) { h->stats.kernel_ms[i] = h->stats.kernel_work[i] = 0; h->stats.kernel_launches[i] = 0; }
     return GMRF_OK;
 }
 

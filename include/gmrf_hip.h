@@ -70,15 +70,20 @@ typedef struct {
     double sweep_ms;           /* duration of the last single sweep                         */
     int64_t n, n_blocks, block_size, block_size_padded;
     int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
-    /* per-kernel-class accounting, filled when profiling is on (gmrf_bt_set_profiling):
-     * class 0 dense MFMA f64 GEMM (64 x 64 tile kernel), 1 potrf panel step (tile Cholesky +
-     * inverse + panel + rank-64 update), 2 MFMA sweep (k >= 2 right-hand sides), 3 GEMV sweep
-     * (k = 1), 4 CSR SpMM, 5 other, 6 / 7 the 128 x 128 tile GEMM kernel gemm_f64_big<false> /
-     * <true> whatever the caller (G1, G2, rank-256 trailing updates, doubling assembly).
-     * work = algorithmic flops (classes 0-2, 6, 7) or algorithmic bytes (classes 3-5). */
-    double kernel_ms[8];
-    double kernel_work[8];
-    int64_t kernel_launches[8];
+    /* per-kernel accounting, filled when profiling is on (gmrf_bt_set_profiling); one class per
+     * kernel symbol so that a class compares with one row of a rocprofv3 kernel trace:
+     *  0 gemm_f64_mfma (64 x 64 tile GEMM: G2, doubling assembly, rank-256 updates, GEMM sweeps)
+     *  1 potrf_step<false> (tile Cholesky + inverse; fused with panel + update for one problem)
+     *  2 sweep_mm (k >= 2 right-hand sides)     3 sweep_gemv_n / _t (k = 1)
+     *  4 csr_spmm                                5 other (scatter, pack, Philox, ...)
+     *  6 gemm_f64_big<false>                     7 gemm_f64_big<true>   (128 x 128 tile GEMM)
+     *  8 potrf_panel                             9 potrf_update
+     * 10 spmm_bxt (sparse C = B X^T)
+     * work = algorithmic flops (0-2, 6-9) or algorithmic bytes (3-5, 10). */
+#define GMRF_KERNEL_CLASSES 16
+    double kernel_ms[GMRF_KERNEL_CLASSES];
+    double kernel_work[GMRF_KERNEL_CLASSES];
+    int64_t kernel_launches[GMRF_KERNEL_CLASSES];
 } gmrf_stats;
 
 /* ------------------------------------------------------------------ life cycle */
