@@ -35,7 +35,8 @@ PEAK_FP64_MFMA_TFLOPS = 78.6     # MI355X datasheet fp64 matrix peak; 77.7 measu
 PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3-6.5 TB/s achievable)
 
 KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_stats)
-    0: ("gemm_f64_mfma", "mfma"),           # 64 x 64 tile GEMM
+    0: ("gemm_f64_mfma<false,false>", "mfma"),   # 64 x 64 tile GEMM, B stored [n][k]
+    11: ("gemm_f64_mfma<false,true>", "mfma"),   # 64 x 64 tile GEMM, B stored [k][n]
     6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
     7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
     1: ("potrf_step<false>", "mfma"),       # tile Cholesky + inverse (latency-bound, B workgroups)
@@ -103,6 +104,8 @@ def main():
     ap.add_argument("--mode", choices=["problems", "shared-factor"], default="problems")
     ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-problem", action="store_true",
+                    help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
     args = ap.parse_args()
 
     import torch
@@ -240,26 +243,27 @@ def main():
         out["phases_ms"] = {"factor": s1["factor_ms"], "mean_2_sweeps": s1["solve_ms"], "samples_1_sweep": s2["sample_ms"]}
         out["factor_tflops"] = st["factor_flops"] / (s1["factor_ms"] * 1e-3) / 1e12
         out["sweep_k1_gbps"] = s1["sweep_bytes"] / (0.5 * s1["solve_ms"] * 1e-3) / 1e9
-        # latency of ONE problem (batch 1) on the same GPU, for reference
-        F1 = pkg.TridiagonalCholeskyFactor(device=local, stream=eng.stream.cuda_stream).factor(w.Q, w.n_blocks)
-        nz1 = eng.nz[0].contiguous(); rhs1 = eng.rhs[0, 0].contiguous()
-        for _ in range(2):
-            torch.cuda.synchronize(); t1 = time.perf_counter()
-            F1.refactor(nz1); mu1 = pkg.ldiv(F1, rhs1); X1 = F1.sample(args.samples, mean=mu1, seed=1, like=rhs1)
-            torch.cuda.synchronize(); lat = time.perf_counter() - t1
-        out["single_problem"] = {"latency_ms": 1e3 * lat, "solves_per_s": (1 + args.samples) / lat}
-        if not args.no_cpu_baseline:
-            base, (mu_o, X_o, Z) = cpu_baseline(w, args.samples)
-            out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
-            out["speedup_vs_cpu"] = out["value"] / base["value"]
-            out["cpu_sparse_direct"] = cpu_sparse_direct(w, args.samples)
-            mu_h = mu1.cpu().numpy()
-            Xh = F1.sample(args.samples, mean=mu_o, z=Z)
-            cond_eps = 3.4e9 * 2.2e-16 if w.name == "darcy256" else None
-            out["parity"] = {"mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
-                             "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o)),
-                             "bound_0.1_cond_eps": 0.1 * cond_eps if cond_eps else None}
-        F1.close()
+        if not args.no_single_problem:
+            # latency of ONE problem (batch 1) on the same GPU, for reference
+            F1 = pkg.TridiagonalCholeskyFactor(device=local, stream=eng.stream.cuda_stream).factor(w.Q, w.n_blocks)
+            nz1 = eng.nz[0].contiguous(); rhs1 = eng.rhs[0, 0].contiguous()
+            for _ in range(2):
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                F1.refactor(nz1); mu1 = pkg.ldiv(F1, rhs1); X1 = F1.sample(args.samples, mean=mu1, seed=1, like=rhs1)
+                torch.cuda.synchronize(); lat = time.perf_counter() - t1
+            out["single_problem"] = {"latency_ms": 1e3 * lat, "solves_per_s": (1 + args.samples) / lat}
+            if not args.no_cpu_baseline:
+                base, (mu_o, X_o, Z) = cpu_baseline(w, args.samples)
+                out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
+                out["speedup_vs_cpu"] = out["value"] / base["value"]
+                out["cpu_sparse_direct"] = cpu_sparse_direct(w, args.samples)
+                mu_h = mu1.cpu().numpy()
+                Xh = F1.sample(args.samples, mean=mu_o, z=Z)
+                cond_eps = 3.4e9 * 2.2e-16 if w.name == "darcy256" else None
+                out["parity"] = {"mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
+                                 "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o)),
+                                 "bound_0.1_cond_eps": 0.1 * cond_eps if cond_eps else None}
+            F1.close()
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

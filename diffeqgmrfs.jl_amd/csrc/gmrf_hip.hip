@@ -209,6 +209,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     // statistics: launches of the 128 x 128 kernel are their own classes (6: B stored [n][k],
     // 7: B stored [k][n]) whoever calls, so that a class is one kernel symbol of a rocprof trace
     if (gemm_uses_big(a_t, g, batch * (int)h->B)) { pclass = b_n ? 7 : 6; pwork = -1.0; }
+    else if (pclass == 0) pclass = a_t ? 12 : (b_n ? 11 : 0);
     ProfScope ps(h, pclass, pwork >= 0.0 ? pwork : flops);
     HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch * (int)h->B));
     return GMRF_OK;

@@ -72,14 +72,15 @@ typedef struct {
     int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
     /* per-kernel accounting, filled when profiling is on (gmrf_bt_set_profiling); one class per
      * kernel symbol so that a class compares with one row of a rocprofv3 kernel trace:
-     *  0 gemm_f64_mfma (64 x 64 tile GEMM: G2, doubling assembly, rank-256 updates, GEMM sweeps)
+     *  0 / 11 / 12 gemm_f64_mfma<false,false> / <false,true> / <true,*> (64 x 64 tile GEMM: G2,
+     *    rank-256 updates, GEMM sweeps / doubling assembly, GEMM sweeps / selected inversion)
      *  1 potrf_step<false> (tile Cholesky + inverse; fused with panel + update for one problem)
      *  2 sweep_mm (k >= 2 right-hand sides)     3 sweep_gemv_n / _t (k = 1)
      *  4 csr_spmm                                5 other (scatter, pack, Philox, ...)
      *  6 gemm_f64_big<false>                     7 gemm_f64_big<true>   (128 x 128 tile GEMM)
      *  8 potrf_panel                             9 potrf_update
      * 10 spmm_bxt (sparse C = B X^T)
-     * work = algorithmic flops (0-2, 6-9) or algorithmic bytes (3-5, 10). */
+     * work = algorithmic flops (0-2, 6-9, 11, 12) or algorithmic bytes (3-5, 10). */
 #define GMRF_KERNEL_CLASSES 16
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];
