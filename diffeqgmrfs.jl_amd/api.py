@@ -300,8 +300,9 @@ class TridiagonalCholeskyFactor:
         return view
 
     def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None):
+        """diag(Q^-1).  "exact" (selected inversion) also serves a batch: returns (batch, n)."""
         m = {"exact": _cabi.VAR_EXACT, "rbmc": _cabi.VAR_RBMC, "mc": _cabi.VAR_MC}[method]
-        out = np.empty(self.N, dtype=np.float64)
+        out = np.empty(self.N if self.batch == 1 else (self.batch, self.N), dtype=np.float64)
         _cabi.check(self._lib.gmrf_bt_marginal_var(self._h, m, k, seed, Q._h if Q is not None else None,
                                                    _cabi.ptr(out)))
         return out

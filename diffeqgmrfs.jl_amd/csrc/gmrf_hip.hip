@@ -126,7 +126,8 @@ struct gmrf_handle {
     double* d_stage = nullptr;
     int64_t stage_cap = 0;
     double* d_mean = nullptr;
-    double* d_acc = nullptr;           // variance accumulator (n)
+    double* d_acc = nullptr;           // variance accumulator / output ([acc_B][n])
+    int64_t acc_B = 0;
     // graphs
     bool eager = false;
     bool split_step = false;           // use the three-launch panel step also for batch 1 (experiment)
@@ -1328,23 +1329,25 @@ static gmrf_status need_single(gmrf_handle* h) {
 
 static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     // S_NN = Linv_N^T Linv_N ;  S_ii = Linv_i^T Linv_i + G^T S_{i+1,i+1} G,  G = C_i Linv_i
+    // (all problems of a batch in lock step: problem strides on every operand; d_out is [B][n])
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp;
+    const int64_t pLX = bstride * h->N, pCm = bstride * std::max<int64_t>(h->N - 1, 1), pW = bstride;
     double* Sg = h->d_S;     // current Sigma_{i+1,i+1}
     double* G = h->d_B;
     double* Hm = h->d_T;
     double* Sn = h->d_W;
     for (int64_t i = h->N - 1; i >= 0; --i) {
         const double* X = h->d_Linv + i * bstride;
-        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, 0, 0, 0));
+        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, pLX, pLX, pW));
         if (i < h->N - 1) {
             const double* C = h->d_C + i * bstride;
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld, 0, 0, 0));
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld, 0, 0, 0));
-            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld, 0, 0, 0));
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld, pCm, pLX, pW));
+            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld, pW, pW, pW));
+            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld, pW, pW, pW));
         }
-        hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((h->bs + 255) / 256)), dim3(256), 0, h->stream,
-                           Sn, ld, (int)h->bs, d_out + i * h->bs);
+        hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((h->bs + 255) / 256), (unsigned)h->B), dim3(256), 0, h->stream,
+                           Sn, ld, (int)h->bs, d_out + i * h->bs, bstride, h->n);
         HIPCHK(hipGetLastError());
         std::swap(Sg, Sn);
     }
@@ -1385,7 +1388,7 @@ gmrf_status gmrf_bt_var_accumulate(gmrf_handle* h, int32_t method, int64_t first
     const bool dev = is_device_ptr(acc);
     double* d_acc = acc;
     if (!dev) {
-        if (!h->d_acc) HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n));
+        if (!h->d_acc) { HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n)); h->acc_B = 1; }
         HIPCHK(hipMemcpyAsync(h->d_acc, acc, sizeof(double) * h->n, hipMemcpyHostToDevice, h->stream));
         d_acc = h->d_acc;
     }
@@ -1399,17 +1402,22 @@ gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint
                                  double* var_out) {
     if (!h || !var_out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "variance before factor"; return GMRF_ERR_NO_FACTOR; }
-    GCHK(need_single(h));
+    if (method != GMRF_VAR_EXACT) GCHK(need_single(h));    // sampled estimators: one problem per handle
     HIPCHK(hipSetDevice(h->device));
-    if (!h->d_acc) HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n));
+    if (!h->d_acc || h->acc_B < h->B) {
+        free_dev(h->d_acc); h->d_acc = nullptr;
+        HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * h->n * h->B));
+        h->acc_B = h->B;
+    }
     const bool dev = is_device_ptr(var_out);
     double* d_out = var_out;
     if (!dev) { GCHK(ensure_stage(h, std::max<int64_t>(h->n, 1))); }
     if (method == GMRF_VAR_EXACT) {
-        // selected inversion writes into d_acc (stage may be reused by nothing here)
+        // selected inversion; var_out is [batch][n]
         GCHK(var_exact(h, h->d_acc));
-        if (dev) HIPCHK(hipMemcpyAsync(d_out, h->d_acc, sizeof(double) * h->n, hipMemcpyDeviceToDevice, h->stream));
-        else HIPCHK(hipMemcpyAsync(var_out, h->d_acc, sizeof(double) * h->n, hipMemcpyDeviceToHost, h->stream));
+        const size_t bytes = sizeof(double) * h->n * h->B;
+        if (dev) HIPCHK(hipMemcpyAsync(d_out, h->d_acc, bytes, hipMemcpyDeviceToDevice, h->stream));
+        else HIPCHK(hipMemcpyAsync(var_out, h->d_acc, bytes, hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->profiling) prof_collect(h);
         return GMRF_OK;

@@ -279,9 +279,9 @@ __global__ __launch_bounds__(256) void logdet_blocks(const double* __restrict__ 
 
 // diag(S) of a dense block into out (selected inversion output)
 __global__ void extract_diag_dense(const double* __restrict__ S, int64_t ld, int bs,
-                                   double* __restrict__ out) {
+                                   double* __restrict__ out, int64_t pS, int64_t pout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < bs) out[i] = S[(int64_t)i * ld + i];
+    if (i < bs) out[(int64_t)blockIdx.y * pout + i] = S[(int64_t)blockIdx.y * pS + (int64_t)i * ld + i];
 }
 
 // S = 0.5 (S + S^T) is not needed: selected inversion keeps symmetry to rounding.

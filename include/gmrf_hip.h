@@ -139,7 +139,8 @@ gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int
                             double* z, int64_t ld);
 
 /* Marginal variances diag(A^-1)  (std(x_cond), solve_darcy_gmrf-fem.jl:192).
- * EXACT: block-tridiagonal selected inversion (deterministic).
+ * EXACT: block-tridiagonal selected inversion (deterministic); serves a batch too, var_out is then
+ *        [batch][n].
  * RBMC:  Rao-Blackwellised Monte Carlo over k Philox samples, needs Q (the factored matrix).
  * MC:    plain Monte Carlo over k samples. */
 gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed,

@@ -375,6 +375,13 @@ def test_batch_of_problems_matches_one_by_one(pkg):
         assert np.array_equal(Fb.chos[2], F1.chos[2]) and abs(Fb.logdet() - F1.logdet()) == 0.0
         Fo = O.tridiagonal_cholesky(Qp, w.n_blocks)
         assert rel(mu_b[p], O.ldiv(Fo, rhs[p])) < solve_tol(w)
+    # exact marginal variances of the whole batch in one call
+    vb = Fb.marginal_var("exact")
+    assert vb.shape == (B, w.n)
+    for p in (0, B - 1):
+        Qp = w.Q.copy(); Qp.data = vals[p]
+        vo = O.marginal_variances_exact(O.tridiagonal_cholesky(Qp, w.n_blocks))
+        assert np.max(np.abs(vb[p] - vo) / vo) < 1e-9
     # a non-SPD member of the batch is reported with its block index
     bad = vals.copy()
     Qb = w.Q.tocsc()
