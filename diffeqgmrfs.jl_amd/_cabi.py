@@ -30,6 +30,7 @@ EXPORTS = [
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
+    "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
 ]
@@ -116,6 +117,11 @@ def load() -> C.CDLL:
         "gmrf_bt_export_factor": [vp, vp, i64],
         "gmrf_bt_import_factor": [vp, vp, i64],
         "gmrf_csr_destroy": [vp],
+        "gmrf_assemble_create": [i32, vp, i64, vp, vp, i64, vp, vp, i32, P(vp)],
+        "gmrf_assemble_destroy": [vp],
+        "gmrf_assemble_pattern": [vp, P(i64), P(i64), vp, vp, i32],
+        "gmrf_assemble_precision": [vp, vp, vp, dbl, vp],
+        "gmrf_assemble_rhs": [vp, vp, vp, vp, vp, dbl, vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],
         "gmrf_test_gemm_rate": [i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, P(dbl)],

@@ -101,6 +101,95 @@ class CsrMatrix:
         return view
 
 
+class PosteriorAssembler:
+    """Device assembly of the Gauss-Newton / conditioning system:
+
+        A   = Q + noise * J' * J                        scripts/solve_burger.jl:145
+        rhs = base + noise * J' * (J * x + obs_diff)    scripts/solve_burger.jl:146
+
+    for fixed sparsity patterns of Q (n x n, symmetric, both triangles) and J (m x n).  The
+    symbolic phase runs once here; `precision()` / `rhs()` take the current values as NumPy arrays
+    or torch CUDA tensors and return the same kind.  `pattern` is the CSC matrix (values 1) whose
+    `.data` order `precision()` fills -- factor it once with `TridiagonalCholeskyFactor.factor`,
+    then `refactor(values)`.  device = -1: symbolic only (no GPU needed)."""
+
+    def __init__(self, Q, J, device: int = 0, stream: int = 0):
+        Q = sp.csc_matrix(Q); Q.sort_indices()
+        J = sp.csr_matrix(J); J.sort_indices()
+        if Q.shape[0] != Q.shape[1] or J.shape[1] != Q.shape[0]:
+            raise ValueError("Q must be n x n and J m x n")
+        self.n, self.m = Q.shape[0], J.shape[0]
+        self.nnz_q, self.nnz_j = int(Q.nnz), int(J.nnz)
+        self._h = C.c_void_p()
+        lib = _cabi.load()
+        qp, qi = Q.indptr.astype(np.int64), Q.indices.astype(np.int64)
+        jp, ji = J.indptr.astype(np.int64), J.indices.astype(np.int64)
+        _cabi.check(lib.gmrf_assemble_create(device, C.c_void_p(stream), self.n, _cabi.ptr(qp), _cabi.ptr(qi), self.m,
+                                             _cabi.ptr(jp), _cabi.ptr(ji), 0, C.byref(self._h)))
+        nnz, nprod = C.c_int64(0), C.c_int64(0)
+        _cabi.check(lib.gmrf_assemble_pattern(self._h, C.byref(nnz), C.byref(nprod), None, None, 0))
+        self.nnz_out, self.n_products = int(nnz.value), int(nprod.value)
+        cp, rv = np.empty(self.n + 1, dtype=np.int64), np.empty(self.nnz_out, dtype=np.int64)
+        _cabi.check(lib.gmrf_assemble_pattern(self._h, None, None, _cabi.ptr(cp), _cabi.ptr(rv), 0))
+        self.pattern = sp.csc_matrix((np.ones(self.nnz_out), rv, cp), shape=(self.n, self.n))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _cabi.load().gmrf_assemble_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _like(ref, count):
+        if _is_torch(ref):
+            import torch
+            return torch.empty(count, dtype=torch.float64, device=ref.device)
+        return np.empty(count, dtype=np.float64)
+
+    @staticmethod
+    def _vec(v, count, name):
+        if v is None:
+            return None
+        if _is_torch(v):
+            v = v.contiguous()
+        else:
+            v = np.ascontiguousarray(v, dtype=np.float64)
+        if (v.numel() if _is_torch(v) else v.size) != count:
+            raise ValueError(f"{name}: expected {count} values")
+        return v
+
+    def precision(self, q_values, j_values, noise: float):
+        q = self._vec(q_values, self.nnz_q, "q_values")
+        j = self._vec(j_values, self.nnz_j, "j_values")
+        out = self._like(j, self.nnz_out)
+        _cabi.check(_cabi.load().gmrf_assemble_precision(self._h, _cabi.ptr(q), _cabi.ptr(j), float(noise), _cabi.ptr(out)))
+        return out
+
+    def rhs(self, base, j_values, x, obs_diff, noise: float):
+        j = self._vec(j_values, self.nnz_j, "j_values")
+        xv = self._vec(x, self.n, "x")
+        b = self._vec(base, self.n, "base")
+        o = self._vec(obs_diff, self.m, "obs_diff")
+        out = self._like(j, self.n)
+        _cabi.check(_cabi.load().gmrf_assemble_rhs(self._h, _cabi.ptr(b) if b is not None else None, _cabi.ptr(j),
+                                                  _cabi.ptr(xv), _cabi.ptr(o) if o is not None else None, float(noise),
+                                                  _cabi.ptr(out)))
+        return out
+
+
+def gn_step(F: "TridiagonalCholeskyFactor", asm: PosteriorAssembler, q_values, Qx_prior, j_values, x, obs_diff,
+            noise: float):
+    """One Gauss-Newton step of scripts/solve_burger.jl:143-149 with everything resident on the
+    device: assemble A = Q + noise J'J and the right-hand side, re-factor on the analysed pattern
+    (`F` must have been factored once on `asm.pattern`), solve."""
+    a_vals = asm.precision(q_values, j_values, noise)
+    rhs = asm.rhs(Qx_prior, j_values, x, obs_diff, noise)
+    F.refactor(a_vals)
+    return ldiv(F, rhs)
+
+
 class _LazyBlocks(Sequence):
     """`F.chos` / `F.Cs`: dense blocks copied from the device on access."""
 

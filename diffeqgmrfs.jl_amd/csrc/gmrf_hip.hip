@@ -15,9 +15,11 @@
 #include <cmath>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gmrf_hip.h"
+#include "assemble.hpp"
 #include "gemm_f64.hpp"
 #include "microbench.hpp"
 #include "misc_kernels.hpp"
@@ -1318,6 +1320,198 @@ gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k, 
         HIPCHK(hipMemcpy2DAsync(Y, ldy * sizeof(double), d_Y, S->n_rows * sizeof(double),
                                 S->n_rows * sizeof(double), k, hipMemcpyDeviceToHost, S->stream));
     HIPCHK(hipStreamSynchronize(S->stream));
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- posterior assembly
+struct gmrf_assembler {
+    int device = -1;                    // -1: symbolic only (pattern queries; no numeric phase)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t n = 0, m = 0, nnz_q = 0, nnz_j = 0, nnz_out = 0, n_pairs = 0;
+    std::vector<int64_t> colptr, rowval;            // result pattern (CSC, 0-based, rows ascending)
+    int64_t *d_pptr = nullptr, *d_qmap = nullptr, *d_jt_ptr = nullptr, *d_j_rptr = nullptr;
+    int32_t *d_pa = nullptr, *d_pb = nullptr, *d_jt_row = nullptr, *d_jt_src = nullptr, *d_j_col = nullptr;
+    double *d_q = nullptr, *d_jv = nullptr, *d_vn = nullptr, *d_vm = nullptr, *d_vn2 = nullptr, *d_out = nullptr;   // staging for host callers
+};
+
+gmrf_status gmrf_assemble_create(int32_t device, void* stream, int64_t n, const int64_t* q_colptr, const int64_t* q_rowval,
+                                 int64_t m, const int64_t* j_rowptr, const int64_t* j_colidx, int32_t index_base,
+                                 gmrf_assembler** out) {
+    if (!out || !q_colptr || !q_rowval || !j_rowptr || !j_colidx || n <= 0 || m <= 0) return bad_shape("bad assembler arguments");
+    if (index_base != 0 && index_base != 1) return bad_shape("index_base must be 0 or 1");
+    const int64_t b = index_base;
+    const int64_t nnz_q = q_colptr[n] - b, nnz_j = j_rowptr[m] - b;
+    if (nnz_q < 0 || nnz_j < 0 || nnz_j >= ((int64_t)1 << 31)) return bad_shape("bad pattern sizes");
+    // J by columns: for column j the (row k, position in the CSR value array)
+    std::vector<int64_t> jt_ptr((size_t)n + 1, 0);
+    for (int64_t p = 0; p < nnz_j; ++p) {
+        const int64_t c = j_colidx[p] - b;
+        if (c < 0 || c >= n) return bad_shape("J column index out of range");
+        jt_ptr[c + 1]++;
+    }
+    for (int64_t i = 0; i < n; ++i) jt_ptr[i + 1] += jt_ptr[i];
+    std::vector<int32_t> jt_row((size_t)nnz_j), jt_src((size_t)nnz_j), j_col((size_t)nnz_j);
+    {
+        std::vector<int64_t> fill(jt_ptr.begin(), jt_ptr.end() - 1);
+        for (int64_t k = 0; k < m; ++k)
+            for (int64_t p = j_rowptr[k] - b; p < j_rowptr[k + 1] - b; ++p) {
+                const int64_t c = j_colidx[p] - b;
+                jt_row[fill[c]] = (int32_t)k; jt_src[fill[c]] = (int32_t)p; fill[c]++;
+                j_col[p] = (int32_t)c;
+            }
+    }
+    // result column j = rows of Q's column j  U  { i : J[k,i] != 0 and J[k,j] != 0 for some k }
+    struct Prod { int64_t i; int32_t k, a, b; };
+    auto* as = new gmrf_assembler();
+    as->n = n; as->m = m; as->nnz_q = nnz_q; as->nnz_j = nnz_j;
+    as->colptr.assign((size_t)n + 1, 0);
+    std::vector<int64_t> pptr(1, 0), qmap;
+    std::vector<int32_t> pa, pb;
+    std::vector<Prod> prods;
+    for (int64_t j = 0; j < n; ++j) {
+        prods.clear();
+        for (int64_t t = jt_ptr[j]; t < jt_ptr[j + 1]; ++t) {
+            const int64_t k = jt_row[t];
+            for (int64_t p = j_rowptr[k] - b; p < j_rowptr[k + 1] - b; ++p)
+                prods.push_back({j_colidx[p] - b, (int32_t)k, (int32_t)p, jt_src[t]});
+        }
+        std::sort(prods.begin(), prods.end(), [](const Prod& x, const Prod& y) { return x.i != y.i ? x.i < y.i : x.k < y.k; });
+        size_t pi = 0;
+        int64_t qp = q_colptr[j] - b;
+        const int64_t qe = q_colptr[j + 1] - b;
+        int64_t last_row = -1;
+        while (pi < prods.size() || qp < qe) {
+            const int64_t rq = qp < qe ? q_rowval[qp] - b : INT64_MAX, rp = pi < prods.size() ? prods[pi].i : INT64_MAX;
+            const int64_t r = std::min(rq, rp);
+            if (r < 0 || r >= n || r <= last_row) { delete as; return bad_shape("Q rows must be ascending within a column and in range"); }
+            last_row = r;
+            as->rowval.push_back(r);
+            qmap.push_back(rq == r ? qp++ : -1);
+            while (pi < prods.size() && prods[pi].i == r) { pa.push_back(prods[pi].a); pb.push_back(prods[pi].b); ++pi; }
+            pptr.push_back((int64_t)pa.size());
+        }
+        as->colptr[j + 1] = (int64_t)as->rowval.size();
+    }
+    as->nnz_out = (int64_t)as->rowval.size();
+    as->n_pairs = (int64_t)pa.size();
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+            delete as;
+            g_last_error = "no HIP device visible (libgmrf_hip needs an MI355X / gfx950 GPU)";
+            return GMRF_ERR_NO_DEVICE;
+        }
+        as->device = device;
+        HIPCHK(hipSetDevice(device));
+        if (stream) as->stream = (hipStream_t)stream;
+        else { HIPCHK(hipStreamCreate(&as->stream)); as->own_stream = true; }
+        auto up = [&](auto** d, const auto& v) -> hipError_t {
+            using T = typename std::remove_reference<decltype(v[0])>::type;
+            hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
+            if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+            return e;
+        };
+        std::vector<int64_t> j_rptr((size_t)m + 1);
+        for (int64_t k = 0; k <= m; ++k) j_rptr[k] = j_rowptr[k] - b;
+        HIPCHK(up(&as->d_pptr, pptr)); HIPCHK(up(&as->d_qmap, qmap)); HIPCHK(up(&as->d_pa, pa)); HIPCHK(up(&as->d_pb, pb));
+        HIPCHK(up(&as->d_jt_ptr, jt_ptr)); HIPCHK(up(&as->d_jt_row, jt_row)); HIPCHK(up(&as->d_jt_src, jt_src));
+        HIPCHK(up(&as->d_j_rptr, j_rptr)); HIPCHK(up(&as->d_j_col, j_col));
+    }
+    *out = as;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_assemble_destroy(gmrf_assembler* as) {
+    if (!as) return GMRF_OK;
+    if (as->device >= 0) {
+        (void)hipSetDevice(as->device);
+        (void)hipStreamSynchronize(as->stream);
+        free_dev(as->d_pptr); free_dev(as->d_qmap); free_dev(as->d_pa); free_dev(as->d_pb);
+        free_dev(as->d_jt_ptr); free_dev(as->d_jt_row); free_dev(as->d_jt_src); free_dev(as->d_j_rptr); free_dev(as->d_j_col);
+        free_dev(as->d_q); free_dev(as->d_jv); free_dev(as->d_vn); free_dev(as->d_vm); free_dev(as->d_vn2); free_dev(as->d_out);
+        if (as->own_stream) (void)hipStreamDestroy(as->stream);
+    }
+    delete as;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_assemble_pattern(const gmrf_assembler* as, int64_t* nnz_out, int64_t* n_products, int64_t* colptr,
+                                  int64_t* rowval, int32_t index_base) {
+    if (!as) return bad_shape("null assembler");
+    if (nnz_out) *nnz_out = as->nnz_out;
+    if (n_products) *n_products = as->n_pairs;
+    if (colptr) for (int64_t j = 0; j <= as->n; ++j) colptr[j] = as->colptr[j] + index_base;
+    if (rowval) for (int64_t e = 0; e < as->nnz_out; ++e) rowval[e] = as->rowval[e] + index_base;
+    return GMRF_OK;
+}
+
+// host pointer -> staged device copy (lazily allocated buffer of `cap` doubles)
+static gmrf_status as_stage_in(gmrf_assembler* as, const double* p, int64_t count, double** buf, const double** d) {
+    if (!p) { *d = nullptr; return GMRF_OK; }
+    if (is_device_ptr(p)) { *d = p; return GMRF_OK; }
+    if (!*buf) HIPCHK(hipMalloc(buf, sizeof(double) * std::max<int64_t>(count, 1)));
+    HIPCHK(hipMemcpyAsync(*buf, p, sizeof(double) * count, hipMemcpyHostToDevice, as->stream));
+    *d = *buf;
+    return GMRF_OK;
+}
+
+static gmrf_status as_numeric_ready(gmrf_assembler* as) {
+    if (!as) return bad_shape("null assembler");
+    if (as->device < 0) { g_last_error = "symbolic-only assembler (created with device -1)"; return GMRF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(as->device));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_assemble_precision(gmrf_assembler* as, const double* q_nzval, const double* j_vals, double noise,
+                                    double* out_nzval) {
+    GCHK(as_numeric_ready(as));
+    if (!q_nzval || !j_vals || !out_nzval) return bad_shape("null pointer");
+    const double *dq, *dj;
+    GCHK(as_stage_in(as, q_nzval, as->nnz_q, &as->d_q, &dq));
+    GCHK(as_stage_in(as, j_vals, as->nnz_j, &as->d_jv, &dj));
+    const bool dev = is_device_ptr(out_nzval);
+    double* d_out = out_nzval;
+    if (!dev) {
+        if (!as->d_out) HIPCHK(hipMalloc(&as->d_out, sizeof(double) * std::max<int64_t>(as->nnz_out, 1)));
+        d_out = as->d_out;
+    }
+    hipLaunchKernelGGL(assemble_precision, dim3((unsigned)((as->nnz_out + 255) / 256)), dim3(256), 0, as->stream, as->d_pptr,
+                       as->d_pa, as->d_pb, as->d_qmap, dq, dj, noise, as->nnz_out, d_out);
+    HIPCHK(hipGetLastError());
+    if (!dev) HIPCHK(hipMemcpyAsync(out_nzval, d_out, sizeof(double) * as->nnz_out, hipMemcpyDeviceToHost, as->stream));
+    HIPCHK(hipStreamSynchronize(as->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_assemble_rhs(gmrf_assembler* as, const double* base, const double* j_vals, const double* x,
+                              const double* obs_diff, double noise, double* out) {
+    GCHK(as_numeric_ready(as));
+    if (!j_vals || !x || !out) return bad_shape("null pointer");
+    const double *dj, *dx, *dadd, *dbase;
+    GCHK(as_stage_in(as, j_vals, as->nnz_j, &as->d_jv, &dj));
+    GCHK(as_stage_in(as, x, as->n, &as->d_vn, &dx));
+    if (!as->d_vm) HIPCHK(hipMalloc(&as->d_vm, sizeof(double) * 2 * as->m));
+    dadd = obs_diff;
+    if (obs_diff && !is_device_ptr(obs_diff)) {
+        HIPCHK(hipMemcpyAsync(as->d_vm + as->m, obs_diff, sizeof(double) * as->m, hipMemcpyHostToDevice, as->stream));
+        dadd = as->d_vm + as->m;
+    }
+    GCHK(as_stage_in(as, base, as->n, &as->d_vn2, &dbase));
+    // v = J x + obs_diff ;  out = base + noise * J' v
+    hipLaunchKernelGGL(assemble_j_apply, dim3((unsigned)((as->m + 255) / 256)), dim3(256), 0, as->stream, as->d_j_rptr,
+                       as->d_j_col, dj, dx, dadd, as->m, as->d_vm);
+    const bool dev = is_device_ptr(out);
+    double* d_out = out;
+    if (!dev) {
+        if (!as->d_out) HIPCHK(hipMalloc(&as->d_out, sizeof(double) * std::max<int64_t>(std::max(as->nnz_out, as->n), 1)));
+        d_out = as->d_out;
+    }
+    hipLaunchKernelGGL(assemble_jt_apply, dim3((unsigned)((as->n + 255) / 256)), dim3(256), 0, as->stream, as->d_jt_ptr,
+                       as->d_jt_row, as->d_jt_src, dj, as->d_vm, dbase, noise, as->n, d_out);
+    HIPCHK(hipGetLastError());
+    if (!dev) HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * as->n, hipMemcpyDeviceToHost, as->stream));
+    HIPCHK(hipStreamSynchronize(as->stream));
     return GMRF_OK;
 }
 

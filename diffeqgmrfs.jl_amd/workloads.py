@@ -274,6 +274,58 @@ def burgers(ns: int, nt: int, ic_noise: float = 1e8, fem_noise: float = 1e12) ->
                     {"dt": dt, "nu": nu_b, "nnz": int(Q.nnz)})
 
 
+def burgers_gauss_newton(ns: int, nt: int, ic_noise: float = 1e8, fem_noise: float = 1e12):
+    """The pieces of the reference's Gauss-Newton loop for the Burgers space-time GMRF
+    (scripts/solve_burger.jl:118-180; residual tangent scripts/burgers/solve_burgers_gmrf-fem.jl:118-149)
+    on the mesh of `burgers`: returns a dict with
+      Q          prior precision with the initial condition conditioned in (CSC, fixed),
+      Qx_prior   Q * x_prior (information vector of the prior part),
+      x_prior    starting point,
+      residual   x -> r(x), the implicit-Euler Burgers residual of slices 1..nt-1 (m = ns (nt-1)),
+      jacobian   x -> J(x) as CSR with ONE fixed sparsity pattern (explicit zeros kept),
+      noise, n_blocks."""
+    nu_b = 0.01 / math.pi
+    dt = 1.0 / (nt - 1)
+    M, lumped, S, Adv = p1_periodic_line(ns)
+    w = burgers(ns, nt, ic_noise, 0.0)                 # prior + initial-condition part only
+    xs = np.arange(ns) / ns
+    ic = np.sin(2 * np.pi * xs) + 0.5 * np.sin(4 * np.pi * xs + 0.3)
+    x_prior = np.full(ns * nt, float(ic.mean()))
+    M = M.tocsr(); S = S.tocsr(); Adv = Adv.tocsr()
+    Jstat = (M + dt * nu_b * S).tocsr()
+    pat_t = (abs(Jstat) + abs(Adv) + sp.identity(ns)).tocsr()
+    pat_t.data[:] = 0.0                                # explicit zeros: the union pattern of a diagonal block of J
+    negM = (-M).tocsr()
+
+    def residual(x):
+        X = x.reshape(nt, ns)
+        out = np.empty((nt - 1, ns))
+        for t in range(1, nt):
+            u = X[t]
+            out[t - 1] = M @ (u - X[t - 1]) + dt * (nu_b * (S @ u) + u * (Adv @ u))
+        return out.ravel()
+
+    def jacobian(x):
+        X = x.reshape(nt, ns)
+        rows = []
+        for t in range(1, nt):
+            u = X[t]
+            Jt = (Jstat + dt * (sp.diags(u) @ Adv + sp.diags(Adv @ u)) + pat_t).tocsr()
+            row = [None] * nt
+            row[t - 1] = negM
+            row[t] = Jt
+            for k in range(nt):
+                if row[k] is None:
+                    row[k] = sp.csr_matrix((ns, ns))
+            rows.append(row)
+        J = sp.bmat(rows, format="csr")
+        J.sort_indices()
+        return J
+
+    return {"Q": w.Q, "Qx_prior": w.rhs, "x_prior": x_prior, "residual": residual, "jacobian": jacobian,
+            "noise": fem_noise, "n_blocks": nt, "n": ns * nt, "m": ns * (nt - 1)}
+
+
 # --------------------------------------------------------------------------- analytic / toy
 
 def laplace_kappa_grid(nx: int, ny: int, kappa2: float = 0.5) -> Workload:

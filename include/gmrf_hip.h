@@ -230,6 +230,30 @@ gmrf_status gmrf_csr_destroy(gmrf_csr* m);
 gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k,
                       int64_t ldx, int64_t ldy);
 
+/* ------------------------------------------------------------------ posterior assembly
+ * The step before the factorisation in the reference's Gauss-Newton loop
+ * (scripts/solve_burger.jl:143-149) and in `condition_on_observations`:
+ *     A   = Q + noise * J' * J                       (gmrf_assemble_precision)
+ *     rhs = base + noise * J' * (J * x + obs_diff)   (gmrf_assemble_rhs; base = Q * x_prior)
+ * Patterns are fixed, values change per iteration.  create() does the symbolic work on the host
+ * (Q: CSC n x n with ascending rows per column, both triangles; J: CSR m x n); the numeric calls
+ * take host or device pointers, and the device output of gmrf_assemble_precision is the `nzval`
+ * array of the pattern gmrf_assemble_pattern returns -- feed it to gmrf_bt_factor_csc once and to
+ * gmrf_bt_refactor_values afterwards.  device = -1: symbolic only (pattern queries). */
+typedef struct gmrf_assembler gmrf_assembler;
+gmrf_status gmrf_assemble_create(int32_t device, void* stream, int64_t n, const int64_t* q_colptr,
+                                 const int64_t* q_rowval, int64_t m, const int64_t* j_rowptr,
+                                 const int64_t* j_colidx, int32_t index_base, gmrf_assembler** out);
+gmrf_status gmrf_assemble_destroy(gmrf_assembler* as);
+/* nnz of the result, number of J[k,i] * J[k,j] products, and (if not NULL) its CSC pattern. */
+gmrf_status gmrf_assemble_pattern(const gmrf_assembler* as, int64_t* nnz_out, int64_t* n_products,
+                                  int64_t* colptr, int64_t* rowval, int32_t index_base);
+gmrf_status gmrf_assemble_precision(gmrf_assembler* as, const double* q_nzval, const double* j_vals,
+                                    double noise, double* out_nzval);
+/* obs_diff and base may be NULL (zero). */
+gmrf_status gmrf_assemble_rhs(gmrf_assembler* as, const double* base, const double* j_vals,
+                              const double* x, const double* obs_diff, double noise, double* out);
+
 /* ------------------------------------------------------------------ test hooks
  * Direct access to the dense device kernels for the parity tests (row-major operands on
  * the HOST; not part of the drop-in surface). */

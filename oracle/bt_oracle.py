@@ -241,6 +241,29 @@ def marginal_variances_mc(X: np.ndarray) -> np.ndarray:
 
 # ----------------------------------------------------------------------------- helpers
 
+def assemble_posterior(Q, J, noise: float):
+    """`A = Symmetric(Q + noise * J_mat' * J_mat)`  -- /root/reference/scripts/solve_burger.jl:145
+    (and `Q + noise_fem * J_final' * J_final`, scripts/burgers/solve_burgers_gmrf-fem.jl:186)."""
+    import scipy.sparse as sp
+    Q = sp.csc_matrix(Q)
+    J = sp.csr_matrix(J)
+    A = (Q + noise * (J.T @ J)).tocsc()
+    A.sort_indices()
+    return A
+
+
+def gn_rhs(Qx_prior: np.ndarray, J, x: np.ndarray, obs_diff: np.ndarray, noise: float) -> np.ndarray:
+    """`rhs = Qx_prior + noise * J_mat' * Array(J_mat * x + obs_diff)`  -- scripts/solve_burger.jl:146."""
+    return Qx_prior + noise * (J.T @ (J @ x + obs_diff))
+
+
+def gn_step(Q, J, Qx_prior: np.ndarray, x: np.ndarray, obs_diff: np.ndarray, noise: float, N_blocks: int) -> np.ndarray:
+    """One `gn_step` of scripts/solve_burger.jl:143-149 with the block-tridiagonal factor in the place
+    of `cholesky(A; perm = perm)`: assemble, factor, solve."""
+    A = assemble_posterior(Q, J, noise)
+    return ldiv(tridiagonal_cholesky(A, N_blocks), gn_rhs(Qx_prior, J, x, obs_diff, noise))
+
+
 def reconstruct(F: TridiagonalCholeskyFactor) -> np.ndarray:
     """Dense L L^T from the block factor (tests only, small n)."""
     N, bs = F.n_blocks, F.block_size

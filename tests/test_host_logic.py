@@ -81,3 +81,21 @@ def test_baseline_config_shapes(pkg):
     w = pkg.workloads.darcy(16)
     assert (w.n, w.n_blocks, w.block_size) == (256, 4, 64)
     assert set(pkg.workloads.CONFIGS) >= {"burgers512x64", "darcy64", "darcy256", "elliptic512", "burgers4096x512"}
+
+
+def test_posterior_assembler_symbolic_phase_without_gpu(pkg, lib):
+    """pattern of Q + noise J'J and the product lists, host side only."""
+    from oracle import bt_oracle as O
+    gn = pkg.workloads.burgers_gauss_newton(32, 6)
+    J = gn["jacobian"](gn["x_prior"])
+    asm = pkg.PosteriorAssembler(gn["Q"], J, device=-1)
+    A = O.assemble_posterior(gn["Q"], J, 1.0)
+    assert asm.nnz_out == A.nnz
+    assert np.array_equal(asm.pattern.indptr, A.indptr) and np.array_equal(asm.pattern.indices, A.indices)
+    assert asm.n_products == int((np.diff(J.indptr) ** 2).sum())
+    assert pkg.workloads.block_bandwidth_ok(asm.pattern, gn["n_blocks"])
+    with pytest.raises(pkg.GmrfError) as e:           # numeric phase needs the GPU: no CPU fallback
+        asm.precision(gn["Q"].data, J.data, 1.0)
+    assert e.value.status == pkg._cabi.ERR_NO_DEVICE
+    with pytest.raises(ValueError):
+        pkg.PosteriorAssembler(gn["Q"], J[:, :-1], device=-1)

@@ -174,3 +174,20 @@ def test_c_restatement_agrees_with_numpy_oracle(pkg):
         assert rel(y, ref) < 1e-12
     D[2, 3, 3] = -5.0
     assert lib.bt_factor_dense(N, bs, p(D), p(B), p(Ld), p(Cs)) == 3
+
+
+def test_gauss_newton_step_restatement(pkg):
+    # scripts/solve_burger.jl:143-149: A = Q + noise J'J, rhs = Qx_prior + noise J'(J x + obs_diff)
+    gn = pkg.workloads.burgers_gauss_newton(32, 6)
+    x = gn["x_prior"]
+    J = gn["jacobian"](x)
+    r = gn["residual"](x)
+    xn = O.gn_step(gn["Q"], J, gn["Qx_prior"], x, -r, gn["noise"], gn["n_blocks"])
+    A = O.assemble_posterior(gn["Q"], J, gn["noise"])
+    rhs = O.gn_rhs(gn["Qx_prior"], J, x, -r, gn["noise"])
+    assert np.linalg.norm(A @ xn - rhs) / np.linalg.norm(rhs) < 1e-12
+    Ad = gn["Q"].toarray() + gn["noise"] * (J.toarray().T @ J.toarray())
+    assert np.max(np.abs(A.toarray() - Ad)) / np.max(np.abs(Ad)) < 1e-15
+    # the step minimises the linearised objective: its gradient vanishes at xn
+    grad = gn["Q"] @ xn - gn["Qx_prior"] + gn["noise"] * (J.T @ (J @ (xn - x) + r))
+    assert np.linalg.norm(grad) / np.linalg.norm(rhs) < 1e-12
