@@ -22,7 +22,7 @@ module DiffEqGMRFsHIP
 
 using SparseArrays, LinearAlgebra
 
-export TridiagonalCholeskyFactor, tridiagonal_cholesky
+export TridiagonalCholeskyFactor, tridiagonal_cholesky, PosteriorAssembler
 
 const libgmrf = get(ENV, "LIBGMRF_HIP", joinpath(@__DIR__, "..", "diffeqgmrfs.jl_amd", "csrc", "libgmrf_hip.so"))
 
@@ -149,6 +149,45 @@ function LinearAlgebra.logdet(F::TridiagonalCholeskyFactor)
     v = Ref{Float64}(0.0)
     check(ccall((:gmrf_bt_logdet, libgmrf), Int32, (Ptr{Cvoid}, Ref{Float64}), F.handle, v))
     return v[]
+end
+
+# --- Gauss-Newton assembly on the device (gn_step, scripts/solve_burger.jl:143-149) -----------------
+"Symbolic phase for A = Q + noise * J' * J with fixed patterns; J is passed through its transpose's CSC arrays (= CSR of J)."
+mutable struct PosteriorAssembler
+    handle::Ptr{Cvoid}
+    pattern::SparseMatrixCSC{Float64,Int}     # values 1.0; nzval order = output order of precision!
+end
+
+function PosteriorAssembler(Q::SparseMatrixCSC{Float64,Int}, J::SparseMatrixCSC{Float64,Int}; device::Integer = 0)
+    Jt = SparseMatrixCSC(J')                   # CSC of J' = CSR of J; its nzval order is what the numeric calls expect
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve Q Jt check(ccall((:gmrf_assemble_create, libgmrf), Int32,
+        (Int32, Ptr{Cvoid}, Int64, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Int64}, Int32, Ref{Ptr{Cvoid}}),
+        device, C_NULL, size(Q, 1), Q.colptr, Q.rowval, size(J, 1), Jt.colptr, Jt.rowval, 1, h))
+    nnz_out = Ref{Int64}(0); nprod = Ref{Int64}(0)
+    check(ccall((:gmrf_assemble_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32),
+                h[], nnz_out, nprod, C_NULL, C_NULL, 1))
+    colptr = Vector{Int64}(undef, size(Q, 1) + 1); rowval = Vector{Int64}(undef, nnz_out[])
+    check(ccall((:gmrf_assemble_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Ptr{Int64}, Int32),
+                h[], C_NULL, C_NULL, colptr, rowval, 1))
+    as = PosteriorAssembler(h[], SparseMatrixCSC(size(Q, 1), size(Q, 1), colptr, rowval, ones(nnz_out[])))
+    finalizer(a -> ccall((:gmrf_assemble_destroy, libgmrf), Int32, (Ptr{Cvoid},), a.handle), as)
+    return as
+end
+
+"nzval of Q + noise * J' * J on `as.pattern` (host vectors here; device pointers work the same way)."
+function precision!(out::Vector{Float64}, as::PosteriorAssembler, q_nzval::Vector{Float64}, jt_nzval::Vector{Float64}, noise::Real)
+    GC.@preserve out q_nzval jt_nzval check(ccall((:gmrf_assemble_precision, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}), as.handle, q_nzval, jt_nzval, Float64(noise), out))
+    return out
+end
+
+"rhs = base + noise * J' * (J * x + obs_diff)"
+function rhs!(out::Vector{Float64}, as::PosteriorAssembler, base, jt_nzval, x, obs_diff, noise::Real)
+    GC.@preserve out base jt_nzval x obs_diff check(ccall((:gmrf_assemble_rhs, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
+        as.handle, base, jt_nzval, x, obs_diff, Float64(noise), out))
+    return out
 end
 
 end # module
