@@ -333,12 +333,12 @@ struct StepArgs {
     int cend;             // potrf_update: column tiles j+1 .. cend-1 only (nt: the whole trailing block)
 };
 
-// grid.x = 1 + m (m + 1) / 2,  m = nt - j - 1.
-// UPDATE_ONLY = false: fused step (grid.x = 1 + m(m+1)/2; with grid.x = 1 it is the tile kernel).
-// UPDATE_ONLY = true : the diagonal tile was factored by a previous launch, X_jj is read from
-//                      global memory (grid.x = m(m+1)/2).  Used for batches of problems, where the
-//                      redundant tile factorisation of the fused form would cost throughput.
-template <bool UPDATE_ONLY>
+// Fused panel step: grid.x = 1 + m (m + 1) / 2, m = nt - j - 1.  Workgroup 0 factors and inverts
+// the diagonal tile and writes it; every other workgroup does the same factorisation for itself
+// (idle CUs otherwise), then forms its two panel tiles and updates its trailing tile.  With
+// grid.x = 1 it is the tile kernel of the split form (batches, large blocks).  The template
+// parameter only keeps the kernel's symbol (profiles, tests); it is always false.
+template <bool UNUSED>
 __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
     sa.L += (int64_t)blockIdx.y * sa.pLX;
@@ -359,15 +359,14 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     const int64_t oj = (int64_t)sa.j * 64;
 
     int r = 0, c = 0;
-    const int w = UPDATE_ONLY ? (int)blockIdx.x + 1 : (int)blockIdx.x;
+    const int w = (int)blockIdx.x;
     if (w > 0) {
         int t = w - 1, rr = 0;
         while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
         r = sa.j + 1 + rr;
         c = sa.j + 1 + (t - rr * (rr + 1) / 2);
     }
-    if (UPDATE_ONLY) tile_g2s(sa.X + oj * ld + oj, ld, Xs, tid);
-    else tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
+    tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
     // the C tile this wave will update (rows 16*wave.., MFMA C/D layout), fetched now, used last
     double* Sg = sa.S + (int64_t)r * 64 * ld + (int64_t)c * 64;
     v4d cpre[4];
@@ -382,13 +381,9 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     side.gA = (w > 0) ? sa.S + (int64_t)r * 64 * ld + oj : nullptr; side.sA = As;
     side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
     side.ld = ld; side.stamps = nullptr;
-    if (UPDATE_ONLY) {
-        tile_g2s(side.gA, ld, As, tid);
-        if (side.gB) tile_g2s(side.gB, ld, Bs, tid);
-    }
     __syncthreads();
     bool bad = false;
-    if (!UPDATE_ONLY) tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
     if (w == 0) {
         if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
         tile_s2g(Ts, sa.L + oj * ld + oj, ld, tid);

@@ -350,6 +350,26 @@ def test_full_size_properties_darcy256(pkg):
     assert abs(F.logdet() - (ld + w.n * np.log(4.0))) < 1e-9 * abs(ld)
 
 
+def test_full_size_properties_elliptic512(pkg):
+    """BASELINE config[3] at full size (512 x 512 nodes, 256 blocks of 1024, 6.4 GB of factor):
+    size-independent properties; 256 device-Philox samples split as two ranks would draw them."""
+    w = pkg.workloads.make("elliptic512")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    mu = pkg.ldiv(F, w.rhs)
+    qn = abs(w.Q).sum(axis=1).max()
+    assert np.linalg.norm(w.Q @ mu - w.rhs) / (qn * np.linalg.norm(mu) + np.linalg.norm(w.rhs)) < 1e-14
+    rng = np.random.default_rng(1)
+    Z = rng.standard_normal((w.n, 2))
+    Xs = pkg.backward_solve(F, Z)
+    assert np.allclose(np.sum(Xs * (w.Q @ Xs), axis=0), np.sum(Z * Z, axis=0), rtol=1e-9)
+    B = rng.standard_normal((w.n, 2))
+    assert rel(pkg.backward_solve(F, pkg.forward_solve(F, B)), pkg.ldiv(F, B)) < 1e-13
+    # sample ids 128..255 drawn alone equal the second half of one 256-sample call (rank invariance)
+    Xa = F.sample(256, mean=mu, seed=9)
+    Xb = F.sample(128, mean=mu, seed=9, first_id=128)
+    assert np.array_equal(Xa[:, 128:], Xb)
+
+
 def test_batch_of_problems_matches_one_by_one(pkg):
     """B independent problems on one pattern, factored / solved / sampled in lock step, equal
     the same problems handled one at a time (bitwise: same kernels, same order of operations)."""
