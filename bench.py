@@ -209,6 +209,9 @@ def main():
                        "sharding": "independent problems per rank, no data-path collective" if job.replicate
                        else f"one shared factor, rccl broadcast in {args.group}-block ranges, samples sharded"},
         }
+    if rank == 0:
+        free_b, total_b = torch.cuda.mem_get_info(local)
+        out["hbm_used_gb"] = round((total_b - free_b) / 1e9, 1)
     # ---- per-kernel roofline + parity + CPU baseline: rank 0, outside the timed region
     if rank == 0 and world == 1:
         import numpy as np
