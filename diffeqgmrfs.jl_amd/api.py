@@ -190,6 +190,74 @@ def gn_step(F: "TridiagonalCholeskyFactor", asm: PosteriorAssembler, q_values, Q
     return ldiv(F, rhs)
 
 
+class ConditionedGMRF:
+    """What `condition_on_observations(x, A, Q_eps, y; solver_blueprint)` returns in the reference's
+    problem loop (scripts/darcy/solve_darcy_gmrf-fem.jl:176-192), served by the block-tridiagonal
+    path: posterior precision Q + Q_eps A'A (assembled on the device), then `mean`, `rand`, `std`,
+    `logdet`.  One object per sparsity pattern; `update(a_values, y)` re-conditions on a new
+    observation matrix with the same pattern (the next problem of the data set) -- values only."""
+
+    def __init__(self, Q, mu, A, q_eps: float, y, n_blocks: int, device: int = 0):
+        Q = sp.csc_matrix(Q); Q.sort_indices()
+        A = sp.csr_matrix(A); A.sort_indices()
+        self.Q, self.q_eps, self.n_blocks = Q, float(q_eps), int(n_blocks)
+        self.mu = np.zeros(Q.shape[0]) if mu is None else np.ascontiguousarray(mu, dtype=np.float64)
+        self._qmu = Q @ self.mu
+        self.asm = PosteriorAssembler(Q, A, device=device)
+        self.F = TridiagonalCholeskyFactor(device=device)
+        self._analysed = False
+        self.update(A.data, y)
+
+    def update(self, a_values, y):
+        """Re-condition with new values of A (same pattern) and new observations y."""
+        self._vals = np.asarray(self.asm.precision(self.Q.data, a_values, self.q_eps))
+        if not self._analysed:
+            self.F.factor(self.precision_matrix(), self.n_blocks)      # symbolic analysis + first factor
+            self._analysed = True
+        else:
+            self.F.refactor(self._vals)
+        # information vector Q mu + Q_eps A' y  (gmrf_assemble_rhs with x = 0, obs_diff = y)
+        self._rhs = self.asm.rhs(self._qmu, a_values, np.zeros(self.asm.n), y, self.q_eps)
+        self._mean = None
+        self._csr = None
+        return self
+
+    def precision_matrix(self):
+        """Posterior precision as a SciPy CSC matrix (`to_matrix(precision_map(x_cond))`)."""
+        P = self.asm.pattern.copy()
+        P.data = self._vals.copy()
+        return P
+
+    def mean(self):
+        if self._mean is None:
+            self._mean = ldiv(self.F, self._rhs)
+        return self._mean
+
+    def rand(self, k: int = 1, seed: int = 0x5EED, first_id: int = 0):
+        """n x k samples  mean + L^-T z  with device Philox normals (`rand(rng, x_cond)`)."""
+        return self.F.sample(k, mean=self.mean(), seed=seed, first_id=first_id)
+
+    def var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED):
+        """Marginal variances: "exact" selected inversion, or "rbmc" = the reference's RBMCStrategy(k)."""
+        if method == "exact":
+            return self.F.marginal_var("exact")
+        if self._csr is None:
+            self._csr = CsrMatrix(self.precision_matrix())
+        return self.F.marginal_var(method, k=k, seed=seed, Q=self._csr)
+
+    def std(self, method: str = "exact", k: int = 50, seed: int = 0x5EED):
+        return np.sqrt(self.var(method, k, seed))
+
+    def logdet(self) -> float:
+        return self.F.logdet()
+
+
+def condition_on_observations(Q, mu, A, q_eps: float, y, n_blocks: int, device: int = 0) -> ConditionedGMRF:
+    """Python twin of the reference's `condition_on_observations(x, A, Q_eps, y)` for a GMRF
+    N(mu, Q^-1) whose posterior precision is block tridiagonal with `n_blocks` blocks."""
+    return ConditionedGMRF(Q, mu, A, q_eps, y, n_blocks, device)
+
+
 class _LazyBlocks(Sequence):
     """`F.chos` / `F.Cs`: dense blocks copied from the device on access."""
 

@@ -170,6 +170,32 @@ def darcy(n_xy: int, rows_per_block: int = 4, q_eps: float = 1e8, beta: float = 
                      "nnz": int(Q.nnz), "mesh": f"{n_xy}x{n_xy} P1"})
 
 
+def darcy_conditioning(n_xy: int, rows_per_block: int = 4, q_eps: float = 1e8, beta: float = 1.0,
+                       seeds=(523802340,)):
+    """The ingredients of the reference's Darcy problem loop (scripts/darcy/solve_darcy_gmrf-fem.jl:
+    176-192) on the mesh of `darcy`: the Matern prior precision Q0 (mean zero), and per seed the
+    observation pair (A = Dirichlet-modified Darcy stiffness for that coefficient field, y = load) --
+    all A share one sparsity pattern.  Returns (Q0, [(A, y), ...], n_blocks)."""
+    obs = []
+    pat = None
+    for seed in seeds:
+        coeff = darcy_coefficient(seed)
+        lumped, G, D, (X, Y) = p1_unit_square(n_xy, n_xy, coeff)
+        on_bnd = (X == 0.0) | (X == 1.0) | (Y == 0.0) | (Y == 1.0)
+        Dd, fd = _dirichlet(D, beta * lumped.copy(), np.flatnonzero(on_bnd))
+        if pat is None:
+            pat = abs(p1_unit_square(n_xy, n_xy, lambda x, y: np.ones_like(x))[2]).tocsr() + sp.identity(n_xy * n_xy)
+            pat.data[:] = 0.0
+        Dd = (Dd + pat).tocsr()                   # explicit zeros: one pattern for every coefficient field
+        Dd.sort_indices()
+        obs.append((Dd, fd))
+    kappa = math.sqrt(8.0 * 2.0) * math.sqrt(n_xy)
+    lumped, G, _, _ = p1_unit_square(n_xy, n_xy)
+    Q0 = matern_precision_2d(lumped, G, kappa, alpha=3).tocsc()
+    Q0.sort_indices()
+    return Q0, obs, n_xy // rows_per_block
+
+
 def elliptic(n_xy: int, rows_per_block: int = 2, bnd_noise: float = 1e12,
              fem_noise: float = 3e13) -> Workload:
     """Nonlinear elliptic -Lap u + u^3 = f (Chen et al.) linearised at the true solution:

@@ -264,6 +264,20 @@ def gn_step(Q, J, Qx_prior: np.ndarray, x: np.ndarray, obs_diff: np.ndarray, noi
     return ldiv(tridiagonal_cholesky(A, N_blocks), gn_rhs(Qx_prior, J, x, obs_diff, noise))
 
 
+def condition_on_observations(Q, mu, A, q_eps: float, y, N_blocks: int):
+    """Linear-Gaussian conditioning as the reference's scripts use it
+    (`condition_on_observations(x, A, Q_eps, ys)`, scripts/darcy/solve_darcy_gmrf-fem.jl:188-189; the
+    function itself lives in the absent GaussianMarkovRandomFields.jl, semantics per SURVEY 8b):
+    posterior precision Q + q_eps A'A, mean = Q_post^-1 (Q mu + q_eps A' y).
+    Returns (Q_post, factor, mean)."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    Qp = assemble_posterior(Q, A, q_eps)
+    F = tridiagonal_cholesky(Qp, N_blocks)
+    mu = np.zeros(Qp.shape[0]) if mu is None else mu
+    return Qp, F, ldiv(F, Q @ mu + q_eps * (A.T @ y))
+
+
 def reconstruct(F: TridiagonalCholeskyFactor) -> np.ndarray:
     """Dense L L^T from the block factor (tests only, small n)."""
     N, bs = F.n_blocks, F.block_size

@@ -508,3 +508,29 @@ def test_posterior_assembly_and_gauss_newton_on_device(pkg):
         assert x_dev.is_cuda
         assert rel(x_dev.cpu().numpy(), x_ora) < 1e-9
         xo = x_ora
+
+
+def test_condition_on_observations_problem_loop(pkg):
+    """The reference's Darcy problem loop (scripts/darcy/solve_darcy_gmrf-fem.jl:176-192) through the
+    Python twin of `condition_on_observations`: condition, mean, std, rand; then the next coefficient
+    field with values only (same pattern)."""
+    Q0, obs, N = pkg.workloads.darcy_conditioning(32, seeds=(523802340, 11))
+    (A, y), (A2, y2) = obs
+    x = pkg.condition_on_observations(Q0, None, A, 1e8, y, N)
+    Qp, Fo, mu_o = O.condition_on_observations(Q0, None, A, 1e8, y, N)
+    w = pkg.workloads.make("darcy32")                  # same posterior as the packaged workload
+    assert abs(x.precision_matrix() - Qp).max() / abs(Qp).max() < 1e-15
+    assert rel(x.mean(), mu_o) < solve_tol(w)
+    vo = O.marginal_variances_exact(Fo)
+    assert np.max(np.abs(x.std() - np.sqrt(vo)) / np.sqrt(vo)) < 1e-9
+    assert abs(x.logdet() - O.logdet(Fo)) < 1e-10 * abs(O.logdet(Fo))
+    s_rb = x.std("rbmc", k=50, seed=3)                 # RBMCStrategy(50) of the reference
+    assert np.median(np.abs(s_rb - np.sqrt(vo)) / np.sqrt(vo)) < 0.05
+    X = x.rand(8, seed=5)
+    Z = x.F.normals(8, seed=5)
+    assert rel(X, O.sample(Fo, mu_o, Z)) < solve_tol(w)
+    # next problem: new coefficient field, same pattern -> values only
+    x.update(A2.data, y2)
+    Qp2, Fo2, mu2 = O.condition_on_observations(Q0, None, A2, 1e8, y2, N)
+    assert rel(x.mean(), mu2) < solve_tol(w)
+    assert np.max(np.abs(x.var() - O.marginal_variances_exact(Fo2)) / O.marginal_variances_exact(Fo2)) < 1e-9

@@ -191,3 +191,19 @@ def test_gauss_newton_step_restatement(pkg):
     # the step minimises the linearised objective: its gradient vanishes at xn
     grad = gn["Q"] @ xn - gn["Qx_prior"] + gn["noise"] * (J.T @ (J @ (xn - x) + r))
     assert np.linalg.norm(grad) / np.linalg.norm(rhs) < 1e-12
+
+
+def test_conditioning_restatement(pkg):
+    # posterior precision Q + q A'A and mean Q_post^-1 (Q mu + q A' y), against dense algebra
+    Q0, obs, N = pkg.workloads.darcy_conditioning(16)
+    A, y = obs[0]
+    mu0 = np.linspace(0.0, 1.0, Q0.shape[0])
+    Qp, F, mu = O.condition_on_observations(Q0, mu0, A, 1e4, y, N)
+    Ad, Qd = A.toarray(), Q0.toarray()
+    Pd = Qd + 1e4 * Ad.T @ Ad
+    assert np.max(np.abs(Qp.toarray() - Pd)) / np.max(np.abs(Pd)) < 1e-15
+    want = np.linalg.solve(Pd, Qd @ mu0 + 1e4 * Ad.T @ y)
+    assert rel(mu, want) < 1e-9
+    # equivalent form mu + Q_post^-1 A' q (y - A mu)   
+    alt = mu0 + np.linalg.solve(Pd, 1e4 * Ad.T @ (y - Ad @ mu0))
+    assert rel(mu, alt) < 1e-9
