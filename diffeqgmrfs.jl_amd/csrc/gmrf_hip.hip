@@ -134,6 +134,14 @@ struct gmrf_handle {
     bool eager = false;
     bool split_step = false;           // use the three-launch panel step also for batch 1 (experiment)
     bool sweep_no_gemm = false;        // keep 64-multiples of right-hand sides on sweep_mm (comparison)
+    bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
+    // second branch of the captured factor graph: the inverse assembly of a block's first half runs
+    // beside the panel chain of its second half (see potrf_block)
+    hipStream_t aux = nullptr;
+    hipStream_t gemm_stream = nullptr; // stream gemm() launches on (h->stream unless inside the aux branch)
+    bool capturing = false;
+    std::vector<hipEvent_t> fork_events;
+    size_t fork_next = 0;
     hipGraphExec_t factor_graph = nullptr;
     int64_t factor_graph_i0 = -1, factor_graph_i1 = -1;
     std::map<int64_t, hipGraphExec_t> sweep_graphs;   // key = mode * 4096 + kp
@@ -214,7 +222,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     if (gemm_uses_big(a_t, g, batch * (int)h->B)) { pclass = b_n ? 7 : 6; pwork = -1.0; }
     else if (pclass == 0) pclass = a_t ? 12 : (b_n ? 11 : 0);
     ProfScope ps(h, pclass, pwork >= 0.0 ? pwork : flops);
-    HIPCHK(launch_gemm(h->stream, a_t, b_n, g, batch * (int)h->B));
+    HIPCHK(launch_gemm(h->gemm_stream ? h->gemm_stream : h->stream, a_t, b_n, g, batch * (int)h->B));
     return GMRF_OK;
 }
 
@@ -425,6 +433,51 @@ static gmrf_status load_values(gmrf_handle* h, const double* nzval) {
 }
 
 // ------------------------------------------------------------------------------------ numeric factor
+// Recursive doubling  X21 = -X22 (L21 X11)  over pairs of hh-wide diagonal blocks, levels hh = lo .. hi.
+// half: -1 all pairs, 0 / 1 only the pairs inside the first / second half of the block.
+static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double* T, int lo, int hi, int half) {
+    const int bsp = (int)h->bsp;
+    const int64_t ld = bsp;
+    const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
+    for (int hh = lo; hh <= hi && hh < bsp; hh *= 2) {
+        int pairs = bsp / (2 * hh), first = 0;
+        if (half >= 0) { pairs /= 2; first = half * pairs; }
+        if (pairs <= 0) continue;
+        const int64_t st = (int64_t)2 * hh * ld + 2 * hh, o = first * st;
+        // T21 = L21 * X11
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + o + (int64_t)hh * ld, ld, X + o, ld, 0.0,
+                  T + o + (int64_t)hh * ld, ld, pLX, pLX, pW, pairs, st, st, st));
+        // X21 = -X22 * T21
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + o + (int64_t)hh * ld + hh, ld,
+                  T + o + (int64_t)hh * ld, ld, 0.0, X + o + (int64_t)hh * ld, ld, pLX, pW, pLX, pairs, st, st, st));
+    }
+    return GMRF_OK;
+}
+
+// The top level (hh = bsp / 2, one pair) in its two halves: T21 = L21 X11, then X21 = -X22 T21.
+static gmrf_status doubling_top(gmrf_handle* h, double* L, double* X, double* T, bool first_product, bool second_product) {
+    const int bsp = (int)h->bsp, hh = bsp / 2;
+    const int64_t ld = bsp;
+    const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
+    if (first_product)
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld, ld, X, ld, 0.0, T + (int64_t)hh * ld, ld,
+                  pLX, pLX, pW));
+    if (second_product)
+        GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld, T + (int64_t)hh * ld, ld, 0.0,
+                  X + (int64_t)hh * ld, ld, pLX, pW, pLX));
+    return GMRF_OK;
+}
+
+static gmrf_status fork_event(gmrf_handle* h, hipEvent_t* out) {
+    if (h->fork_next == h->fork_events.size()) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->fork_events.push_back(e);
+    }
+    *out = h->fork_events[h->fork_next++];
+    return GMRF_OK;
+}
+
 static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, double* T, int blk_id) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
@@ -437,6 +490,16 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
     const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
     const int pw = (!fused && nt >= 8) ? 4 : nt;           // panel width in tiles
+    // Opt-in (set_eager bit 4): inside a captured graph the block forks once its first half is
+    // factored: a second branch assembles the inverse of that half and the top-level product
+    // T21 = L21 X11 (everything they read is final) while this branch runs the latency-bound panel
+    // chain of the second half.  Measured on darcy256: the branches do overlap (3.4 ms of a 42 ms
+    // factor) but the two cross-queue dependencies per block cost as much, and with several handles
+    // the extra streams share hardware queues (3 x 32: 22.6 k -> 19.3 k solves/s).  Off by default.
+    const bool overlap = h->capturing && h->fork_graph && nt >= 8;
+    if (overlap && !h->aux) HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (overlap) { GCHK(fork_event(h, &ev_fork)); GCHK(fork_event(h, &ev_join)); }
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
@@ -478,18 +541,25 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             GCHK(gemm(h, false, false, mr * 64, mr * 64, pw * 64, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, Sr, ld, sa.pLX, sa.pLX,
                       sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * 64.0 * 64.0 * (pw * 64.0) * (mr * (mr + 1) / 2) * (double)h->B));
         }
+        if (overlap && j + 1 == nt / 2) {
+            HIPCHK(hipEventRecord(ev_fork, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->aux, ev_fork, 0));
+            h->gemm_stream = h->aux;
+            gmrf_status st = doubling_levels(h, L, X, T, 64, bsp / 4, 0);
+            if (st == GMRF_OK) st = doubling_top(h, L, X, T, true, false);
+            h->gemm_stream = nullptr;
+            GCHK(st);
+        }
     }
-    // X = L^-1 by recursive doubling over the 64-wide diagonal inverses
-    for (int hh = 64; hh < bsp; hh *= 2) {
-        const int pairs = bsp / (2 * hh);
-        const int64_t st = (int64_t)2 * hh * ld + 2 * hh;
-        // T21 = L21 * X11
-        const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
-        GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld, ld, X, ld, 0.0,
-                  T + (int64_t)hh * ld, ld, pLX, pLX, pW, pairs, st, st, st));
-        // X21 = -X22 * T21
-        GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld,
-                  T + (int64_t)hh * ld, ld, 0.0, X + (int64_t)hh * ld, ld, pLX, pW, pLX, pairs, st, st, st));
+    // X = L^-1 by recursive doubling over the 64-wide diagonal inverses (the part not done beside
+    // the panel chain above)
+    if (overlap) {
+        GCHK(doubling_levels(h, L, X, T, 64, bsp / 4, 1));       // second half, levels below the top
+        HIPCHK(hipEventRecord(ev_join, h->aux));
+        HIPCHK(hipStreamWaitEvent(h->stream, ev_join, 0));       // T21 of the top level is ready
+        GCHK(doubling_top(h, L, X, T, false, true));
+    } else {
+        GCHK(doubling_levels(h, L, X, T, 64, bsp / 2, -1));
     }
     return GMRF_OK;
 }
@@ -563,7 +633,9 @@ static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
         if (h->factor_graph) { (void)hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        h->capturing = true; h->fork_next = 0;
         gmrf_status s = factor_blocks_range(h, i0, i1);
+        h->capturing = false;
         hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (s != GMRF_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
         HIPCHK(e);
@@ -771,6 +843,8 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (auto e : h->fork_events) (void)hipEventDestroy(e);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return GMRF_OK;
@@ -811,6 +885,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 2) != 0) != h->split_step) { destroy_graphs(h); h->split_step = (eager & 2) != 0; }
     if (((eager & 4) != 0) != h->sweep_no_gemm) { destroy_graphs(h); h->sweep_no_gemm = (eager & 4) != 0; }
     if (((eager & 8) != 0) != h->dense_g1) { destroy_graphs(h); h->dense_g1 = (eager & 8) != 0; }
+    if (((eager & 16) != 0) != h->fork_graph) { destroy_graphs(h); h->fork_graph = (eager & 16) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }

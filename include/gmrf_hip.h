@@ -213,7 +213,8 @@ gmrf_status gmrf_bt_stats(gmrf_handle* h, gmrf_stats* out);
 gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
 /* bit 0: plain stream launches instead of replaying captured HIP graphs; bit 1: three-launch
  * panel step also for batch 1; bit 2: keep 64-multiples of right-hand sides on sweep_mm;
- * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse. */
+ * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse; bit 4: second
+ * branch in the captured factor graph (inverse assembly beside the panel chain; experiment). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 

@@ -171,6 +171,21 @@ def test_panel_sweeps_through_gemm_match_sweep_kernel(pkg):
     assert rel(a[0][7].T, O.ldiv(Fo, B[7].T)) < solve_tol(w)
 
 
+def test_forked_factor_graph_matches_single_branch(pkg):
+    """Opt-in (set_eager bit 4): for blocks of 8+ tiles the captured factor graph assembles the inverse
+    of a block's first half on a second branch beside the panel chain of the second half.  Same
+    kernels on the same data: bitwise equal to the single-branch graph and to plain stream launches."""
+    w = pkg.workloads.make("burgers512x64")
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    a = pkg.ldiv(F, w.rhs); la = F.chos[40].copy(); xa = F.get_block(pkg._cabi.BLOCK_LINV, 40)
+    for flags in (16, 1, 16):
+        F.set_eager(flags)
+        for _ in range(2):                   # capture, then a replay of the forked graph
+            F.refactor(w.Q.data)
+            assert np.array_equal(pkg.ldiv(F, w.rhs), a) and np.array_equal(F.chos[40], la)
+            assert np.array_equal(F.get_block(pkg._cabi.BLOCK_LINV, 40), xa)
+
+
 def test_extract_blocks_route_and_padding(pkg):
     # block size 40 is padded to 64 inside the library; blocks come from extract_blocks
     w = pkg.workloads.random_block_tridiagonal(5, 40, seed=3)

@@ -15,6 +15,7 @@ for spec in (sys.argv[2] if len(sys.argv) > 2 else "1x8,2x4,2x8,4x4").split(",")
         with torch.cuda.stream(st):
             eng = post.HipEngine(pkg, w, batch=B)
             job = post.ShardedPosterior(eng, k_samples=64, replicate_factor=True)
+            if os.environ.get('GMRF_EAGER_FLAGS'): eng.F.set_eager(int(os.environ['GMRF_EAGER_FLAGS']))
             job.prepare()
             job.step(0)
         jobs.append((st, eng, job))
