@@ -230,8 +230,19 @@ def main():
         else:
             achieved = work[dom] / (ms[dom] * 1e-3) / 1e9
             peak, unit = PEAK_HBM_GBPS, "GB/s"
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this workload
+        # (profiles/README.md); null when the profile has no row for it
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            key = next((k for k in prof["kernels"] if k.replace(" ", "").startswith(name.replace(" ", "").rstrip(">"))), None)
+            if key and w.name == "darcy256" and batch == 32:
+                traffic = prof["kernels"][key]["read_bytes_per_launch"] + prof["kernels"][key]["write_bytes_per_launch"]
+                traffic_src = "profiles/r01_hbm_traffic.json: " + key
+        except Exception:
+            pass
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
-                           "frac": achieved / peak, "traffic": None, "kernel": name,
+                           "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel": name,
                            "launches_per_step": int(cnt[dom]), "avg_launch_us": 1e3 * ms[dom] / max(cnt[dom], 1)}
         out["kernels"] = {KERNEL_CLASSES[c][0]: {"ms_per_step": ms[c], "launches": int(cnt[c]),
                                                   ("tflops" if KERNEL_CLASSES[c][1] == "mfma" else "gbps"):

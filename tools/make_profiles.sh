@@ -12,7 +12,7 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv 
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem > /dev/null 2> $OUT/pmc_write.err || exit 1
 python3 $R/tools/trace_summary.py $(ls $OUT/trace/*/*kernel_trace.csv | head -1) 1 45 > $OUT/trace_by_grid.txt
 python3 $R/tools/trace_summary.py $(ls $OUT/trace1/*/*kernel_trace.csv | head -1) 1 45 > $OUT/trace1_by_grid.txt
-python3 $R/tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) > $OUT/pmc_table.md
+python3 $R/tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/hbm_traffic.json > $OUT/pmc_table.md
 cp $(ls $OUT/trace/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_3streams.csv
 cp $(ls $OUT/trace1/*/*kernel_stats.csv | head -1) $OUT/kernel_stats_1stream.csv
 rm -rf $OUT/trace $OUT/trace1 $OUT/pmc_fetch $OUT/pmc_write
