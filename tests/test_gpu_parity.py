@@ -230,6 +230,50 @@ def test_degenerate_shapes(pkg):
     assert rel(pkg.ldiv(F2, w2.rhs), O.ldiv(O.tridiagonal_cholesky(w2.Q, 40), w2.rhs)) < 1e-12
 
 
+@pytest.mark.parametrize("bs", [1, 3, 40, 64, 65, 130, 200, 520])
+def test_ragged_block_sizes_and_panel_widths(pkg, bs):
+    """Block sizes around the 64 / 128 / 512 padding boundaries (bs = 1: scalar tridiagonal),
+    chains of 1, 2 and 5 blocks, 1 / 3 / 65 / 130 right-hand sides: factor blocks, the three solves,
+    samples with given z, exact variances and logdet against the oracle."""
+    for N in (1, 2, 5):
+        w = pkg.workloads.random_block_tridiagonal(N, bs, seed=100 + bs + N, density=min(1.0, 6.0 / bs))
+        F = pkg.tridiagonal_cholesky(w.Q, N)
+        Fo = O.tridiagonal_cholesky(w.Q, N)
+        assert np.max(np.abs(np.tril(F.chos[N - 1]) - Fo.chos[N - 1])) / np.max(np.abs(Fo.chos[N - 1])) < TOL_FACTOR
+        if N > 1:
+            assert np.max(np.abs(F.Cs[N - 2] - Fo.Cs[N - 2])) <= TOL_FACTOR * max(1e-300, np.max(np.abs(Fo.Cs[N - 2])))
+        rng = np.random.default_rng(bs * 7 + N)
+        for k in (1, 3, 65, 130):
+            B = rng.standard_normal((w.n, k)) if k > 1 else rng.standard_normal(w.n)
+            assert rel(pkg.ldiv(F, B), O.ldiv(Fo, B)) < 1e-12
+            assert rel(pkg.forward_solve(F, B), O.forward_solve(Fo, B)) < 1e-12
+            assert rel(pkg.backward_solve(F, B), O.backward_solve(Fo, B)) < 1e-12
+        Z = rng.standard_normal((w.n, 5))
+        mu = O.ldiv(Fo, w.rhs)
+        assert rel(F.sample(5, mean=mu, z=Z), O.sample(Fo, mu, Z)) < 1e-12
+        vo = O.marginal_variances_exact(Fo)
+        assert np.max(np.abs(F.marginal_var("exact") - vo) / vo) < 1e-10
+        assert abs(F.logdet() - O.logdet(Fo)) < 1e-11 * max(1.0, abs(O.logdet(Fo)))
+
+
+def test_batch_with_padded_blocks_on_the_two_level_path(pkg):
+    # bs = 520 is padded to 1024 (16 tiles): batches take the 256-column panel path on padded blocks
+    w = pkg.workloads.random_block_tridiagonal(3, 520, seed=31, density=0.012)
+    vals = np.stack([w.Q.data, w.Q.data * 0.5, w.Q.data * 3.0])
+    rhs = np.stack([w.rhs, -w.rhs, 2.0 * w.rhs])
+    Fb = pkg.TridiagonalCholeskyFactor(batch=3).factor(w.Q, 3, values=vals)
+    mu = Fb.solve_batch(rhs[:, None, :])[:, 0, :]
+    Fo = O.tridiagonal_cholesky(w.Q, 3)
+    x0 = O.ldiv(Fo, w.rhs)
+    for p, f in enumerate((1.0, -2.0, 2.0 / 3.0)):
+        assert rel(mu[p], f * x0) < 1e-12
+    vb = Fb.marginal_var("exact")
+    vo = O.marginal_variances_exact(Fo)
+    assert np.max(np.abs(vb[1] - 2.0 * vo) / vo) < 1e-9
+    Fb.select_problem(2)
+    assert abs(Fb.logdet() - (O.logdet(Fo) + w.n * np.log(3.0))) < 1e-10 * abs(O.logdet(Fo))
+
+
 @pytest.mark.parametrize("name", ["darcy64", "burgers64x8"])
 def test_sparse_and_dense_coupling_product_agree(pkg, name):
     """C = B X^T: the sparse kernel (spmm_bxt, default for FEM coupling blocks) against the dense
