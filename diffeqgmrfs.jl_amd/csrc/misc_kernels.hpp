@@ -100,10 +100,10 @@ __global__ void fill_normals_panel(double* __restrict__ P, int64_t n_pad, int bs
 // 2 bs^3 and the kernel is bound by writing C):
 //   C[r][c] = sum_{(r,j) in B} B[r][j] X[c][j]          X lower triangular, zeros stored above
 // A thread owns one row r of B: it loads the row's (at most KM) entries once into registers, then
-// walks 64 columns c; for entry t the 64 lanes of a wave (consecutive r) read X[c][j_t(r)], which
+// walks cw columns c; for entry t the 64 lanes of a wave (consecutive r) read X[c][j_t(r)], which
 // for a stencil coupling are consecutive addresses of one row of X.  No LDS, every load of the c
 // loop is independent.  The lower blocks' entry lists are stored row by row (rowptr).
-// grid ((bsp - cm) / 64, ceil(rm / 256), problems).
+// grid ((bsp - cm) / cw, ceil(rm / 256), problems).
 struct BxtArgs {
     const int* rowptr;        // [bsp + 1], local row -> range in keys / vals
     const uint64_t* keys;     // row << 32 | col
@@ -113,12 +113,13 @@ struct BxtArgs {
     double* C;
     int64_t ld, pX, pC;
     int cm, rm;
+    int cw;                   // columns of C per workgroup (16, 32 or 64: enough workgroups for a lone problem)
 };
 
 template <int KM>
 __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
     const int r = (int)blockIdx.y * 256 + (int)threadIdx.x;
-    const int c0 = a.cm + (int)blockIdx.x * 64;
+    const int c0 = a.cm + (int)blockIdx.x * a.cw;
     const double* __restrict__ X = a.X + (int64_t)blockIdx.z * a.pX;
     double* __restrict__ C = a.C + (int64_t)blockIdx.z * a.pC;
     const double* __restrict__ vals = a.vals + (int64_t)blockIdx.z * a.n_entries;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
     const int tid = (int)threadIdx.x;
     const int wr = tid >> 4, wc = tid & 15;        // write-out: 16 lanes per row, 16 rows per pass
     const int rbase = (int)blockIdx.y * 256;
-    for (int c = c0; c < c0 + 64; c += 16) {
+    for (int c = c0; c < c0 + a.cw; c += 16) {
         const double* xr = X + (int64_t)c * a.ld;
         double acc[16];
 #pragma unroll
