@@ -134,6 +134,7 @@ struct gmrf_handle {
     bool eager = false;
     bool split_step = false;           // use the three-launch panel step also for batch 1 (experiment)
     bool sweep_no_gemm = false;        // keep 64-multiples of right-hand sides on sweep_mm (comparison)
+    unsigned long long* dbg_stamps = nullptr;   // test hook: phase stamps of the fused panel step
     bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
@@ -503,7 +504,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
-        sa.info = h->d_info; sa.blk = blk_id;
+        sa.info = h->d_info; sa.blk = blk_id; sa.dbg = h->dbg_stamps;
         sa.pS = (int64_t)bsp * bsp; sa.pLX = (int64_t)bsp * bsp * h->N; sa.blk_per_problem = (int)h->N;
         const int m = nt - j - 1;
         const int cend = std::min(nt, (j / pw + 1) * pw);  // first column tile outside this panel
@@ -1843,6 +1844,7 @@ gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
     out[0] = g_tile_us;
     for (int i = 0; i < 17; ++i) out[1 + i] = (double)(g_tile_stamps[i] - g_tile_stamps[15]);
     if (n >= 24) for (int i = 0; i < 3; ++i) out[18 + i] = (double)(g_tile_stamps[20 + i] - g_tile_stamps[15]);
+    if (n >= 30) for (int i = 0; i < 6; ++i) out[24 + i] = (double)(g_tile_stamps[24 + i] - g_tile_stamps[24]);   // fused step phases (gmrf_test_potrf_block)
     return GMRF_OK;
 }
 
@@ -1852,6 +1854,11 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
     GCHK(gmrf_bt_create(device, nullptr, &h));
     h->N = 1; h->n = bs; h->bs = bs; h->bsp = bs; h->n_pad = bs; h->B = 1;
     gmrf_status s = alloc_factor(h);
+    unsigned long long* dst = nullptr;
+    if (s == GMRF_OK && hipMalloc(&dst, 8 * sizeof(unsigned long long)) == hipSuccess) {
+        (void)hipMemset(dst, 0, 8 * sizeof(unsigned long long));
+        h->dbg_stamps = dst;
+    }
     if (s == GMRF_OK) {
         hipError_t e = hipMemcpyAsync(h->d_S, S, sizeof(double) * bs * bs, hipMemcpyHostToDevice, h->stream);
         if (e == hipSuccess) s = potrf_block(h, h->d_S, h->d_L, h->d_Linv, h->d_T, 1);
@@ -1862,8 +1869,10 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
             (void)hipMemcpyAsync(Linv, h->d_Linv, sizeof(double) * bs * bs, hipMemcpyDeviceToHost, h->stream);
             if (hipStreamSynchronize(h->stream) != hipSuccess) s = GMRF_ERR_HIP;
             if (info) *info = hi;
+            if (dst) (void)hipMemcpy(g_tile_stamps + 24, dst, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         }
     }
+    if (dst) (void)hipFree(dst);
     gmrf_bt_destroy(h);
     return s;
 }

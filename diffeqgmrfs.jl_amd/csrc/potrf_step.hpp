@@ -278,26 +278,28 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
     // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
     // eps * cond(16x16 block); the cheaper recursive doubling X21 = -X22 (L21 X11) multiplies two
     // computed inverses and was measured 20-100x less accurate for cond(tile) >= 1e5.
+    // Wave J owns block column J: everything block (I, J) reads was written by the same wave
+    // (X[K][J], its scratch) or before the last barrier (L, the diagonal inverses 0..2), so block
+    // rows 1 and 2 need no workgroup barrier -- LDS operations of one wave are served in order.
+    // Wave 3 meanwhile inverts the last diagonal block; one barrier, then block row 3.
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
-    if (wave == 3) inv16(Ts, rinvs, Xs, 48, lane);
-#pragma unroll
-    for (int I = 1; I < 4; ++I) {
-        // wave J < I owns block (I, J)
-        const int J = wave;
-        double* Wm = Wk + wave * 16 * 18;
-        if (J < I) {
-            v4d t = zero;
-            for (int K = J; K < I; ++K)
-                t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
-            store_d16(Wm, 18, t, li, lq);
-        }
-        __syncthreads();            // also orders wave 3's inv16(48) before its use at I = 3
-        if (J < I) {
-            v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Wm, 18, zero, true, li, lq);
-            store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
-        }
-        __syncthreads();
+    double* Wm = Wk + wave * 16 * 18;
+    auto block_ij = [&](int I, int J) {
+        v4d t = zero;
+        for (int K = J; K < I; ++K)
+            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+        store_d16(Wm, 18, t, li, lq);
+        const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Wm, 18, zero, true, li, lq);
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
+    };
+    if (wave == 3) {
+        inv16(Ts, rinvs, Xs, 48, lane);
+    } else {
+        for (int I = wave + 1; I < 3; ++I) block_ij(I, wave);
     }
+    __syncthreads();
+    if (wave < 3) block_ij(3, wave);
+    __syncthreads();
     TILE_STAMP(14);
 }
 
@@ -331,6 +333,7 @@ struct StepArgs {
     int64_t pS, pLX;      // per-problem strides of S and of L / X (blockIdx.y)
     int blk_per_problem;  // reported id = blk + blockIdx.y * blk_per_problem
     int cend;             // potrf_update: column tiles j+1 .. cend-1 only (nt: the whole trailing block)
+    unsigned long long* dbg;   // diagnostic stamps of workgroup 1 of step 0 (tests), else nullptr
 };
 
 // Fused panel step: grid.x = 1 + m (m + 1) / 2, m = nt - j - 1.  Workgroup 0 factors and inverts
@@ -382,8 +385,11 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
     side.ld = ld; side.stamps = nullptr;
     __syncthreads();
+    const bool stamp = sa.dbg && sa.j == 0 && w == 1 && tid == 0 && blockIdx.y == 0;
+    if (stamp) sa.dbg[0] = __builtin_amdgcn_s_memtime();
     bool bad = false;
     tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+    if (stamp) sa.dbg[1] = __builtin_amdgcn_s_memtime();
     if (w == 0) {
         if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
         tile_s2g(Ts, sa.L + oj * ld + oj, ld, tid);
@@ -416,6 +422,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
             }
         }
     }
+    if (stamp) sa.dbg[2] = __builtin_amdgcn_s_memtime();
     __syncthreads();                                   // every wave is done reading As / Bs
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
@@ -423,6 +430,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
         if (c != r) store_d16(Bs + (16 * wave) * TLD + 16 * Jb, TLD, lc[Jb], li, lq);
     }
     __syncthreads();
+    if (stamp) sa.dbg[3] = __builtin_amdgcn_s_memtime();
     if (c == sa.j + 1) tile_s2g(As, sa.L + (int64_t)r * 64 * ld + oj, ld, tid);
     // ---- S[r,c] -= Lr Lc^T ; wave owns rows 16*wave.., on a diagonal tile only Jb <= wave matters
     const double* Lcs = (c != r) ? Bs : As;
@@ -446,6 +454,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
             }
         }
     }
+    if (stamp) sa.dbg[4] = __builtin_amdgcn_s_memtime();
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
         if (Jb < jb_end) {
@@ -454,6 +463,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
                 Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
         }
     }
+    if (stamp) sa.dbg[5] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------------------------------
