@@ -210,9 +210,17 @@ struct SideLoad {          // global 64x64 tiles staged into LDS by waves 1-3 du
 #define TILE_STAMP(i) do { if (side.stamps && tid == 0) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
 __device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int64_t ld, double* s, int t192) {
-    for (int idx = t192; idx < 2048; idx += 192) {
-        const int r = idx >> 5, c = (idx & 31) * 2;
-        *reinterpret_cast<v2d*>(s + r * TLD + c) = *reinterpret_cast<const v2d*>(g + (int64_t)r * ld + c);
+    // all 11 loads of a thread are in flight before the first LDS store (one memory latency, not 11)
+    v2d v[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int idx = t192 + 192 * i;
+        if (idx < 2048) v[i] = *reinterpret_cast<const v2d*>(g + (int64_t)(idx >> 5) * ld + (idx & 31) * 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int idx = t192 + 192 * i;
+        if (idx < 2048) *reinterpret_cast<v2d*>(s + (idx >> 5) * TLD + (idx & 31) * 2) = v[i];
     }
 }
 
