@@ -37,6 +37,7 @@ PEAK_HBM_GBPS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec (6.3-6.5 TB/
 KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_stats)
     0: ("gemm_f64_mfma<false,false>", "mfma"),   # 64 x 64 tile GEMM, B stored [n][k]
     11: ("gemm_f64_mfma<false,true>", "mfma"),   # 64 x 64 tile GEMM, B stored [k][n]
+    13: ("gemm_f64_ll", "mfma"),                 # 32 x 32 tile GEMM of launches with <= 128 tiles of 64 x 64
     6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
     7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
     1: ("potrf_step<false>", "mfma"),       # tile Cholesky + inverse (latency-bound, B workgroups)

@@ -415,6 +415,120 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Low-latency kernel for launches that leave most CUs idle (one problem: 64 .. 78 tiles of 64 x 64
+// on 256 CUs, every tile a serial K loop bound by ONE CU's matrix pipes): 32 x 32 output tiles, so
+// the same product spreads over four times as many CUs; 4 waves, one 16 x 16 MFMA tile each.
+// A K step is then ~0.25 us of MFMAs, far less than a memory latency: operand tiles are requested
+// THREE steps ahead into a ring of three register sets and reach the other LDS buffer one step
+// ahead.  Same fragment scheme and summation order per output element as gemm_f64_mfma (bitwise
+// identical results; skipped K ranges hold exact zeros).  K must be a multiple of 32.
+constexpr int GEMM_LL = 32;
+
+template <bool A_T, bool B_N>
+__global__ __launch_bounds__(256, 2) void gemm_f64_ll(GemmArgs g) {
+    constexpr int BT = GEMM_LL, BK = 32, LD = BK + 4;
+    int bm, bn, z;
+    gemm_tile_order<BT>(g, bm, bn, z);
+    if (g.lower_only == 2 && bn > bm) return;
+    const int m0 = bm * BT, n0 = bn * BT;
+    const int zi = z % g.nb1, zp = z / g.nb1;
+    const double* __restrict__ A = g.A + (int64_t)zi * g.strideA + (int64_t)zp * g.pA;
+    const double* __restrict__ B = g.B + (int64_t)zi * g.strideB + (int64_t)zp * g.pB;
+    double* C = g.C + (int64_t)zi * g.strideC + (int64_t)zp * g.pC;
+    const double* Dm = g.D ? g.D + (int64_t)zp * g.pD : C;
+    const int64_t ldd = g.D ? g.ldd : g.ldc;
+
+    int kb = 0, ke = g.K;
+    if (g.tri & TRI_A_LOWER) ke = min(ke, m0 + BT);
+    if (g.tri & TRI_A_UPPER) kb = max(kb, m0);
+    if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
+    if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + BT);
+
+    __shared__ __attribute__((aligned(16))) double As0[2 * BT * LD];
+    __shared__ __attribute__((aligned(16))) double Bs0[2 * BT * LD];
+    const int t = threadIdx.x;
+    const int lane = t & 63, w = t >> 6;
+    const int wm = (w >> 1) * 16, wn = (w & 1) * 16;
+    const int li = lane & 15, lq = lane >> 4;
+
+    // staging: 512 16-byte pieces per operand tile, two per thread
+    auto load_tile = [&](bool rows_contig, const double* P, int64_t ld, int row0, int k0, v2d (&rg)[2]) {
+        if (!rows_contig) {      // stored [row][k]: 16 threads per row, rows r and r + 16
+            const double* p = P + (int64_t)(row0 + (t >> 4)) * ld + k0 + (t & 15) * 2;
+            rg[0] = *reinterpret_cast<const v2d*>(p);
+            rg[1] = *reinterpret_cast<const v2d*>(p + 16 * ld);
+        } else {                 // stored [k][row]: 16 threads per k, k and k + 16
+            const double* p = P + (int64_t)(k0 + (t >> 4)) * ld + row0 + (t & 15) * 2;
+            rg[0] = *reinterpret_cast<const v2d*>(p);
+            rg[1] = *reinterpret_cast<const v2d*>(p + 16 * ld);
+        }
+    };
+    auto store_tile = [&](bool rows_contig, double* sm, const v2d (&rg)[2]) {
+        if (!rows_contig) {
+            double* q = sm + (t >> 4) * LD + (t & 15) * 2;
+            *reinterpret_cast<v2d*>(q) = rg[0];
+            *reinterpret_cast<v2d*>(q + 16 * LD) = rg[1];
+        } else {
+            const int kk = t >> 4, r = (t & 15) * 2;
+            sm[r * LD + kk] = rg[0].x; sm[(r + 1) * LD + kk] = rg[0].y;
+            sm[r * LD + kk + 16] = rg[1].x; sm[(r + 1) * LD + kk + 16] = rg[1].y;
+        }
+    };
+
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int nkt = (ke > kb) ? (ke - kb) / BK : 0;
+    v2d ra[3][2], rb[3][2];
+    auto request = [&](int stage, v2d (&a2)[2], v2d (&b2)[2]) {
+        if (stage < nkt) {
+            load_tile(A_T, A, g.lda, m0, kb + stage * BK, a2);
+            load_tile(B_N, B, g.ldb, n0, kb + stage * BK, b2);
+        }
+    };
+    request(0, ra[0], rb[0]);
+    request(1, ra[1], rb[1]);
+    request(2, ra[2], rb[2]);
+    if (nkt > 0) {
+        store_tile(A_T, As0, ra[0]);
+        store_tile(B_N, Bs0, rb[0]);
+    }
+    __syncthreads();
+    // step kt: request stage kt + 3 into the set stage kt came from, multiply buffer kt & 1,
+    // write stage kt + 1 (set `nxt`) into the other buffer
+    auto step = [&](int kt, v2d (&a_far)[2], v2d (&b_far)[2], v2d (&a_nxt)[2], v2d (&b_nxt)[2]) {
+        const int cur = kt & 1;
+        request(kt + 3, a_far, b_far);
+        const double* as = As0 + cur * BT * LD + (wm + li) * LD + 2 * lq;
+        const double* bs = Bs0 + cur * BT * LD + (wn + li) * LD + 2 * lq;
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            const v2d a = *reinterpret_cast<const v2d*>(as + kg * 8);
+            const v2d b = *reinterpret_cast<const v2d*>(bs + kg * 8);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc, 0, 0, 0);
+        }
+        if (kt + 1 < nkt) {
+            store_tile(A_T, As0 + (cur ^ 1) * BT * LD, a_nxt);
+            store_tile(B_N, Bs0 + (cur ^ 1) * BT * LD, b_nxt);
+        }
+        __syncthreads();
+    };
+    for (int kt = 0; kt < nkt; kt += 3) {
+        step(kt, ra[0], rb[0], ra[1], rb[1]);
+        if (kt + 1 < nkt) step(kt + 1, ra[1], rb[1], ra[2], rb[2]);
+        if (kt + 2 < nkt) step(kt + 2, ra[2], rb[2], ra[0], rb[0]);
+    }
+    const double alpha = g.alpha, beta = g.beta;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm + lq + 4 * r;
+        const int col = n0 + wn + li;
+        double v = alpha * acc[r];
+        if (beta != 0.0) v += beta * Dm[(int64_t)row * ldd + col];
+        C[(int64_t)row * g.ldc + col] = v;
+    }
+}
+
 template <int BK>
 constexpr size_t gemm_lds_bytes() { return (size_t)4 * 64 * (BK + 4) * sizeof(double); }
 
@@ -427,6 +541,7 @@ inline hipError_t gemm_init() {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_lds_bytes<32>());
     GMRF_GEMM_ATTR(false, false) GMRF_GEMM_ATTR(false, true) GMRF_GEMM_ATTR(true, false) GMRF_GEMM_ATTR(true, true)
 #undef GMRF_GEMM_ATTR
+
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)gemm_f64_big<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)gemm_big_lds_bytes<false>());
@@ -513,6 +628,18 @@ inline bool gemm_uses_big(bool a_t, const GemmArgs& g, int batch) {
     return it->second;
 }
 
+// The 32 x 32 low-latency kernel: launches with so few 64 x 64 tiles that most CUs would idle.
+inline int& gemm_ll_policy() {       // 0: by launch size, 2: never (tests compare the two kernels)
+    static int v = 0;
+    return v;
+}
+inline bool gemm_uses_ll(const GemmArgs& g, int batch) {
+    if (gemm_ll_policy() == 2 || g.K % 32 || (g.tri & ~15) || g.stamps) return false;
+    const int64_t sx = g.N / GEMM_BN, sy = g.M / GEMM_BM;
+    const int64_t tiles = ((g.lower_only && g.M == g.N) ? sx * (sx + 1) / 2 : sx * sy) * batch;
+    return tiles <= 128;
+}
+
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
 inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, int batch) {
     if (g.M <= 0 || g.N <= 0 || batch <= 0) return hipSuccess;
@@ -529,6 +656,17 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
         return hipGetLastError();
     }
     const bool wide = (g.K % 32 == 0);
+    if (gemm_uses_ll(g, batch)) {
+        const int64_t lx = g.N / GEMM_LL, ly = g.M / GEMM_LL;
+        dim3 lgrid((unsigned)((tri_grid ? lx * (lx + 1) / 2 : lx * ly) * batch));
+#define GMRF_GEMM_LL(AT, BN) hipLaunchKernelGGL((gemm_f64_ll<AT, BN>), lgrid, block, 0, st, gs)
+        if (!a_t && !b_n) GMRF_GEMM_LL(false, false);
+        else if (!a_t && b_n) GMRF_GEMM_LL(false, true);
+        else if (a_t && !b_n) GMRF_GEMM_LL(true, false);
+        else GMRF_GEMM_LL(true, true);
+#undef GMRF_GEMM_LL
+        return hipGetLastError();
+    }
 #define GMRF_GEMM_LAUNCH(AT, BN)                                                                 \
     do {                                                                                         \
         if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>(), st, gs); \

@@ -221,7 +221,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     // statistics: launches of the 128 x 128 kernel are their own classes (6: B stored [n][k],
     // 7: B stored [k][n]) whoever calls, so that a class is one kernel symbol of a rocprof trace
     if (gemm_uses_big(a_t, g, batch * (int)h->B)) { pclass = b_n ? 7 : 6; pwork = -1.0; }
-    else if (pclass == 0) pclass = a_t ? 12 : (b_n ? 11 : 0);
+    else if (pclass == 0) pclass = gemm_uses_ll(g, batch * (int)h->B) ? 13 : (a_t ? 12 : (b_n ? 11 : 0));
     ProfScope ps(h, pclass, pwork >= 0.0 ? pwork : flops);
     HIPCHK(launch_gemm(h->gemm_stream ? h->gemm_stream : h->stream, a_t, b_n, g, batch * (int)h->B));
     return GMRF_OK;
@@ -1731,19 +1731,21 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     g.pA = g.pB = g.pC = 0; g.nb1 = 1;
     g.D = nullptr; g.ldd = 0; g.pD = 0;
     // tri_flags bit 2048: take the 128 x 128 kernel whatever the tile count
-    const bool force_big = (tri_flags & 2048) != 0;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~2048; g.lower_only = lower_only;
+    // bit 4096: the 32 x 32 low-latency kernel (taken by launches of <= 128 tiles of 64 x 64)
+    const bool force_big = (tri_flags & 2048) != 0, use_ll = (tri_flags & 4096) != 0;
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~(2048 | 4096); g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta;
     unsigned long long* dst = nullptr;
     HIPCHK(hipMalloc(&dst, 16));
     HIPCHK(hipMemset(dst, 0, 16));
-    g.stamps = force_big ? nullptr : dst;
+    g.stamps = (force_big || use_ll) ? nullptr : dst;
     HIPCHK(gemm_init());
-    const int saved = gemm_big_policy();
+    const int saved = gemm_big_policy(), saved_ll = gemm_ll_policy();
     gemm_big_policy() = force_big ? 1 : 2;
+    gemm_ll_policy() = use_ll ? 0 : 2;
     // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
     hipError_t le = launch_gemm(nullptr, transA != 0, transB == 0, g, 1);
-    gemm_big_policy() = saved;
+    gemm_big_policy() = saved; gemm_ll_policy() = saved_ll;
     HIPCHK(le);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));

@@ -79,8 +79,8 @@ typedef struct {
      *  4 csr_spmm                                5 other (scatter, pack, Philox, ...)
      *  6 gemm_f64_big<false>                     7 gemm_f64_big<true>   (128 x 128 tile GEMM)
      *  8 potrf_panel                             9 potrf_update
-     * 10 spmm_bxt (sparse C = B X^T)
-     * work = algorithmic flops (0-2, 6-9, 11, 12) or algorithmic bytes (3-5, 10). */
+     * 10 spmm_bxt (sparse C = B X^T)          13 gemm_f64_ll (32 x 32 tile GEMM of small launches)
+     * work = algorithmic flops (0-2, 6-9, 11-13) or algorithmic bytes (3-5, 10). */
 #define GMRF_KERNEL_CLASSES 16
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];

@@ -83,6 +83,20 @@ def test_gemm_big_matches_small_bitwise(lib, pkg):
     assert np.array_equal(c, d)
 
 
+LL = 4096    # gmrf_test_gemm: the 32 x 32 low-latency kernel
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("tri", [0, 1, 4])
+def test_gemm_low_latency_kernel_matches_bitwise(lib, pkg, ta, tb, tri):
+    if tri and ta:
+        tri = 2                      # A upper triangular for the transposed operand
+    a, ref, _ = _gemm(lib, pkg, 256, 192 if not tri else 256, 256, ta, tb, tri=tri | LL, alpha=-0.5, beta=1.0, seed=90 + tri)
+    b, _, _ = _gemm(lib, pkg, 256, 192 if not tri else 256, 256, ta, tb, tri=tri, alpha=-0.5, beta=1.0, seed=90 + tri)
+    assert np.max(np.abs(a - ref)) < 1e-12 * 256
+    assert np.array_equal(a, b)      # same summation order per element as the 64 x 64 kernel
+
+
 def test_gemm_big_lower_only(lib, pkg):
     out, ref, c0 = _gemm(lib, pkg, 384, 384, 64, 0, 0, tri=BIG, lower=1, alpha=-1.0, beta=1.0, seed=6)
     for bm in range(3):
