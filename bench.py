@@ -117,11 +117,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # Rehearsal of the N > 1 control flow on a one-GPU box: GMRF_BENCH_BACKEND=gloo with
+    # GMRF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (gloo moves CUDA tensors through the host).
+    backend = os.environ.get("GMRF_BENCH_BACKEND", "nccl")
+    if os.environ.get("GMRF_BENCH_ONE_DEVICE") == "1" and backend == "gloo":
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
 
     import numpy as np
