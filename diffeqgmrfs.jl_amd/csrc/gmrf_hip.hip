@@ -516,13 +516,13 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const double f_upd = 2.0 * 64.0 * 64.0 * 64.0 * utiles * nb;
         if (fused || m == 0) {
             ProfScope ps(h, 1, f_tile + f_panel + f_upd);
-            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256), POTRF_STEP_LDS,
-                               h->stream, sa);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256),
+                               m == 0 ? POTRF_TILE_LDS : POTRF_STEP_LDS, h->stream, sa);
         } else {
             // factor the B diagonal tiles once, then panel and update without the redundant tile work
             {
                 ProfScope ps(h, 1, f_tile);
-                hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+                hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_TILE_LDS, h->stream, sa);
             }
             {
                 ProfScope ps(h, 8, f_panel);

@@ -358,10 +358,12 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
-    double* As = Xs + TILE_ELEMS;
-    double* Bs = As + TILE_ELEMS;
-    double* Wk = Bs + TILE_ELEMS;               // 4 * 16 * 18
+    // the tile-only launch (grid.x = 1) allocates up to here only (POTRF_TILE_LDS): with 75 KB instead
+    // of 144 KB a GEMM workgroup of another stream still fits on the CU beside it
+    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
     double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* As = rinvs + 64;                    // fused form only: the two panel tiles
+    double* Bs = As + TILE_ELEMS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
