@@ -655,7 +655,8 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
         else hipLaunchKernelGGL(gemm_f64_big<false>, bgrid, block, gemm_big_lds_bytes<false>(), st, g);
         return hipGetLastError();
     }
-    const bool wide = (g.K % 32 == 0);
+    static const bool force_bk16 = getenv("GMRF_GEMM_BK16") != nullptr;     // tuning aid
+    const bool wide = (g.K % 32 == 0) && !force_bk16;
     if (gemm_uses_ll(g, batch)) {
         const int64_t lx = g.N / GEMM_LL, ly = g.M / GEMM_LL;
         dim3 lgrid((unsigned)((tri_grid ? lx * (lx + 1) / 2 : lx * ly) * batch));
