@@ -99,3 +99,33 @@ def test_posterior_assembler_symbolic_phase_without_gpu(pkg, lib):
     assert e.value.status == pkg._cabi.ERR_NO_DEVICE
     with pytest.raises(ValueError):
         pkg.PosteriorAssembler(gn["Q"], J[:, :-1], device=-1)
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """The Julia shim cannot be executed here (no Julia in the image): check statically that every
+    `ccall` names an exported function with the same number of arguments and compatible C types."""
+    src = open(os.path.join(ROOT, "julia", "DiffEqGMRFsHIP.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "gmrf_hip.h")).read()
+    calls = re.findall(r"ccall\(\(:(\w+),\s*libgmrf\),\s*(\w+),\s*\(([^)]*)\)", src, flags=re.S)
+    protos = {m.group(1): m.group(2) for m in re.finditer(r"gmrf_status\s+(gmrf_\w+)\s*\(([^;]*?)\);", hdr, flags=re.S)}
+    assert len(calls) >= 12
+
+    def c_kind(a):
+        a = a.strip()
+        if "*" in a:
+            return "ptr"
+        return {"int64_t": "Int64", "int32_t": "Int32", "uint64_t": "UInt64", "double": "Float64"}[a.split()[0]]
+
+    def j_kind(a):
+        a = a.strip()
+        return "ptr" if a.startswith(("Ptr{", "Ref{")) else a
+
+    for name, ret, args in calls:
+        if name == "gmrf_last_error":
+            assert ret == "Cstring"
+            continue
+        assert name in protos, name
+        assert ret == "Int32"                                  # gmrf_status
+        jt = [j_kind(a) for a in args.split(",") if a.strip()]
+        ct = [c_kind(a) for a in protos[name].split(",") if a.strip() and a.strip() != "void"]
+        assert jt == ct, (name, jt, ct)
