@@ -28,7 +28,7 @@ EXPORTS = [
     "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
-    "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
+    "gmrf_bt_marginal_var_batch", "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
@@ -113,6 +113,7 @@ def load() -> C.CDLL:
         "gmrf_bt_set_batch": [vp, i64],
         "gmrf_bt_select_problem": [vp, i64],
         "gmrf_csr_create": [i32, vp, i64, i64, vp, vp, vp, i32, i32, P(vp)],
+        "gmrf_bt_marginal_var_batch": [vp, i32, i64, u64, vp, vp, vp],
         "gmrf_bt_export_size": [vp, P(i64)],
         "gmrf_bt_export_factor": [vp, vp, i64],
         "gmrf_bt_import_factor": [vp, vp, i64],

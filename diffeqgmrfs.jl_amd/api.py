@@ -456,10 +456,21 @@ class TridiagonalCholeskyFactor:
                                              _cabi.ptr(store), self.N))
         return view
 
-    def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None):
-        """diag(Q^-1).  "exact" (selected inversion) also serves a batch: returns (batch, n)."""
+    def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None,
+                     q_values=None):
+        """diag(Q^-1).  "exact" (selected inversion), "rbmc" (the reference's RBMCStrategy(k); needs Q)
+        or "mc".  A batch returns (batch, n); its sampled estimators take Q for the pattern and
+        `q_values` (batch, nnz): every problem's values in Q's CSR order (for a symmetric matrix the
+        nzval arrays the factor was given)."""
         m = {"exact": _cabi.VAR_EXACT, "rbmc": _cabi.VAR_RBMC, "mc": _cabi.VAR_MC}[method]
         out = np.empty(self.N if self.batch == 1 else (self.batch, self.N), dtype=np.float64)
+        if self.batch > 1 and m != _cabi.VAR_EXACT:
+            qv = None
+            if q_values is not None:
+                qv = q_values.contiguous() if _is_torch(q_values) else np.ascontiguousarray(q_values, dtype=np.float64)
+            _cabi.check(self._lib.gmrf_bt_marginal_var_batch(self._h, m, k, seed, Q._h if Q is not None else None,
+                                                             _cabi.ptr(qv) if qv is not None else None, _cabi.ptr(out)))
+            return out
         _cabi.check(self._lib.gmrf_bt_marginal_var(self._h, m, k, seed, Q._h if Q is not None else None,
                                                    _cabi.ptr(out)))
         return out

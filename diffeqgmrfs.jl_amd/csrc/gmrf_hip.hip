@@ -1347,14 +1347,19 @@ gmrf_status gmrf_csr_destroy(gmrf_csr* m) {
 }
 
 static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* d_X, int64_t ldx, double* d_Y,
-                               int64_t ldy, int k) {
+                               int64_t ldy, int k, const double* vals_override = nullptr) {
     const double avg = (double)S->nnz / (double)S->n_rows;
     const int bl = 256;
     auto grid_for = [&](int G) { return dim3((unsigned)((S->n_rows * G + bl - 1) / bl)); };
 #define SPMM_LAUNCH(VT, G, VP)                                                                               \
     hipLaunchKernelGGL((csr_spmm<VT, G>), grid_for(G), dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP,        \
                        S->n_rows, d_X, ldx, d_Y, ldy, k)
-    if (S->d_vals32) {
+    if (vals_override) {                      // same pattern, another problem's values (fp64)
+        if (avg > 40) SPMM_LAUNCH(double, 64, vals_override);
+        else if (avg > 20) SPMM_LAUNCH(double, 32, vals_override);
+        else if (avg > 10) SPMM_LAUNCH(double, 16, vals_override);
+        else SPMM_LAUNCH(double, 8, vals_override);
+    } else if (S->d_vals32) {
         if (avg > 40) SPMM_LAUNCH(float, 64, S->d_vals32);
         else if (avg > 20) SPMM_LAUNCH(float, 32, S->d_vals32);
         else if (avg > 10) SPMM_LAUNCH(float, 16, S->d_vals32);
@@ -1709,6 +1714,77 @@ gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint
     HIPCHK(hipStreamSynchronize(h->stream));
     if (h->profiling) prof_collect(h);
     return GMRF_OK;
+}
+
+// Sampled marginal variances of every problem of a batch (the reference's per-problem
+// `std(x_cond)` with RBMCStrategy(k), scripts/darcy/solve_darcy_gmrf-fem.jl:174,192).  Q gives the
+// sparsity pattern (its values are not used); q_vals[p] are problem p's values in Q's CSR order --
+// for a symmetric matrix the nzval array the factor was given.  Problem p draws the sample ids
+// p * k .. p * k + k - 1, so problem 0 equals what a one-problem handle computes.
+gmrf_status gmrf_bt_marginal_var_batch(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed, const gmrf_csr* Q,
+                                       const double* q_vals, double* var_out) {
+    if (!h || !var_out) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "variance before factor"; return GMRF_ERR_NO_FACTOR; }
+    if (method != GMRF_VAR_RBMC && method != GMRF_VAR_MC) return bad_shape("batch variances: RBMC or MC (exact: gmrf_bt_marginal_var)");
+    if (method == GMRF_VAR_RBMC && (!Q || Q->n_rows != h->n || Q->n_cols != h->n || !q_vals)) return bad_shape("RBMC needs the pattern of Q and its values per problem");
+    if (k <= 0) return bad_shape("k <= 0");
+    HIPCHK(hipSetDevice(h->device));
+    const int64_t n = h->n, B = h->B;
+    if (!h->d_acc || h->acc_B < B) {
+        free_dev(h->d_acc); h->d_acc = nullptr;
+        HIPCHK(hipMalloc(&h->d_acc, sizeof(double) * n * B));
+        h->acc_B = B;
+    }
+    HIPCHK(hipMemsetAsync(h->d_acc, 0, sizeof(double) * n * B, h->stream));
+    double *d_qv = nullptr, *d_diag = nullptr;
+    const double* qv = q_vals;
+    if (method == GMRF_VAR_RBMC) {
+        if (!is_device_ptr(q_vals)) {
+            HIPCHK(hipMalloc(&d_qv, sizeof(double) * Q->nnz * B));
+            HIPCHK(hipMemcpyAsync(d_qv, q_vals, sizeof(double) * Q->nnz * B, hipMemcpyHostToDevice, h->stream));
+            qv = d_qv;
+        }
+        HIPCHK(hipMalloc(&d_diag, sizeof(double) * n * B));
+        for (int64_t p = 0; p < B; ++p)
+            hipLaunchKernelGGL(csr_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, Q->d_rowptr,
+                               Q->d_colidx, qv + p * Q->nnz, (const float*)nullptr, n, d_diag + p * n);
+        HIPCHK(hipGetLastError());
+    }
+    gmrf_status st = GMRF_OK;
+    for (int64_t c0 = 0; c0 < k && st == GMRF_OK; c0 += 64) {
+        const int kc = (int)std::min<int64_t>(64, k - c0);
+        st = sample_chunk(h, seed, c0, kc, nullptr, 0, k);          // every problem's chunk in one sweep
+        if (st == GMRF_OK) st = ensure_stage(h, 2 * (int64_t)kc * n);
+        double* Xc = h->d_stage;
+        double* QX = h->d_stage + (int64_t)kc * n;
+        const int kp = pad_k(kc);
+        for (int64_t p = 0; p < B && st == GMRF_OK; ++p) {
+            const int64_t total = n * (int64_t)kc;
+            hipLaunchKernelGGL(unpack_panel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, h->stream,
+                               h->d_Y + p * kp * h->n_pad, h->n_pad, Xc, n, (int)h->bs, (int)h->bsp, n, kc, kp,
+                               (const double*)nullptr);
+            if (method == GMRF_VAR_RBMC) {
+                st = spmm_device(Q, h->stream, Xc, n, QX, n, kc, qv + p * Q->nnz);
+                hipLaunchKernelGGL(rbmc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, QX, Xc, n,
+                                   d_diag + p * n, n, kc, h->d_acc + p * n);
+            } else {
+                hipLaunchKernelGGL(mc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, Xc, n, n, kc,
+                                   h->d_acc + p * n);
+            }
+        }
+    }
+    if (st == GMRF_OK) {
+        for (int64_t p = 0; p < B; ++p)
+            hipLaunchKernelGGL(var_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d_acc + p * n,
+                               method == GMRF_VAR_RBMC ? d_diag + p * n : (const double*)nullptr, 1.0 / (double)k, n,
+                               h->d_acc + p * n);
+        if (hipGetLastError() != hipSuccess) st = GMRF_ERR_HIP;
+        const hipMemcpyKind kind = is_device_ptr(var_out) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+        if (st == GMRF_OK && hipMemcpyAsync(var_out, h->d_acc, sizeof(double) * n * B, kind, h->stream) != hipSuccess) st = GMRF_ERR_HIP;
+    }
+    (void)hipStreamSynchronize(h->stream);
+    free_dev(d_qv); free_dev(d_diag);
+    return st;
 }
 
 // --------------------------------------------------------------------------------- test hooks

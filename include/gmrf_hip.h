@@ -146,6 +146,13 @@ gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int
 gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed,
                                  const gmrf_csr* Q, double* var_out);
 
+/* RBMC / MC variances of every problem of a batch in one call (var_out is [batch][n]).  Q gives
+ * the sparsity pattern only; q_vals[batch][nnz] are the problems' values in Q's CSR order (for
+ * a symmetric matrix: the nzval arrays the factor was given).  Problem p draws the sample ids
+ * p*k .. p*k+k-1. */
+gmrf_status gmrf_bt_marginal_var_batch(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed,
+                                       const gmrf_csr* Q, const double* q_vals, double* var_out);
+
 /* Accumulators for sharded variance estimation: adds this rank's contribution of samples
  * [first_id, first_id + k) to acc (length n; RBMC: sum of squared off-diagonal terms,
  * MC: sum of squares).  The caller all-reduces acc and finishes with

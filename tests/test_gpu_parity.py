@@ -461,6 +461,18 @@ def test_batch_of_problems_matches_one_by_one(pkg):
         Qp = w.Q.copy(); Qp.data = vals[p]
         vo = O.marginal_variances_exact(O.tridiagonal_cholesky(Qp, w.n_blocks))
         assert np.max(np.abs(vb[p] - vo) / vo) < 1e-9
+    # sampled variances of the whole batch: RBMCStrategy(k) per problem, problem 0 = the one-problem path
+    Qc = pkg.CsrMatrix(w.Q)
+    vr = Fb.marginal_var("rbmc", k=64, seed=9, Q=Qc, q_values=vals)
+    vm = Fb.marginal_var("mc", k=64, seed=9)
+    Q0 = w.Q.copy(); Q0.data = vals[0]
+    F0 = pkg.tridiagonal_cholesky(Q0, w.n_blocks)
+    assert np.array_equal(vr[0], F0.marginal_var("rbmc", k=64, seed=9, Q=pkg.CsrMatrix(Q0)))
+    assert np.array_equal(vm[0], F0.marginal_var("mc", k=64, seed=9))
+    for p in range(B):
+        Qp = w.Q.copy(); Qp.data = vals[p]
+        vo = O.marginal_variances_exact(O.tridiagonal_cholesky(Qp, w.n_blocks))
+        assert np.median(np.abs(vr[p] - vo) / vo) < 0.12 and np.median(np.abs(vm[p] - vo) / vo) < 0.25   # k = 64 samples
     # a non-SPD member of the batch is reported with its block index
     bad = vals.copy()
     Qb = w.Q.tocsc()
