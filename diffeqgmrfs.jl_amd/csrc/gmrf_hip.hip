@@ -575,18 +575,13 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     for (int64_t i = i0; i < i1; ++i) {
         double* L = h->d_L + i * bstride;
         double* X = h->d_Linv + i * bstride;
-        HIPCHK(hipMemsetAsync(h->d_S, 0, blk_bytes, h->stream));
-        if (h->diag_count[i] > 0) {
-            hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256), nb), dim3(256), 0,
-                               h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld,
-                               h->n_entries, bstride);
-            HIPCHK(hipGetLastError());
-        }
-        if (h->bsp > h->bs) {
-            hipLaunchKernelGGL(pad_identity, dim3((unsigned)((h->bsp - h->bs + 255) / 256), nb), dim3(256), 0,
-                               h->stream, h->d_S, ld, (int)h->bs, bsp, bstride);
-            HIPCHK(hipGetLastError());
-        }
+        // S = D_i - C C^T is built as  S := -C C^T (GEMM, beta = 0)  then  S += D_i (scatter): same
+        // single rounding as D - acc, and only the rows the product does not write (>= rmax) need
+        // zeroing -- a quarter of the block on darcy instead of all of it.  The first block has no product.
+        const int rm_s = (i > 0) ? (int)h->rmax : 0;
+        if (rm_s < bsp)
+            HIPCHK(hipMemset2DAsync(h->d_S + (int64_t)rm_s * ld, (size_t)bstride * sizeof(double), 0,
+                                    (size_t)(bsp - rm_s) * bsp * sizeof(double), (size_t)h->B, h->stream));
         if (i > 0) {
             double* C = h->d_C + (i - 1) * bstride;
             const double* Xp = h->d_Linv + (i - 1) * bstride;
@@ -596,7 +591,7 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 if (h->low_count[i] > 0) {
                     hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->low_count[i] + 255) / 256), nb), dim3(256), 0,
                                        h->stream, h->d_keys, h->d_vals, h->low_first[i], h->low_count[i], h->d_B, ld,
-                                       h->n_entries, bstride);
+                                       h->n_entries, bstride, 0);
                     HIPCHK(hipGetLastError());
                 }
             }
@@ -621,9 +616,20 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 GCHK(gemm(h, false, false, rm, bsp - cm, bsp - cm, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
                           Xp + (int64_t)cm * ld + cm, ld, 0.0, C + cm, ld, bstride, pLX, pC));
             }
-            // S = D - C C^T             (src/tridiagonal_cholesky.jl:77)
-            GCHK(gemm(h, false, false, rm, rm, bsp - cm, 0, 1, -1.0, C + cm, ld, C + cm, ld, 1.0, h->d_S, ld, pC, pC,
+            // S = D - C C^T             (src/tridiagonal_cholesky.jl:77): the product part
+            GCHK(gemm(h, false, false, rm, rm, bsp - cm, 0, 1, -1.0, C + cm, ld, C + cm, ld, 0.0, h->d_S, ld, pC, pC,
                       bstride));
+        }
+        if (h->diag_count[i] > 0) {
+            hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256), nb), dim3(256), 0,
+                               h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld,
+                               h->n_entries, bstride, 1);
+            HIPCHK(hipGetLastError());
+        }
+        if (h->bsp > h->bs) {
+            hipLaunchKernelGGL(pad_identity, dim3((unsigned)((h->bsp - h->bs + 255) / 256), nb), dim3(256), 0,
+                               h->stream, h->d_S, ld, (int)h->bs, bsp, bstride);
+            HIPCHK(hipGetLastError());
         }
         GCHK(potrf_block(h, h->d_S, L, X, h->d_T, (int)(i + 1)));
     }

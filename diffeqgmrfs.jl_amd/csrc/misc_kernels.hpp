@@ -11,14 +11,17 @@ namespace gmrf {
 // Replaces `Array(A[rows, cols])` of /root/reference/src/tridiagonal_cholesky.jl:67,73,76.
 // Entries are (row << 32 | col) keys local to the block.
 // blockIdx.y = problem: values at vals + y * pvals, destination block at dst + y * pdst.
+// add != 0: dst += value (the diagonal block lands on top of -C C^T; every key occurs once).
 __global__ void scatter_block(const uint64_t* __restrict__ keys, const double* __restrict__ vals,
                               int64_t first, int64_t count, double* __restrict__ dst, int64_t ld,
-                              int64_t pvals, int64_t pdst) {
+                              int64_t pvals, int64_t pdst, int add) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint64_t key = keys[first + i];
     const int64_t r = (int64_t)(key >> 32), c = (int64_t)(key & 0xffffffffu);
-    dst[(int64_t)blockIdx.y * pdst + r * ld + c] = vals[(int64_t)blockIdx.y * pvals + first + i];
+    double* d = dst + (int64_t)blockIdx.y * pdst + r * ld + c;
+    const double v = vals[(int64_t)blockIdx.y * pvals + first + i];
+    *d = add ? *d + v : v;
 }
 
 // Identity on the padding rows [bs, bsp) of a padded diagonal block.
