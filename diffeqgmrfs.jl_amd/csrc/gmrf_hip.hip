@@ -606,7 +606,8 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 const int W = bsp - cm;
                 const int rch = (rm + 255) / 256;
                 ba.cw = ((int64_t)(W / 64) * rch * nb >= 512) ? 64 : (((int64_t)(W / 32) * rch * nb >= 512) ? 32 : 16);
-                const dim3 grid((unsigned)(W / ba.cw), (unsigned)rch, nb);
+                ba.bsp = bsp;
+                const dim3 grid((unsigned)((W / ba.cw) * rch * (int)nb));
                 ProfScope ps(h, 10, 8.0 * ((double)rm * W + 0.5 * (double)W * W) * (double)h->B);
                 if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
                 else if (h->lo_row_max <= 16) hipLaunchKernelGGL(spmm_bxt<16>, grid, dim3(256), 0, h->stream, ba);

@@ -106,7 +106,7 @@ __global__ void fill_normals_panel(double* __restrict__ P, int64_t n_pad, int bs
 // walks cw columns c; for entry t the 64 lanes of a wave (consecutive r) read X[c][j_t(r)], which
 // for a stencil coupling are consecutive addresses of one row of X.  No LDS, every load of the c
 // loop is independent.  The lower blocks' entry lists are stored row by row (rowptr).
-// grid ((bsp - cm) / cw, ceil(rm / 256), problems).
+// 1-D grid of (bsp - cm) / cw * ceil(rm / 256) * problems workgroups.
 struct BxtArgs {
     const int* rowptr;        // [bsp + 1], local row -> range in keys / vals
     const uint64_t* keys;     // row << 32 | col
@@ -115,17 +115,31 @@ struct BxtArgs {
     const double* X;          // previous block's inverse
     double* C;
     int64_t ld, pX, pC;
-    int cm, rm;
+    int cm, rm, bsp;
     int cw;                   // columns of C per workgroup (16, 32 or 64: enough workgroups for a lone problem)
 };
 
 template <int KM>
 __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
-    const int r = (int)blockIdx.y * 256 + (int)threadIdx.x;
-    const int c0 = a.cm + (int)blockIdx.x * a.cw;
-    const double* __restrict__ X = a.X + (int64_t)blockIdx.z * a.pX;
-    double* __restrict__ C = a.C + (int64_t)blockIdx.z * a.pC;
-    const double* __restrict__ vals = a.vals + (int64_t)blockIdx.z * a.n_entries;
+    // 1-D grid over (column chunk, row chunk, problem).  Workgroup ids go round-robin over the 8
+    // XCDs: with a multiple of 8 problems id % 8 picks the problem group and the row chunks of one
+    // column chunk follow each other on the SAME XCD, so the rows of X they share come from its L2
+    // (PMC before: X fetched 2.6 times per launch).
+    const int ncc = (a.bsp - a.cm) / a.cw, nrc = (a.rm + 255) / 256;
+    const int nprob = (int)gridDim.x / (ncc * nrc);
+    int cc, rc, prob;
+    {
+        const int groups = (nprob % 8 == 0) ? 8 : 1;
+        const int xg = (int)blockIdx.x % groups, q = (int)blockIdx.x / groups;
+        rc = q % nrc;
+        cc = (q / nrc) % ncc;
+        prob = xg + groups * (q / (nrc * ncc));
+    }
+    const int r = rc * 256 + (int)threadIdx.x;
+    const int c0 = a.cm + cc * a.cw;
+    const double* __restrict__ X = a.X + (int64_t)prob * a.pX;
+    double* __restrict__ C = a.C + (int64_t)prob * a.pC;
+    const double* __restrict__ vals = a.vals + (int64_t)prob * a.n_entries;
     int k0 = 0, len = 0;
     if (r < a.rm) { k0 = a.rowptr[r]; len = a.rowptr[r + 1] - k0; }
     int jt[KM];
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
     __shared__ double ls[256 * 17];
     const int tid = (int)threadIdx.x;
     const int wr = tid >> 4, wc = tid & 15;        // write-out: 16 lanes per row, 16 rows per pass
-    const int rbase = (int)blockIdx.y * 256;
+    const int rbase = rc * 256;
     for (int c = c0; c < c0 + a.cw; c += 16) {
         const double* xr = X + (int64_t)c * a.ld;
         double acc[16];
