@@ -579,9 +579,12 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
         // single rounding as D - acc, and only the rows the product does not write (>= rmax) need
         // zeroing -- a quarter of the block on darcy instead of all of it.  The first block has no product.
         const int rm_s = (i > 0) ? (int)h->rmax : 0;
-        if (rm_s < bsp)
-            HIPCHK(hipMemset2DAsync(h->d_S + (int64_t)rm_s * ld, (size_t)bstride * sizeof(double), 0,
-                                    (size_t)(bsp - rm_s) * bsp * sizeof(double), (size_t)h->B, h->stream));
+        if (rm_s < bsp) {
+            const int64_t cnt = (int64_t)(bsp - rm_s) * bsp;
+            hipLaunchKernelGGL(zero_rows, dim3((unsigned)((cnt / 2 + 255) / 256), nb), dim3(256), 0, h->stream,
+                               h->d_S + (int64_t)rm_s * ld, cnt, bstride);
+            HIPCHK(hipGetLastError());
+        }
         if (i > 0) {
             double* C = h->d_C + (i - 1) * bstride;
             const double* Xp = h->d_Linv + (i - 1) * bstride;
