@@ -230,7 +230,11 @@ def main():
         st = eng.F.stats()
         eng.F.set_profiling(0)
         ms, work, cnt = st["kernel_ms"], st["kernel_work"], st["kernel_launches"]
-        dom = max(KERNEL_CLASSES, key=lambda c: ms[c])
+        # the kernel with the largest time; classes within 15 % of it count as tied and the first in
+        # KERNEL_CLASSES order is named, so that the roofline object does not flip between the two
+        # operand layouts of the same GEMM kernel from run to run
+        top = max(ms[c] for c in KERNEL_CLASSES)
+        dom = next(c for c in KERNEL_CLASSES if ms[c] >= 0.85 * top)
         name, bound = KERNEL_CLASSES[dom]
         if bound == "mfma":
             achieved = work[dom] / (ms[dom] * 1e-3) / 1e12
