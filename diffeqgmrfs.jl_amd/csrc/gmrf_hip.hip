@@ -264,12 +264,26 @@ static gmrf_status alloc_work(gmrf_handle* h) {
     return GMRF_OK;
 }
 
+// Buffers sized by n / n_pad / the batch: dropped whenever the shape or the batch changes
+// (they are re-created on demand with the new sizes).
+static void release_shape_buffers(gmrf_handle* h) {
+    for (auto& kv : h->sweep_graphs) (void)hipGraphExecDestroy(kv.second);
+    h->sweep_graphs.clear();
+    free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
+    h->d_P = h->d_Y = h->d_Tp = nullptr; h->kp_cap = 0;
+    free_dev(h->d_mean); h->d_mean = nullptr;
+    free_dev(h->d_acc); h->d_acc = nullptr; h->acc_B = 0;
+    free_dev(h->d_stage); h->d_stage = nullptr; h->stage_cap = 0;
+}
+
 static gmrf_status set_shape(gmrf_handle* h, int64_t n, int64_t N) {
     if (n <= 0 || N <= 0 || n % N != 0) return bad_shape("n must be a positive multiple of N_blocks");
     const int64_t bs = n / N;
     if (bs > (1 << 20)) return bad_shape("block size too large");
     if (h->n != n || h->N != N) {
+        (void)hipStreamSynchronize(h->stream);
         destroy_graphs(h);
+        release_shape_buffers(h);
         h->factored = false;
         h->analyzed = false;
     }
@@ -345,8 +359,11 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
     HIPCHK(hipMalloc(&h->d_nz_stage, std::max<int64_t>(nnz_in, 1) * sizeof(double) * h->B));
     h->vals_B = h->B;
     if (!keys.empty()) {
-        HIPCHK(hipMemcpy(h->d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+        // (stream-ordered copies + a stream wait: a synchronous hipMemcpy goes through the legacy stream,
+        //  which HIP refuses while another host thread is capturing a graph)
+        HIPCHK(hipMemcpyAsync(h->d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
     }
     // row pointers into the lower blocks' entry lists for the sparse C = B X^T (spmm_bxt)
     free_dev(h->d_lo_rowptr);
@@ -364,7 +381,8 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
             for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
         }
         HIPCHK(hipMalloc(&h->d_lo_rowptr, rowptr.size() * sizeof(int)));
-        HIPCHK(hipMemcpy(h->d_lo_rowptr, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(h->d_lo_rowptr, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         // dense GEMM: 2 bs^3 flop at ~50 TF/s; sparse: one pass over C.  Rows of up to 32 entries go
         // the sparse way, anything denser keeps the GEMM.
         h->lo_row_max = max_row;
@@ -832,7 +850,8 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
     HIPCHK(hipMalloc(&h->d_info, sizeof(int)));
-    HIPCHK(hipMemset(h->d_info, 0, sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
@@ -872,9 +891,7 @@ gmrf_status gmrf_bt_set_batch(gmrf_handle* h, int64_t batch) {
         h->B = batch;
         h->sel = 0;
         h->factored = false;
-        free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
-        h->d_P = h->d_Y = h->d_Tp = nullptr; h->kp_cap = 0;
-        free_dev(h->d_mean); h->d_mean = nullptr;
+        release_shape_buffers(h);
         if (h->n > 0) (void)set_shape(h, h->n, h->N);      // flop accounting follows the batch
     }
     return GMRF_OK;
@@ -1068,7 +1085,10 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
     if (dev_out) { cm.resize((size_t)bs * bs); dst = cm.data(); ldd = bs; }
     for (int64_t r = 0; r < bs; ++r)
         for (int64_t c = 0; c < bs; ++c) dst[c * ldd + r] = tmp[(size_t)r * bsp + c];   // row-major -> column-major
-    if (dev_out) HIPCHK(hipMemcpy2D(out, ld * sizeof(double), cm.data(), bs * sizeof(double), bs * sizeof(double), bs, hipMemcpyHostToDevice));
+    if (dev_out) {
+        HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), cm.data(), bs * sizeof(double), bs * sizeof(double), bs, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
     return GMRF_OK;
 }
 
@@ -1126,7 +1146,8 @@ gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes
             for (int64_t c = 0; c < bs; ++c) tmp[(size_t)r * bsp + c] = src[c * bs + r];   // column-major -> row-major
         if (unit_pad)
             for (int64_t r = bs; r < bsp; ++r) tmp[(size_t)r * bsp + r] = 1.0;
-        HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(dst, tmp.data(), tmp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
         return GMRF_OK;
     };
     const double* in = (const double*)((const char*)buf + 64);
@@ -1323,16 +1344,19 @@ gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
     HIPCHK(hipMalloc(&m->d_rowptr, sizeof(int64_t) * (n_rows + 1)));
     HIPCHK(hipMalloc(&m->d_colidx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-    HIPCHK(hipMemcpy(m->d_rowptr, rp.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(m->d_colidx, ci.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpyAsync(m->d_rowptr, rp.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipMemcpyAsync(m->d_colidx, ci.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
     if (values_f32) {
         std::vector<float> vf((size_t)nnz);
         for (int64_t p = 0; p < nnz; ++p) vf[p] = (float)vals[p];
         HIPCHK(hipMalloc(&m->d_vals32, sizeof(float) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMemcpy(m->d_vals32, vf.data(), sizeof(float) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(m->d_vals32, vf.data(), sizeof(float) * nnz, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
     } else {
         HIPCHK(hipMalloc(&m->d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMemcpy(m->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpyAsync(m->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
     }
     if (n_rows == n_cols) {
         HIPCHK(hipMalloc(&m->d_diag, sizeof(double) * n_rows));
@@ -1502,7 +1526,8 @@ gmrf_status gmrf_assemble_create(int32_t device, void* stream, int64_t n, const 
         auto up = [&](auto** d, const auto& v) -> hipError_t {
             using T = typename std::remove_reference<decltype(v[0])>::type;
             hipError_t e = hipMalloc((void**)d, std::max<size_t>(v.size(), 1) * sizeof(T));
-            if (e == hipSuccess && !v.empty()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+            if (e == hipSuccess && !v.empty()) e = hipMemcpyAsync(*d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, as->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(as->stream);
             return e;
         };
         std::vector<int64_t> j_rptr((size_t)m + 1);

@@ -220,6 +220,42 @@ def test_error_paths(pkg):
         pkg.ldiv(F, np.zeros(256))                             # solve before factor
 
 
+def test_handle_life_cycle_recovery_and_reuse(pkg):
+    """One handle through a failed factorisation, a recovery on the same pattern, a different
+    pattern and shape, a change of batch size, and several handles driven from host threads."""
+    import threading
+    w = pkg.workloads.random_block_tridiagonal(4, 64, seed=1)
+    F = pkg.tridiagonal_cholesky(w.Q, 4)
+    x0 = pkg.ldiv(F, w.rhs)
+    bad = w.Q.data.copy()
+    Qc = w.Q.tocsc()
+    d = np.flatnonzero((Qc.indices == 130) & (np.repeat(np.arange(w.n), np.diff(Qc.indptr)) == 130))[0]
+    bad[d] = -50.0
+    with pytest.raises(pkg.NotPositiveDefinite):
+        F.refactor(bad)
+    with pytest.raises(pkg.GmrfError):                        # the failed factor is not usable
+        pkg.ldiv(F, w.rhs)
+    F.refactor(w.Q.data)                                       # same handle recovers
+    assert np.array_equal(pkg.ldiv(F, w.rhs), x0)
+    w2 = pkg.workloads.random_block_tridiagonal(3, 130, seed=6)   # other pattern, other shape
+    F.factor(w2.Q, 3)
+    assert rel(pkg.ldiv(F, w2.rhs), O.ldiv(O.tridiagonal_cholesky(w2.Q, 3), w2.rhs)) < 1e-12
+    F.set_batch(2)                                             # other batch size on the same handle
+    F.factor(w.Q, 4, values=np.stack([w.Q.data, 2.0 * w.Q.data]))
+    xb = F.solve_batch(np.stack([w.rhs, w.rhs])[:, None, :])[:, 0, :]
+    assert np.array_equal(xb[0], x0) and rel(xb[1], 0.5 * x0) < 1e-13
+    # independent handles on their own streams, one host thread each
+    res = [None] * 4
+    def work(i):
+        Fi = pkg.tridiagonal_cholesky(w.Q, 4)
+        for _ in range(5):
+            Fi.refactor(w.Q.data)
+            res[i] = pkg.ldiv(Fi, w.rhs)
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert all(np.array_equal(r, x0) for r in res)
+
+
 def test_degenerate_shapes(pkg):
     # N = 1 (plain dense Cholesky) and a long chain of small blocks
     w1 = pkg.workloads.random_block_tridiagonal(1, 128, seed=2)
