@@ -244,6 +244,17 @@ def test_handle_life_cycle_recovery_and_reuse(pkg):
     F.factor(w.Q, 4, values=np.stack([w.Q.data, 2.0 * w.Q.data]))
     xb = F.solve_batch(np.stack([w.rhs, w.rhs])[:, None, :])[:, 0, :]
     assert np.array_equal(xb[0], x0) and rel(xb[1], 0.5 * x0) < 1e-13
+    # alternating shapes on one handle do not leak device memory
+    import torch
+    F.set_batch(1)
+    used = []
+    for it in range(6):
+        wa = w if it % 2 == 0 else w2
+        F.factor(wa.Q, wa.n_blocks)
+        pkg.ldiv(F, wa.rhs); F.sample(3, seed=1); F.marginal_var("exact")
+        free_b, total_b = torch.cuda.mem_get_info(0)
+        used.append(total_b - free_b)
+    assert max(used[2:]) - min(used[2:]) < 64 << 20
     # independent handles on their own streams, one host thread each
     res = [None] * 4
     def work(i):
@@ -254,6 +265,35 @@ def test_handle_life_cycle_recovery_and_reuse(pkg):
     ths = [threading.Thread(target=work, args=(i,)) for i in range(4)]
     [t.start() for t in ths]; [t.join() for t in ths]
     assert all(np.array_equal(r, x0) for r in res)
+
+
+def test_c_abi_leading_dimensions_in_place_and_mixed_k(pkg, lib):
+    """Straight through the C ABI: column-major right-hand sides with ld > n (host and device
+    memory), in place (y == b, as ldiv! allows), right-hand-side counts changing from call to call,
+    and the factor image of a batch member other than the first."""
+    import torch
+    w = pkg.workloads.random_block_tridiagonal(5, 40, seed=12)
+    F = pkg.tridiagonal_cholesky(w.Q, 5)
+    Fo = O.tridiagonal_cholesky(w.Q, 5)
+    n, ld = w.n, w.n + 7
+    rng = np.random.default_rng(2)
+    for k in (1, 3, 64, 200, 2, 129, 1):
+        B = rng.standard_normal((n, k))
+        buf = np.full((k, ld), np.nan)                    # k columns of length ld, column-major n x k inside
+        buf[:, :n] = B.T
+        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(buf), pkg._cabi.ptr(buf), k, ld, pkg._cabi.SOLVE_FULL))
+        assert rel(buf[:, :n].T, O.ldiv(Fo, B)) < 1e-12 and np.all(np.isnan(buf[:, n:]))
+        dev = torch.full((k, ld), float("nan"), dtype=torch.float64, device="cuda")
+        dev[:, :n] = torch.from_numpy(B.T.copy()).cuda()
+        out = torch.zeros_like(dev)
+        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(dev), pkg._cabi.ptr(out), k, ld, pkg._cabi.SOLVE_BACKWARD))
+        assert rel(out[:, :n].T.cpu().numpy(), O.backward_solve(Fo, B)) < 1e-12
+        assert float(out[:, n:].abs().sum()) == 0.0       # the padding of the output is not written
+    # export the factor of problem 1 of a batch
+    Fb = pkg.TridiagonalCholeskyFactor(batch=2).factor(w.Q, 5, values=np.stack([w.Q.data, 4.0 * w.Q.data]))
+    Fb.select_problem(1)
+    G = pkg.TridiagonalCholeskyFactor().import_factor(Fb.export_factor())
+    assert rel(pkg.ldiv(G, w.rhs), 0.25 * O.ldiv(Fo, w.rhs)) < 1e-12
 
 
 def test_degenerate_shapes(pkg):
