@@ -366,6 +366,12 @@ def test_sparse_and_dense_coupling_product_agree(pkg, name):
         assert np.max(np.abs(Fd.Cs[i] - Fo.Cs[i])) / scale < TOL_FACTOR
         assert np.max(np.abs(Fd.Cs[i] - Fs.Cs[i])) / scale < 1e-13
     assert rel(pkg.ldiv(Fs, w.rhs), pkg.ldiv(Fd, w.rhs)) < solve_tol(w)
+    # the GEMM route with a batch (dense image of B per problem)
+    Fb = pkg.TridiagonalCholeskyFactor(batch=2)
+    Fb.set_eager(8)
+    Fb.factor(w.Q, w.n_blocks, values=np.stack([w.Q.data, 2.0 * w.Q.data]))
+    xb = Fb.solve_batch(np.stack([w.rhs, w.rhs])[:, None, :])[:, 0, :]
+    assert np.array_equal(xb[0], pkg.ldiv(Fd, w.rhs)) and rel(xb[1], 0.5 * xb[0]) < solve_tol(w)
     # a block-dense coupling (more than 32 entries per row) takes the GEMM route by itself
     wd = pkg.workloads.random_block_tridiagonal(3, 128, seed=2, density=0.6)
     F = pkg.tridiagonal_cholesky(wd.Q, wd.n_blocks)
