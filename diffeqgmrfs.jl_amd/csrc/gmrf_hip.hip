@@ -509,6 +509,9 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
     const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
     const int pw = (!fused && nt >= 8) ? 4 : nt;           // panel width in tiles
+    // a lone problem with larger blocks: two-level, with the fused kernel restricted to the panel's
+    // own columns as the in-panel step (one launch instead of three where the panel has columns left)
+    const bool fused_in_panel = (h->B == 1 && !h->split_step && nt > 16);
     // Opt-in (set_eager bit 4): inside a captured graph the block forks once its first half is
     // factored: a second branch assembles the inverse of that half and the top-level product
     // T21 = L21 X11 (everything they read is final) while this branch runs the latency-bound panel
@@ -536,6 +539,10 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             ProfScope ps(h, 1, f_tile + f_panel + f_upd);
             hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256),
                                m == 0 ? POTRF_TILE_LDS : POTRF_STEP_LDS, h->stream, sa);
+        } else if (fused_in_panel && utiles > 0) {
+            // the workgroups of column j+1 write the whole panel L[j+1.., j]
+            ProfScope ps(h, 1, f_tile + f_panel + f_upd);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + utiles, 1), dim3(256), POTRF_STEP_LDS, h->stream, sa);
         } else {
             // factor the B diagonal tiles once, then panel and update without the redundant tile work
             {

@@ -344,7 +344,8 @@ struct StepArgs {
     unsigned long long* dbg;   // diagnostic stamps of workgroup 1 of step 0 (tests), else nullptr
 };
 
-// Fused panel step: grid.x = 1 + m (m + 1) / 2, m = nt - j - 1.  Workgroup 0 factors and inverts
+// Fused panel step: grid.x = 1 + m (m + 1) / 2, m = nt - j - 1  (cend < nt: 1 + the tiles of columns
+// j+1 .. cend-1 only; the rest of the trailing block is updated per panel by the GEMM kernel).  Workgroup 0 factors and inverts
 // the diagonal tile and writes it; every other workgroup does the same factorisation for itself
 // (idle CUs otherwise), then forms its two panel tiles and updates its trailing tile.  With
 // grid.x = 1 it is the tile kernel of the split form (batches, large blocks).  The template
@@ -374,10 +375,17 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     int r = 0, c = 0;
     const int w = (int)blockIdx.x;
     if (w > 0) {
-        int t = w - 1, rr = 0;
-        while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
-        r = sa.j + 1 + rr;
-        c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+        if (sa.cend >= sa.nt) {                  // the whole trailing block, row by row
+            int t = w - 1, rr = 0;
+            while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+            r = sa.j + 1 + rr;
+            c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+        } else {                                 // columns j+1 .. cend-1 only (two-level form), column by column
+            int t = w - 1;
+            c = sa.j + 1;
+            while (t >= sa.nt - c) { t -= sa.nt - c; ++c; }
+            r = c + t;
+        }
     }
     tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
     // the C tile this wave will update (rows 16*wave.., MFMA C/D layout), fetched now, used last

@@ -133,7 +133,7 @@ def test_potrf_tile_reports_non_spd(lib, pkg):
     assert info.value == 1
 
 
-@pytest.mark.parametrize("bs", [64, 128, 256, 1024])
+@pytest.mark.parametrize("bs", [64, 128, 256, 1024, 2048])
 def test_potrf_block_with_inverse(lib, pkg, bs):
     A = _spd(bs, bs)
     S = np.tril(A).copy()           # only the lower triangle is read
