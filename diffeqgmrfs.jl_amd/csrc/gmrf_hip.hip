@@ -80,6 +80,7 @@ struct gmrf_csr {
     double* d_vals = nullptr;
     float* d_vals32 = nullptr;
     double* d_diag = nullptr;
+    bool tiles_ok = false;             // every SPMV_ROWS-row tile has at most SPMV_CAP entries (csr_spmv_tiles)
     double* d_stage_x = nullptr;
     double* d_stage_y = nullptr;
     int64_t stage_cap = 0;
@@ -1347,6 +1348,9 @@ gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_
     }
     gmrf_csr* m = new gmrf_csr();
     m->device = device;
+    m->tiles_ok = true;
+    for (int64_t r = 0; r < n_rows; r += SPMV_ROWS)
+        if (rp[std::min(n_rows, r + SPMV_ROWS)] - rp[r] > SPMV_CAP) { m->tiles_ok = false; break; }
     if (stream) { m->stream = (hipStream_t)stream; } else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
     HIPCHK(hipMalloc(&m->d_rowptr, sizeof(int64_t) * (n_rows + 1)));
@@ -1391,6 +1395,18 @@ static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* 
                                int64_t ldy, int k, const double* vals_override = nullptr) {
     const double avg = (double)S->nnz / (double)S->n_rows;
     const int bl = 256;
+    if (k == 1 && S->tiles_ok) {
+        // SpMV: LDS-staged row tiles (with 3+ right-hand sides the lane-group kernel, which reuses the
+        // entries for four of them, is faster than one pass per right-hand side)
+        const dim3 grid((unsigned)((S->n_rows + SPMV_ROWS - 1) / SPMV_ROWS));
+        for (int r = 0; r < k; ++r) {
+            if (vals_override) hipLaunchKernelGGL(csr_spmv_tiles<double>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, vals_override, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
+            else if (S->d_vals32) hipLaunchKernelGGL(csr_spmv_tiles<float>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, S->d_vals32, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
+            else hipLaunchKernelGGL(csr_spmv_tiles<double>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, S->d_vals, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
+        }
+        HIPCHK(hipGetLastError());
+        return GMRF_OK;
+    }
     auto grid_for = [&](int G) { return dim3((unsigned)((S->n_rows * G + bl - 1) / bl)); };
 #define SPMM_LAUNCH(VT, G, VP)                                                                               \
     hipLaunchKernelGGL((csr_spmm<VT, G>), grid_for(G), dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP,        \

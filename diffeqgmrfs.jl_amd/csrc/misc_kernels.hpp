@@ -237,6 +237,60 @@ __global__ __launch_bounds__(256) void csr_spmm(const int64_t* __restrict__ rowp
     }
 }
 
+// SpMV with LDS-staged row tiles (one right-hand side).  A workgroup owns SPMV_ROWS consecutive rows
+// = one contiguous range of entries.  Phase 1: thread t takes entries e0 + t, e0 + t + 256, ...: the
+// colidx / vals reads are perfectly coalesced and every load of a thread is independent (a whole
+// tile's worth of bytes in flight per workgroup -- the lane-group kernel above keeps one dependent
+// chain rowptr -> entries -> x per row in flight and ran at 2 TB/s on a 31 M-entry matrix); the
+// products v * x[col] go to LDS.  Phase 2: one thread per row adds its segment of the LDS image in
+// entry order (fixed summation order) and writes y.  The host checks at creation that no tile has
+// more than SPMV_CAP entries; otherwise the lane-group kernel is used.
+constexpr int SPMV_ROWS = 64;
+constexpr int SPMV_CAP = 2304;            // doubles of LDS per workgroup (18 KB: eight workgroups per CU)
+
+template <typename VT>
+__global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ colidx,
+                                                      const VT* __restrict__ vals, int64_t n_rows,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+    __shared__ double prod[SPMV_CAP];
+    __shared__ int64_t rp[SPMV_ROWS + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * SPMV_ROWS;
+    const int nr = (int)min((int64_t)SPMV_ROWS, n_rows - r0);
+    const int t = threadIdx.x;
+    if (t <= nr) rp[t] = rowptr[r0 + t];
+    __syncthreads();
+    const int64_t e0 = rp[0];
+    const int cnt = (int)(rp[nr] - e0);
+    // four entries per thread and pass, all loads issued before the first product is stored
+    for (int base = 0; base < cnt; base += 1024) {
+        int c[4];
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = base + t + 256 * i;
+            const bool ok = e < cnt;
+            c[i] = ok ? colidx[e0 + e] : 0;
+            v[i] = ok ? (double)vals[e0 + e] : 0.0;
+        }
+        double xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = x[c[i]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = base + t + 256 * i;
+            if (e < cnt) prod[e] = v[i] * xv[i];
+        }
+    }
+    __syncthreads();
+    if (t < nr) {
+        const int a = (int)(rp[t] - e0), b = (int)(rp[t + 1] - e0);
+        double s = 0.0;
+        for (int e = a; e < b; ++e) s += prod[e];
+        y[r0 + t] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------- variances
 // acc[i] += sum_s ((QX[s][i] - d_i X[s][i]) / d_i)^2     (RBMC off-diagonal term)
 __global__ void rbmc_accumulate(const double* __restrict__ QX, const double* __restrict__ X,

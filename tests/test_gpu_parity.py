@@ -134,6 +134,18 @@ def test_spmm_fp64_and_fp32_values(pkg):
     ref32 = sp.csr_matrix((w.Q.tocsr().data.astype(np.float32).astype(np.float64), w.Q.tocsr().indices,
                            w.Q.tocsr().indptr), shape=w.Q.shape) @ X
     assert rel(Q32 @ X, ref32) < 1e-14
+    assert rel(Q32 @ X[:, 1], ref32[:, 1]) < 1e-14          # SpMV (LDS-staged row tiles), fp32 values
+    # ragged rows: empty rows, a row count that is no multiple of the 64-row tile, rectangular shape
+    rng = np.random.default_rng(8)
+    A = sp.random(1000, 700, density=0.01, random_state=rng, data_rvs=rng.standard_normal).tolil()
+    A[5, :] = 0.0; A[999, :] = 0.0
+    A = A.tocsr(); A.eliminate_zeros()
+    x = rng.standard_normal(700)
+    assert rel(pkg.CsrMatrix(A) @ x, A @ x) < 1e-14
+    # a tile with more entries than the LDS image holds falls back to the lane-group kernel
+    D = sp.random(200, 300, density=0.5, random_state=rng, data_rvs=rng.standard_normal).tocsr()
+    xd = rng.standard_normal(300)
+    assert rel(pkg.CsrMatrix(D) @ xd, D @ xd) < 1e-13
 
 
 def test_refactor_values_same_pattern(pkg):
