@@ -256,6 +256,14 @@ def main():
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                            "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel": name,
                            "launches_per_step": int(cnt[dom]), "avg_launch_us": 1e3 * ms[dom] / max(cnt[dom], 1)}
+        # the HBM-bound leg of the path (north_star: sweep HBM GB/s against the 8 TB/s roofline): the k = 1
+        # GEMV sweep kernels of the same instrumented step; bytes = the reference's dense L / C blocks
+        if ms[3] > 0:
+            g3 = work[3] / (ms[3] * 1e-3) / 1e9
+            out["roofline_sweep"] = {"bound": "hbm", "achieved": g3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                                     "frac": g3 / PEAK_HBM_GBPS, "kernel": "sweep_gemv_n / sweep_gemv_t",
+                                     "launches_per_step": int(cnt[3]), "avg_launch_us": 1e3 * ms[3] / max(cnt[3], 1),
+                                     "note": "algorithmic bytes of the dense blocks (SURVEY 8d); the kernels read only the non-zero part of C"}
         out["kernels"] = {KERNEL_CLASSES[c][0]: {"ms_per_step": ms[c], "launches": int(cnt[c]),
                                                   ("tflops" if KERNEL_CLASSES[c][1] == "mfma" else "gbps"):
                                                   (work[c] / (ms[c] * 1e-3) / (1e12 if KERNEL_CLASSES[c][1] == "mfma" else 1e9)) if ms[c] > 0 else 0.0}
