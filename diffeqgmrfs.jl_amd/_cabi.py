@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgmrf_hip.so")
 
 GMRF_OK = 0
-ERR_NOT_SPD, ERR_BAD_SHAPE, ERR_BAND, ERR_HIP, ERR_NO_FACTOR, ERR_NO_DEVICE, ERR_ALLOC = -1, -2, -3, -4, -5, -6, -7
+ERR_NOT_SPD, ERR_BAD_SHAPE, ERR_BAND, ERR_HIP, ERR_NO_FACTOR, ERR_NO_DEVICE, ERR_ALLOC, ERR_RCCL = -1, -2, -3, -4, -5, -6, -7, -8
 SOLVE_FULL, SOLVE_FORWARD, SOLVE_BACKWARD = 0, 1, 2
 VAR_EXACT, VAR_RBMC, VAR_MC = 0, 1, 2
 BLOCK_L, BLOCK_C, BLOCK_LINV = 0, 1, 2
@@ -25,11 +25,14 @@ EXPORTS = [
     "gmrf_bt_factor_csc", "gmrf_bt_factor_blocks", "gmrf_bt_refactor_values",
     "gmrf_bt_solve", "gmrf_bt_sample", "gmrf_bt_normals", "gmrf_bt_marginal_var",
     "gmrf_bt_var_accumulate", "gmrf_bt_logdet", "gmrf_bt_get_block", "gmrf_bt_factor_buffer",
-    "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
+    "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_adopt_layout", "gmrf_bt_get_layout", "gmrf_bt_block_range",
+    "gmrf_bt_set_keep_l", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
     "gmrf_bt_factor_step_async", "gmrf_bt_factor_end", "gmrf_bt_stats",
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_bt_marginal_var_batch", "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
-    "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm",
+    "gmrf_comm_unique_id", "gmrf_comm_create", "gmrf_comm_destroy", "gmrf_comm_bcast_host", "gmrf_comm_allreduce_sum",
+    "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait",
+    "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
@@ -47,6 +50,7 @@ class Stats(C.Structure):
         ("n", C.c_int64), ("n_blocks", C.c_int64), ("block_size", C.c_int64),
         ("block_size_padded", C.c_int64), ("factor_bytes", C.c_int64),
         ("kernel_ms", C.c_double * 16), ("kernel_work", C.c_double * 16), ("kernel_launches", C.c_int64 * 16),
+        ("sweep_bytes_streamed", C.c_double),
     ]
 
 
@@ -100,9 +104,20 @@ def load() -> C.CDLL:
         "gmrf_bt_get_block": [vp, i32, i64, vp, i64],
         "gmrf_bt_factor_buffer": [vp, i32, P(vp), P(i64)],
         "gmrf_bt_adopt_shape": [vp, i64, i64],
-        "gmrf_bt_storage_bytes": [i64, i64, P(i64), P(i64), P(i64)],
-        "gmrf_bt_set_storage": [vp, i64, i64, vp, vp, vp],
-        "gmrf_bt_adopt_commit": [vp],
+        "gmrf_bt_storage_bytes": [i64, i64, i64, P(i64), P(i64), P(i64)],
+        "gmrf_bt_set_storage": [vp, i64, i64, i64, vp, vp, vp],
+        "gmrf_bt_adopt_commit": [vp, i32],
+        "gmrf_bt_adopt_layout": [vp, i64, i64, vp, i64],
+        "gmrf_bt_get_layout": [vp, vp, i64, P(i64)],
+        "gmrf_bt_block_range": [vp, i32, i64, i64, P(i64), P(i64), P(i64)],
+        "gmrf_bt_set_keep_l": [vp, i32],
+        "gmrf_comm_unique_id": [vp],
+        "gmrf_comm_create": [i32, i32, i32, vp, P(vp)],
+        "gmrf_comm_destroy": [vp],
+        "gmrf_comm_bcast_host": [vp, vp, i64, i32],
+        "gmrf_comm_allreduce_sum": [vp, vp, vp, i64],
+        "gmrf_bt_bcast_blocks_async": [vp, vp, i32, i64, i64, i32],
+        "gmrf_comm_wait": [vp, vp],
         "gmrf_bt_factor_begin_csc": [vp, i64, i64, vp, vp, vp, i32],
         "gmrf_bt_factor_step_async": [vp, i64, i64],
         "gmrf_bt_factor_end": [vp, P(i32)],
@@ -124,6 +139,7 @@ def load() -> C.CDLL:
         "gmrf_assemble_precision": [vp, vp, vp, dbl, vp],
         "gmrf_assemble_rhs": [vp, vp, vp, vp, vp, dbl, vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
+        "gmrf_spmm_rows": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],
         "gmrf_test_gemm_rate": [i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, P(dbl)],
         "gmrf_test_potrf_tile": [i32, vp, vp, P(i32)],

@@ -93,8 +93,32 @@ class CsrMatrix:
     def __matmul__(self, X):
         return self.matmul(X)
 
+    def matmul_rows(self, X):
+        """Y = S X for X stored node-major: an (n, k) C-contiguous NumPy array or torch CUDA tensor (the k
+        values of a node side by side).  This is the layout of the LDS-tiled SpMM kernel."""
+        n = self.shape[1]
+        if X.ndim != 2 or X.shape[0] != n:
+            raise ValueError("dimension mismatch")
+        k = X.shape[1]
+        if _is_torch(X):
+            import torch
+            if X.dtype != torch.float64:
+                raise TypeError("float64 required")
+            X = X.contiguous()
+            Y = torch.empty((self.shape[0], k), dtype=torch.float64, device=X.device)
+        else:
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            Y = np.empty((self.shape[0], k), dtype=np.float64)
+        _cabi.check(_cabi.load().gmrf_spmm_rows(self._h, _cabi.ptr(X), _cabi.ptr(Y), k, k, k))
+        return Y
+
     def matmul(self, X):
         n = self.shape[1]
+        # a row-major (n, k) operand already is node-major: no copy, LDS-tiled kernel
+        if getattr(X, "ndim", 0) == 2 and X.shape[1] > 1 and X.shape[0] == n:
+            row_major = X.is_contiguous() if _is_torch(X) else (X.flags.c_contiguous and not X.flags.f_contiguous)
+            if row_major and (not _is_torch(X) or X.dtype.is_floating_point):
+                return self.matmul_rows(X)
         xa, k, ld, one_d = _colmajor(X, n)
         store, view = _alloc_like(xa, self.shape[0], k, one_d)
         _cabi.check(_cabi.load().gmrf_spmm(self._h, _cabi.ptr(xa), _cabi.ptr(store), k, ld, self.shape[0]))
@@ -525,8 +549,36 @@ class TridiagonalCholeskyFactor:
         _cabi.check(self._lib.gmrf_bt_adopt_shape(self._h, n, n_blocks))
         self._set_shape(n, n_blocks)
 
-    def adopt_commit(self):
-        _cabi.check(self._lib.gmrf_bt_adopt_commit(self._h))
+    def get_layout(self) -> np.ndarray:
+        """Layout record of the stored coupling blocks: [cmin, rmax, n_row_tiles, kst...] (int64)."""
+        cnt = C.c_int64(0)
+        _cabi.check(self._lib.gmrf_bt_get_layout(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, dtype=np.int64)
+        _cabi.check(self._lib.gmrf_bt_get_layout(self._h, _cabi.ptr(out), out.size, C.byref(cnt)))
+        return out
+
+    def adopt_layout(self, n: int, n_blocks: int, layout=None):
+        """A rank that receives the factor: shape + the root's layout record, storage without factoring."""
+        if layout is None:
+            _cabi.check(self._lib.gmrf_bt_adopt_layout(self._h, n, n_blocks, None, 0))
+        else:
+            lay = np.ascontiguousarray(layout, dtype=np.int64)
+            _cabi.check(self._lib.gmrf_bt_adopt_layout(self._h, n, n_blocks, _cabi.ptr(lay), lay.size))
+        self._set_shape(n, n_blocks)
+
+    def adopt_commit(self, l_blocks_valid: bool = False):
+        _cabi.check(self._lib.gmrf_bt_adopt_commit(self._h, int(l_blocks_valid)))
+
+    def set_keep_l(self, keep: bool):
+        """keep = False: the blocks chos[i].L are not retained (sweeps, samples, variances and logdet do
+        not need them): 1.6 -> 0.84 GB per darcy256 posterior; `F.chos` then raises."""
+        _cabi.check(self._lib.gmrf_bt_set_keep_l(self._h, int(keep)))
+
+    def block_range(self, kind: int, i0: int, i1: int):
+        """(first element, element count, problem stride) of blocks [i0, i1) inside a factor buffer."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _cabi.check(self._lib.gmrf_bt_block_range(self._h, kind, i0, i1, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
 
     def factor_begin(self, A, N_blocks: int):
         A = sp.csc_matrix(A)
@@ -629,3 +681,49 @@ def extract_blocks(I, J, V, block_size: int):
 
 def logdet(L: TridiagonalCholeskyFactor) -> float:
     return L.logdet()
+
+
+class Comm:
+    """RCCL communicator of this process (one per GPU) through the C ABI -- what a Julia host uses to
+    share a factor over xGMI (include/gmrf_hip.h, "multi-GPU").  `unique_id()` on rank 0, ship the
+    128 bytes to the other ranks by any means, then `Comm(device, rank, world, id)` everywhere."""
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        _cabi.check(_cabi.load().gmrf_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def __init__(self, device: int, rank: int, world: int, uid: bytes):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        self._lib = _cabi.load()
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        _cabi.check(self._lib.gmrf_comm_create(device, rank, world, C.cast(buf, C.c_void_p), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.gmrf_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bcast_host(self, arr: np.ndarray, root: int = 0) -> np.ndarray:
+        """In-place broadcast of a small contiguous NumPy array."""
+        _cabi.check(self._lib.gmrf_comm_bcast_host(self._h, _cabi.ptr(arr), arr.nbytes, root))
+        return arr
+
+    def bcast_blocks_async(self, F: TridiagonalCholeskyFactor, i0: int, i1: int, root: int = 0, with_l: bool = False):
+        _cabi.check(self._lib.gmrf_bt_bcast_blocks_async(F._h, self._h, root, i0, i1, int(with_l)))
+
+    def wait(self, F: TridiagonalCholeskyFactor):
+        _cabi.check(self._lib.gmrf_comm_wait(F._h, self._h))
+
+    def allreduce_sum(self, dev_tensor, F: Optional[TridiagonalCholeskyFactor] = None):
+        _cabi.check(self._lib.gmrf_comm_allreduce_sum(self._h, F._h if F is not None else None, _cabi.ptr(dev_tensor),
+                                                      dev_tensor.numel()))
+        return dev_tensor

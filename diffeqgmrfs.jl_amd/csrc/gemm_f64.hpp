@@ -50,6 +50,12 @@ struct GemmArgs {
     const double* D;                     // addend: C = beta * D + alpha * A B  (nullptr: D = C, in place)
     int64_t ldd, pD;                     // its row stride and problem stride
     unsigned long long* stamps;          // diagnostic (tests): s_memtime / s_memrealtime of block 0
+    // Optional per-tile K bounds (device arrays indexed by 64-wide tile, values multiples of 64): the
+    // staircase of the coupling blocks C_i (row tile t of C is zero left of column kst[t]; column
+    // tile u is zero below row mend[u]).  K starts at max(kb_m[bm], kb_n[bn]) and ends at ke_n[bn].
+    const int* kb_m = nullptr;
+    const int* kb_n = nullptr;
+    const int* ke_n = nullptr;
 };
 
 constexpr int GEMM_BM = 64;
@@ -112,7 +118,7 @@ __device__ __forceinline__ void gemm_tile_order(const GemmArgs& g, int& bm, int&
         bn = tile - bm * (bm + 1) / 2;
     } else {
         const bool cls_n = (g.tri & (TRI_B_LOWER | TRI_B_UPPER)) || !(g.tri & (TRI_A_LOWER | TRI_A_UPPER));
-        const bool desc = cls_n ? (g.tri & TRI_B_UPPER) != 0 : (g.tri & TRI_A_LOWER) != 0;
+        const bool desc = cls_n ? ((g.tri & TRI_B_UPPER) != 0 || (g.ke_n && !g.kb_n)) : (g.tri & TRI_A_LOWER) != 0;
         const int ncls = cls_n ? nx : ny, other = cls_n ? ny : nx;
         int c = q / (other * nzg);
         const int rem = q % (other * nzg);
@@ -166,6 +172,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     if (g.tri & TRI_A_UPPER) kb = max(kb, m0);
     if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
     if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + GEMM_BN);
+    if (g.kb_m) kb = max(kb, g.kb_m[bm]);
+    if (g.kb_n) kb = max(kb, g.kb_n[bn]);
+    if (g.ke_n) ke = min(ke, g.ke_n[bn]);
 
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double* As0 = gsm;                               // [2][64 * LD]
@@ -295,6 +304,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_big(GemmArgs g) {
     if (g.tri & TRI_A_UPPER) kb = max(kb, m0);
     if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
     if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + BT);
+    // staircase bounds are kept per 64-wide tile and are monotone: a 128-wide tile starts at its first half's
+    // bound and ends at its second half's
+    if (g.kb_m) kb = max(kb, g.kb_m[2 * bm]);
+    if (g.kb_n) kb = max(kb, g.kb_n[2 * bn]);
+    if (g.ke_n) ke = min(ke, g.ke_n[2 * bn + 1]);
 
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double* As0 = gsm;                      // [2][A_STAGE]
@@ -444,6 +458,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_ll(GemmArgs g) {
     if (g.tri & TRI_A_UPPER) kb = max(kb, m0);
     if (g.tri & TRI_B_LOWER) kb = max(kb, n0);
     if (g.tri & TRI_B_UPPER) ke = min(ke, n0 + BT);
+    if (g.kb_m) kb = max(kb, g.kb_m[bm >> 1]);
+    if (g.kb_n) kb = max(kb, g.kb_n[bn >> 1]);
+    if (g.ke_n) ke = min(ke, g.ke_n[bn >> 1]);
 
     __shared__ __attribute__((aligned(16))) double As0[2 * BT * LD];
     __shared__ __attribute__((aligned(16))) double Bs0[2 * BT * LD];

@@ -7,13 +7,16 @@
 // matrix-panel products.  Launch sequences are captured once into HIP graphs and replayed
 // (the chains are launch-latency bound: ~60 dependent launches per block).
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -84,6 +87,12 @@ struct gmrf_csr {
     double* d_stage_x = nullptr;
     double* d_stage_y = nullptr;
     int64_t stage_cap = 0;
+    // tile plan of csr_spmm_tiles (node-major right-hand sides), built on first use
+    int plan_state = 0;                // 0: not built, 1: usable, -1: a tile exceeds the LDS image
+    int64_t* d_tile_uptr = nullptr;    // [tiles + 1] ranges into d_ucols
+    int32_t* d_ucols = nullptr;        // distinct columns of every tile, ascending
+    uint16_t* d_lidx = nullptr;        // per entry: index of its column in the tile's list
+    int64_t n_ucols = 0;
 };
 
 // ------------------------------------------------------------------------------------ handle
@@ -109,7 +118,18 @@ struct gmrf_handle {
     double* d_nz_stage = nullptr;      // staging for host nzval
     std::vector<int64_t> diag_first, diag_count, low_first, low_count;
     bool analyzed = false;
-    int64_t cmin = 0, rmax = 0;        // lower blocks B_i are zero left of column cmin and below row rmax (64-aligned)
+    // Layout of the coupling blocks C_i of the CURRENT factor (set by the symbolic phase, by
+    // gmrf_bt_adopt_layout for a factor received by broadcast, "dense" for an imported image): C_i is
+    // zero left of column cmin and below row rmax (64-aligned), and inside that window row tile t
+    // (64 rows) is zero left of column cmin + kst[t] -- the staircase a FEM coupling block has
+    // (kst: monotone envelope over all blocks).  C is STORED as the window only: [rmax][bsp - cmin].
+    int64_t cmin = 0, rmax = 0;
+    std::vector<int> kst, mend;        // mend[u]: column tile u (64 columns from cmin) is zero below row mend[u]
+    int* d_kst = nullptr;              // device copies: [bsp / 64] each
+    int* d_mend = nullptr;
+    int kst_cap = 0;
+    double c_streamed = 0.0;           // doubles of one C_i inside the staircase (what a k = 1 sweep reads)
+    double g2_tile_k = 0.0;            // sum over lower tiles of the K extent of S = -C C^T (flop accounting)
     bool c_dirty = false;              // C must be re-zeroed (new pattern)
     int* d_lo_rowptr = nullptr;        // [N][bsp + 1] row-wise view of the lower blocks' entry lists
     int64_t lo_row_max = 0;            // most entries in one row of a lower block
@@ -118,6 +138,10 @@ struct gmrf_handle {
     // factor storage
     double *d_L = nullptr, *d_C = nullptr, *d_Linv = nullptr;
     bool external_storage = false;
+    bool keep_l = true;                // false: L_i lives in a one-block work buffer (sweeps need Linv and C only)
+    bool l_valid = false;              // d_L holds the blocks of the current factor (get_block / export / logdet from L)
+    int64_t alloc_rm = 0, alloc_wc = 0;
+    bool alloc_keep_l = true;
     double *d_S = nullptr, *d_B = nullptr, *d_T = nullptr, *d_W = nullptr;
     int* d_info = nullptr;
     double* d_logdet = nullptr;
@@ -137,6 +161,7 @@ struct gmrf_handle {
     bool sweep_no_gemm = false;        // keep 64-multiples of right-hand sides on sweep_mm (comparison)
     unsigned long long* dbg_stamps = nullptr;   // test hook: phase stamps of the fused panel step
     bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
+    bool no_staircase = false;         // treat the coupling window as dense (comparison; takes effect at the next analysis)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -207,8 +232,10 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
                         double alpha, const double* A, int64_t lda, const double* B, int64_t ldb,
                         double beta, double* C, int64_t ldc, int64_t pA, int64_t pB, int64_t pC,
                         int batch = 1, int64_t sA = 0, int64_t sB = 0, int64_t sC = 0, const double* D = nullptr,
-                        int64_t ldd = 0, int64_t pD = 0, int pclass = 0, double pwork = -1.0) {
+                        int64_t ldd = 0, int64_t pD = 0, int pclass = 0, double pwork = -1.0,
+                        const int* kb_m = nullptr, const int* kb_n = nullptr, const int* ke_n = nullptr) {
     GemmArgs g;
+    g.kb_m = kb_m; g.kb_n = kb_n; g.ke_n = ke_n;
     g.D = D; g.ldd = ldd; g.pD = pD;
     g.A = A; g.B = B; g.C = C;
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
@@ -232,36 +259,108 @@ static void free_dev(void* p) {
     if (p) (void)hipFree(p);
 }
 
+// element counts / strides of the factor arrays (doubles)
+static inline int64_t blk_elems(const gmrf_handle* h) { return h->bsp * h->bsp; }
+static inline int64_t c_ld(const gmrf_handle* h) { return h->bsp - h->cmin; }                      // row stride of a stored C_i
+static inline int64_t c_blk(const gmrf_handle* h) { return h->rmax * (h->bsp - h->cmin); }         // one stored C_i
+static inline int64_t stride_pL(const gmrf_handle* h) { return blk_elems(h) * (h->keep_l ? h->N : 1); }
+static inline int64_t stride_pX(const gmrf_handle* h) { return blk_elems(h) * h->N; }
+static inline int64_t stride_pC(const gmrf_handle* h) { return c_blk(h) * std::max<int64_t>(h->N - 1, 1); }
+static inline double* l_block(const gmrf_handle* h, int64_t i) { return h->d_L + (h->keep_l ? i * blk_elems(h) : 0); }
+
+// Layout of the coupling blocks (see gmrf_handle): validates, derives mend / the accounting sums and
+// uploads the per-tile bounds.  kst_abs[t]: first non-zero column of row tile t (absolute, any value;
+// it is rounded down to 64 and replaced by its monotone envelope).  Needs set_shape first.
+static gmrf_status set_layout(gmrf_handle* h, int64_t cmin, int64_t rmax, const std::vector<int64_t>& kst_abs) {
+    const int64_t bsp = h->bsp;
+    if (cmin < 0 || cmin >= bsp || cmin % 64 || rmax <= 0 || rmax > bsp || rmax % 64) return bad_shape("bad coupling-block layout");
+    const int nrt = (int)(rmax / 64), nct = (int)((bsp - cmin) / 64), ntile = (int)(bsp / 64);
+    if ((int)kst_abs.size() != nrt) return bad_shape("bad coupling-block layout (row tiles)");
+    (void)hipStreamSynchronize(h->stream);
+    destroy_graphs(h);
+    h->cmin = cmin; h->rmax = rmax;
+    h->kst.assign((size_t)ntile, 0);
+    int64_t run = bsp - 64;                                   // envelope from the bottom: kst[t] = min over t' >= t
+    for (int t = nrt - 1; t >= 0; --t) {
+        int64_t v = std::min(std::max(kst_abs[t], cmin), bsp - 64);
+        run = std::min(run, (v / 64) * 64);
+        h->kst[t] = (int)(run - cmin);
+    }
+    if (nrt > 0) h->kst[0] = 0;                               // cmin is the smallest start by definition
+    for (int t = nrt; t < ntile; ++t) h->kst[t] = (int)(bsp - cmin);      // rows below rmax: empty
+    h->mend.assign((size_t)ntile, (int)rmax);
+    for (int u = 0; u < nct; ++u) {
+        int m = 0;
+        for (int t = 0; t < nrt; ++t) if (h->kst[t] <= 64 * u) m = 64 * (t + 1);
+        h->mend[u] = m;
+    }
+    h->c_streamed = 0.0; h->g2_tile_k = 0.0;
+    for (int t = 0; t < nrt; ++t) {
+        h->c_streamed += 64.0 * (double)(bsp - cmin - h->kst[t]);
+        h->g2_tile_k += (double)(t + 1) * (double)(bsp - cmin - h->kst[t]);    // tiles (t, 0..t) start at kst[t]
+    }
+    if (!h->d_kst || !h->d_mend || h->kst_cap < ntile) {
+        free_dev(h->d_kst); free_dev(h->d_mend); h->d_kst = h->d_mend = nullptr; h->kst_cap = 0;
+        HIPCHK(hipMalloc(&h->d_kst, sizeof(int) * ntile));
+        HIPCHK(hipMalloc(&h->d_mend, sizeof(int) * ntile));
+        h->kst_cap = ntile;
+    }
+    HIPCHK(hipMemcpyAsync(h->d_kst, h->kst.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->d_mend, h->mend.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->c_dirty = true;
+    return GMRF_OK;
+}
+
+static gmrf_status set_layout_dense(gmrf_handle* h) {
+    return set_layout(h, 0, h->bsp, std::vector<int64_t>((size_t)(h->bsp / 64), 0));
+}
+
 static gmrf_status alloc_work(gmrf_handle* h);
 static gmrf_status alloc_factor(gmrf_handle* h) {
-    if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->alloc_B == h->B && h->d_L) return GMRF_OK;
-    if (h->external_storage) { g_last_error = "external factor storage does not match the shape"; return GMRF_ERR_BAD_SHAPE; }
+    if (h->alloc_N == h->N && h->alloc_bsp == h->bsp && h->alloc_B == h->B && h->alloc_rm == h->rmax &&
+        h->alloc_wc == c_ld(h) && h->alloc_keep_l == h->keep_l && h->d_Linv)
+        return GMRF_OK;
     destroy_graphs(h);
+    if (h->external_storage) {
+        // caller-owned L / C / Linv (sized by gmrf_bt_storage_bytes for this shape and batch): only the
+        // work buffers follow the layout
+        if (h->alloc_N != h->N || h->alloc_bsp != h->bsp || h->alloc_B != h->B || h->alloc_keep_l != h->keep_l) {
+            g_last_error = "external factor storage does not match the shape / batch";
+            return GMRF_ERR_BAD_SHAPE;
+        }
+        h->alloc_rm = h->rmax; h->alloc_wc = c_ld(h);
+        h->l_valid = false;
+        return GMRF_OK;
+    }
     free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv);
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
     free_dev(h->d_logdet);
     h->d_L = h->d_C = h->d_Linv = h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
-    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double) * (size_t)h->B;
-    HIPCHK(hipMalloc(&h->d_L, blk * h->N));
+    h->l_valid = false;
+    const size_t blk = (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B;
+    HIPCHK(hipMalloc(&h->d_L, blk * (h->keep_l ? h->N : 1)));
     HIPCHK(hipMalloc(&h->d_Linv, blk * h->N));
-    HIPCHK(hipMalloc(&h->d_C, blk * std::max<int64_t>(h->N - 1, 1)));
+    HIPCHK(hipMalloc(&h->d_C, (size_t)stride_pC(h) * sizeof(double) * (size_t)h->B));
+    // tiles strictly above the block diagonal of L / Linv are never written: keep them zero
+    HIPCHK(hipMemsetAsync(h->d_L, 0, blk * (h->keep_l ? h->N : 1), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_Linv, 0, blk * h->N, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_C, 0, (size_t)stride_pC(h) * sizeof(double) * (size_t)h->B, h->stream));
+    h->c_dirty = false;
     GCHK(alloc_work(h));
+    h->alloc_rm = h->rmax; h->alloc_wc = c_ld(h); h->alloc_keep_l = h->keep_l;
     return GMRF_OK;
 }
 
 static gmrf_status alloc_work(gmrf_handle* h) {
-    const size_t blk = (size_t)h->bsp * h->bsp * sizeof(double) * (size_t)h->B;
+    const size_t blk = (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B;
     HIPCHK(hipMalloc(&h->d_S, blk));
     HIPCHK(hipMalloc(&h->d_B, blk));
     HIPCHK(hipMalloc(&h->d_T, blk));
     HIPCHK(hipMalloc(&h->d_W, blk));
     HIPCHK(hipMalloc(&h->d_logdet, sizeof(double) * h->N * h->B));
-    // tiles strictly above the block diagonal of L / Linv are never written: keep them zero
-    HIPCHK(hipMemsetAsync(h->d_L, 0, blk * h->N, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_Linv, 0, blk * h->N, h->stream));
-    HIPCHK(hipMemsetAsync(h->d_C, 0, blk * std::max<int64_t>(h->N - 1, 1), h->stream));
     h->alloc_N = h->N; h->alloc_bsp = h->bsp; h->alloc_B = h->B;
-    h->stats.factor_bytes = (int64_t)(blk * (3 * h->N - 1));
+    h->stats.factor_bytes = (int64_t)(blk * ((h->keep_l ? 2 : 1) * h->N) + (size_t)stride_pC(h) * sizeof(double) * (size_t)h->B);
     return GMRF_OK;
 }
 
@@ -290,7 +389,6 @@ static gmrf_status set_shape(gmrf_handle* h, int64_t n, int64_t N) {
     }
     h->n = n; h->N = N; h->bs = bs;
     h->bsp = 64 * next_pow2((bs + 63) / 64);
-    if (!h->analyzed) { h->cmin = 0; h->rmax = h->bsp; }      // no pattern known (adopted / imported factor): all of C
     h->n_pad = h->bsp * N;
     h->stats.n = n; h->stats.n_blocks = N; h->stats.block_size = bs; h->stats.block_size_padded = h->bsp;
     h->stats.factor_flops = ((double)N * bs * bs * bs / 3.0 + (double)(N - 1) * 2.0 * bs * bs * bs) * (double)h->B;
@@ -337,18 +435,24 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
         std::stable_sort(byrow.begin(), byrow.end(), [](const HostEntry& x, const HostEntry& y) { return x.key < y.key; });
         for (auto& e : byrow) { keys.push_back(e.key); src.push_back(e.src); }
     }
-    // zero structure shared by all lower blocks: first non-zero column, last non-zero row
-    int64_t cmin = h->bsp, rmax = 0;
-    for (int64_t i = 1; i < N; ++i)
-        for (auto& e : lo[i]) {
-            const int64_t r = (int64_t)(e.key >> 32), c = (int64_t)(e.key & 0xffffffffu);
-            cmin = std::min(cmin, c); rmax = std::max(rmax, r + 1);
-        }
-    if (rmax == 0) { cmin = 0; rmax = 64; }
-    h->cmin = (cmin / 64) * 64;
-    h->rmax = std::min<int64_t>(h->bsp, (rmax + 63) / 64 * 64);
-    h->c_dirty = true;
-    destroy_graphs(h);
+    // zero structure shared by all lower blocks: first non-zero column, last non-zero row, and per
+    // 64-row tile the first non-zero column (the staircase; set_layout takes its monotone envelope)
+    {
+        int64_t cmin = h->bsp, rmax = 0;
+        std::vector<int64_t> first((size_t)(h->bsp / 64), h->bsp);
+        for (int64_t i = 1; i < N; ++i)
+            for (auto& e : lo[i]) {
+                const int64_t r = (int64_t)(e.key >> 32), c = (int64_t)(e.key & 0xffffffffu);
+                cmin = std::min(cmin, c); rmax = std::max(rmax, r + 1);
+                first[(size_t)(r / 64)] = std::min(first[(size_t)(r / 64)], c);
+            }
+        if (rmax == 0) { cmin = 0; rmax = 64; first[0] = 0; }
+        cmin = (cmin / 64) * 64;
+        rmax = std::min<int64_t>(h->bsp, (rmax + 63) / 64 * 64);
+        first.resize((size_t)(rmax / 64));
+        if (h->no_staircase) std::fill(first.begin(), first.end(), cmin);
+        GCHK(set_layout(h, cmin, rmax, first));
+    }
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     h->d_keys = nullptr; h->d_vals = nullptr; h->d_src = nullptr; h->d_nz_stage = nullptr;
     h->n_entries = (int64_t)keys.size();
@@ -458,7 +562,7 @@ static gmrf_status load_values(gmrf_handle* h, const double* nzval) {
 static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double* T, int lo, int hi, int half) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
-    const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
+    const int64_t pL = stride_pL(h), pX = stride_pX(h), pW = (int64_t)bsp * bsp;
     for (int hh = lo; hh <= hi && hh < bsp; hh *= 2) {
         int pairs = bsp / (2 * hh), first = 0;
         if (half >= 0) { pairs /= 2; first = half * pairs; }
@@ -466,10 +570,10 @@ static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double*
         const int64_t st = (int64_t)2 * hh * ld + 2 * hh, o = first * st;
         // T21 = L21 * X11
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + o + (int64_t)hh * ld, ld, X + o, ld, 0.0,
-                  T + o + (int64_t)hh * ld, ld, pLX, pLX, pW, pairs, st, st, st));
+                  T + o + (int64_t)hh * ld, ld, pL, pX, pW, pairs, st, st, st));
         // X21 = -X22 * T21
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + o + (int64_t)hh * ld + hh, ld,
-                  T + o + (int64_t)hh * ld, ld, 0.0, X + o + (int64_t)hh * ld, ld, pLX, pW, pLX, pairs, st, st, st));
+                  T + o + (int64_t)hh * ld, ld, 0.0, X + o + (int64_t)hh * ld, ld, pX, pW, pX, pairs, st, st, st));
     }
     return GMRF_OK;
 }
@@ -478,13 +582,13 @@ static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double*
 static gmrf_status doubling_top(gmrf_handle* h, double* L, double* X, double* T, bool first_product, bool second_product) {
     const int bsp = (int)h->bsp, hh = bsp / 2;
     const int64_t ld = bsp;
-    const int64_t pLX = (int64_t)bsp * bsp * h->N, pW = (int64_t)bsp * bsp;
+    const int64_t pL = stride_pL(h), pX = stride_pX(h), pW = (int64_t)bsp * bsp;
     if (first_product)
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld, ld, X, ld, 0.0, T + (int64_t)hh * ld, ld,
-                  pLX, pLX, pW));
+                  pL, pX, pW));
     if (second_product)
         GCHK(gemm(h, false, true, hh, hh, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld, T + (int64_t)hh * ld, ld, 0.0,
-                  X + (int64_t)hh * ld, ld, pLX, pW, pLX));
+                  X + (int64_t)hh * ld, ld, pX, pW, pX));
     return GMRF_OK;
 }
 
@@ -527,7 +631,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
         sa.info = h->d_info; sa.blk = blk_id; sa.dbg = h->dbg_stamps;
-        sa.pS = (int64_t)bsp * bsp; sa.pLX = (int64_t)bsp * bsp * h->N; sa.blk_per_problem = (int)h->N;
+        sa.pS = (int64_t)bsp * bsp; sa.pL = stride_pL(h); sa.pX = stride_pX(h); sa.blk_per_problem = (int)h->N;
         const int m = nt - j - 1;
         const int cend = std::min(nt, (j / pw + 1) * pw);  // first column tile outside this panel
         sa.cend = cend;
@@ -565,7 +669,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             const int j0 = cend - pw, mr = nt - cend;
             const double* Lp = L + (int64_t)cend * 64 * ld + (int64_t)j0 * 64;
             double* Sr = S + (int64_t)cend * 64 * ld + (int64_t)cend * 64;
-            GCHK(gemm(h, false, false, mr * 64, mr * 64, pw * 64, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, Sr, ld, sa.pLX, sa.pLX,
+            GCHK(gemm(h, false, false, mr * 64, mr * 64, pw * 64, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, Sr, ld, sa.pL, sa.pL,
                       sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * 64.0 * 64.0 * (pw * 64.0) * (mr * (mr + 1) / 2) * (double)h->B));
         }
         if (overlap && j + 1 == nt / 2) {
@@ -596,10 +700,11 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     const int64_t ld = bsp;
     const size_t blk_bytes = (size_t)bsp * bsp * sizeof(double) * (size_t)h->B;
     const int64_t bstride = (int64_t)bsp * bsp;
-    const int64_t pLX = bstride * h->N, pC = bstride * std::max<int64_t>(h->N - 1, 1);
+    const int64_t pX = stride_pX(h), pC = stride_pC(h);
+    const int64_t ldc = c_ld(h), cstride = c_blk(h);
     const unsigned nb = (unsigned)h->B;
     for (int64_t i = i0; i < i1; ++i) {
-        double* L = h->d_L + i * bstride;
+        double* L = l_block(h, i);
         double* X = h->d_Linv + i * bstride;
         // S = D_i - C C^T is built as  S := -C C^T (GEMM, beta = 0)  then  S += D_i (scatter): same
         // single rounding as D - acc, and only the rows the product does not write (>= rmax) need
@@ -612,7 +717,7 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
             HIPCHK(hipGetLastError());
         }
         if (i > 0) {
-            double* C = h->d_C + (i - 1) * bstride;
+            double* C = h->d_C + (i - 1) * cstride;              // stored window: rows 0 .. rm, columns cm ..
             const double* Xp = h->d_Linv + (i - 1) * bstride;
             const bool sparse_g1 = h->sparse_b && !h->dense_g1;
             if (!sparse_g1) {          // dense image of B for the GEMM route
@@ -625,30 +730,36 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 }
             }
             // C = B * Linv_{i-1}^T      (src/tridiagonal_cholesky.jl:74).  B is zero left of column
-            // cmin and below row rmax, hence C is zero there too and only the rest is computed.
+            // cmin and below row rmax, hence C is zero there too and only the rest is computed; inside that
+            // window row tile t of B -- and of C, Linv being lower triangular -- is zero left of kst[t].
             const int cm = (int)h->cmin, rm = (int)h->rmax;
+            const int W = bsp - cm;
             if (sparse_g1) {
                 BxtArgs ba;
                 ba.rowptr = h->d_lo_rowptr + i * (h->bsp + 1); ba.keys = h->d_keys;
                 ba.vals = h->d_vals; ba.n_entries = h->n_entries;
-                ba.X = Xp; ba.C = C; ba.ld = ld; ba.pX = pLX; ba.pC = pC; ba.cm = cm; ba.rm = rm;
-                const int W = bsp - cm;
+                ba.X = Xp; ba.C = C; ba.ld = ld; ba.ldc = ldc; ba.pX = pX; ba.pC = pC; ba.cm = cm; ba.rm = rm;
+                ba.kst = h->d_kst;
                 const int rch = (rm + 255) / 256;
                 ba.cw = ((int64_t)(W / 64) * rch * nb >= 512) ? 64 : (((int64_t)(W / 32) * rch * nb >= 512) ? 32 : 16);
                 ba.bsp = bsp;
                 const dim3 grid((unsigned)((W / ba.cw) * rch * (int)nb));
-                ProfScope ps(h, 10, 8.0 * ((double)rm * W + 0.5 * (double)W * W) * (double)h->B);
+                // streamed bytes: C inside the staircase (written) + the rows of Linv from the first gathered column on (read)
+                ProfScope ps(h, 10, 8.0 * (h->c_streamed + 0.5 * (double)W * W) * (double)h->B);
                 if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
                 else if (h->lo_row_max <= 16) hipLaunchKernelGGL(spmm_bxt<16>, grid, dim3(256), 0, h->stream, ba);
                 else hipLaunchKernelGGL(spmm_bxt<32>, grid, dim3(256), 0, h->stream, ba);
                 HIPCHK(hipGetLastError());
             } else {
-                GCHK(gemm(h, false, false, rm, bsp - cm, bsp - cm, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
-                          Xp + (int64_t)cm * ld + cm, ld, 0.0, C + cm, ld, bstride, pLX, pC));
+                GCHK(gemm(h, false, false, rm, W, W, TRI_B_UPPER, 0, 1.0, h->d_B + cm, ld,
+                          Xp + (int64_t)cm * ld + cm, ld, 0.0, C, ldc, bstride, pX, pC, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0,
+                          h->d_kst, nullptr, nullptr));
             }
-            // S = D - C C^T             (src/tridiagonal_cholesky.jl:77): the product part
-            GCHK(gemm(h, false, false, rm, rm, bsp - cm, 0, 1, -1.0, C + cm, ld, C + cm, ld, 0.0, h->d_S, ld, pC, pC,
-                      bstride));
+            // S = D - C C^T             (src/tridiagonal_cholesky.jl:77): the product part.  Tile (R, R') sums over
+            // the columns from max(kst[R], kst[R']) on -- the rest of the two row tiles is structurally zero.
+            GCHK(gemm(h, false, false, rm, rm, W, 0, 1, -1.0, C, ldc, C, ldc, 0.0, h->d_S, ld, pC, pC,
+                      bstride, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * 64.0 * 64.0 * h->g2_tile_k * (double)h->B,
+                      h->d_kst, h->d_kst, nullptr));
         }
         if (h->diag_count[i] > 0) {
             hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256), nb), dim3(256), 0,
@@ -662,6 +773,12 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
             HIPCHK(hipGetLastError());
         }
         GCHK(potrf_block(h, h->d_S, L, X, h->d_T, (int)(i + 1)));
+        if (!h->keep_l) {
+            // L_i lives in a work buffer that the next block overwrites: its log-determinant part is taken now
+            hipLaunchKernelGGL(logdet_blocks, dim3(1, nb), dim3(256), 0, h->stream, L, bstride, ld, (int)h->bs,
+                               h->d_logdet + i, stride_pL(h), h->N);
+            HIPCHK(hipGetLastError());
+        }
     }
     return GMRF_OK;
 }
@@ -699,6 +816,7 @@ static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
         return GMRF_ERR_NOT_SPD;
     }
     h->factored = true;
+    h->l_valid = h->keep_l;
     return GMRF_OK;
 }
 
@@ -706,7 +824,7 @@ static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* 
     if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
     GCHK(alloc_factor(h));
     if (h->c_dirty) {
-        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * h->bsp * h->bsp * std::max<int64_t>(h->N - 1, 1) * h->B, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
         h->c_dirty = false;
     }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
@@ -736,15 +854,17 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
     s.ld = ld;
     const int nprob = (int)h->B;
     const int64_t pPanel = (int64_t)kp * npad;
-    const int64_t pLX = bstride * N, pCm = bstride * std::max<int64_t>(N - 1, 1);
-    // C_i is zero left of column cmin and below row rmax (symbolic phase): only that sub-block is
-    // applied.  forward: rows m < rm take sums over k >= cm; backward (C^T): outputs k >= cm take
-    // sums over m < rm.
+    const int64_t pX = stride_pX(h), pCm = stride_pC(h);
+    const int64_t ldc = c_ld(h), cstride = c_blk(h);
+    // C_i is stored as its non-zero window (rows 0 .. rm, columns cm ..); inside it row tile t is zero
+    // left of kst[t] (staircase).  forward: rows m < rm take sums over k >= cm + kst; backward (C^T):
+    // outputs k >= cm take sums over the rows m < mend.
     const int cm = (int)h->cmin, rm = (int)h->rmax, wc = bsp - cm;
-    // class 3 (k = 1): algorithmic bytes of the block read; class 2: flops of the panel product
+    // class 3 (k = 1): bytes the kernels stream (C inside the staircase, the lower triangle of Linv);
+    // class 2: flops of the panel product
     const int pclass = (kp == 1) ? 3 : 2;
-    const double blk_bytes_c = ((kp == 1) ? 8.0 * bsp * (double)bsp : 2.0 * bsp * (double)bsp * kp) * nprob;
-    const double blk_bytes_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
+    const double blk_work_c = ((kp == 1) ? 8.0 * h->c_streamed : 2.0 * h->c_streamed * kp) * nprob;
+    const double blk_work_t = ((kp == 1) ? 4.0 * bsp * (double)(bsp + 1) : 1.0 * bsp * (double)(bsp + 1) * kp) * nprob;
     // 64-multiples of right-hand sides go through the GEMM kernel (panel = the [m][k] operand) when
     // the batch gives it enough 64 x 64 tiles; a lone problem stays on sweep_mm (256 workgroups)
     const bool via_gemm = (kp % 64 == 0) && !h->sweep_no_gemm && (int64_t)nprob * (bsp / 64) * (kp / 64) >= 128;
@@ -755,19 +875,21 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
             // forward: P_i -= C_{i-1} y_{i-1};  backward: P_i -= C_i^T x_{i+1}      (in place)
             const int64_t ci = backward ? i : (i - 1);
             const int64_t prev = backward ? (i + 1) : (i - 1);
-            const double* Cs = h->d_C + ci * bstride + cm;            // columns cm .. of rows 0 .. rm
+            const double* Cs = h->d_C + ci * cstride;
             const double* xin = Yout + prev * bsp + (backward ? 0 : cm);
             double* out = rhs + (backward ? cm : 0);
             const int rows = backward ? wc : rm, kdim = backward ? rm : wc;
             if (via_gemm) {
                 // T[r][m] = P[r][m] - sum_k y[r][k] c(k,m): the panel is the [m][k] operand, the block the other
-                GCHK(gemm(h, false, backward, kp, rows, kdim, 0, 0, -1.0, xin, npad, Cs, ld, 1.0, out, npad, pPanel, pCm,
-                          pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
+                GCHK(gemm(h, false, backward, kp, rows, kdim, 0, 0, -1.0, xin, npad, Cs, ldc, 1.0, out, npad, pPanel, pCm,
+                          pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * h->c_streamed * kp * nprob,
+                          nullptr, backward ? nullptr : h->d_kst, backward ? h->d_mend : nullptr));
             } else {
-                s.Mat = Cs; s.Xin = xin; s.ldx = npad; s.Bin = out; s.ldb = npad; s.Out = out; s.ldo = npad;
+                s.Mat = Cs; s.ld = ldc; s.Xin = xin; s.ldx = npad; s.Bin = out; s.ldb = npad; s.Out = out; s.ldo = npad;
                 s.rows = rows; s.kdim = kdim; s.sub = 1;
                 s.pMat = pCm; s.pXin = pPanel; s.pBin = pPanel; s.pOut = pPanel;
-                ProfScope ps(h, pclass, blk_bytes_c);
+                s.kst = h->d_kst; s.mend = h->d_mend;
+                ProfScope ps(h, pclass, blk_work_c);
                 HIPCHK(launch_sweep(h->stream, backward, false, kp, s, nprob));
             }
         }
@@ -777,12 +899,13 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
         if (via_gemm) {
             // forward: Linv stored [m][k], zero for k > m; backward: Linv^T, stored [k][m], zero for k < m
             GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs, npad, X, ld, 0.0,
-                      yout, npad, pPanel, pLX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
+                      yout, npad, pPanel, pX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
         } else {
-            s.Mat = X; s.Xin = rhs; s.ldx = npad; s.Bin = nullptr; s.ldb = 0; s.Out = yout; s.ldo = npad;
+            s.Mat = X; s.ld = ld; s.Xin = rhs; s.ldx = npad; s.Bin = nullptr; s.ldb = 0; s.Out = yout; s.ldo = npad;
             s.rows = bsp; s.kdim = bsp; s.sub = 0;
-            s.pMat = pLX; s.pXin = pPanel; s.pBin = 0; s.pOut = pPanel;
-            ProfScope ps(h, pclass, blk_bytes_t);
+            s.pMat = pX; s.pXin = pPanel; s.pBin = 0; s.pOut = pPanel;
+            s.kst = nullptr; s.mend = nullptr;
+            ProfScope ps(h, pclass, blk_work_t);
             HIPCHK(launch_sweep(h->stream, backward, true, kp, s, nprob));
         }
     }
@@ -874,8 +997,9 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     (void)hipStreamSynchronize(h->stream);
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
-    free_dev(h->d_lo_rowptr);
+    free_dev(h->d_lo_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
+    else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
     free_dev(h->d_info); free_dev(h->d_logdet);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
@@ -924,6 +1048,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 4) != 0) != h->sweep_no_gemm) { destroy_graphs(h); h->sweep_no_gemm = (eager & 4) != 0; }
     if (((eager & 8) != 0) != h->dense_g1) { destroy_graphs(h); h->dense_g1 = (eager & 8) != 0; }
     if (((eager & 16) != 0) != h->fork_graph) { destroy_graphs(h); h->fork_graph = (eager & 16) != 0; }
+    h->no_staircase = (eager & 32) != 0;
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -958,7 +1083,7 @@ gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks
     if (!h->analyzed) { g_last_error = "no sparsity pattern analysed"; return GMRF_ERR_NO_FACTOR; }
     GCHK(alloc_factor(h));
     if (h->c_dirty) {
-        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * h->bsp * h->bsp * std::max<int64_t>(h->N - 1, 1) * h->B, h->stream));
+        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
         h->c_dirty = false;
     }
     GCHK(load_values(h, nzval));
@@ -1022,52 +1147,139 @@ gmrf_status gmrf_bt_factor_blocks(gmrf_handle* h, int64_t n, int64_t n_blocks, c
 }
 
 
-gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t* bytes_L, int64_t* bytes_C, int64_t* bytes_Linv) {
-    if (n <= 0 || n_blocks <= 0 || n % n_blocks != 0 || !bytes_L || !bytes_C || !bytes_Linv)
-        return bad_shape("n must be a positive multiple of N_blocks");
+gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t batch, int64_t* bytes_L, int64_t* bytes_C,
+                                  int64_t* bytes_Linv) {
+    if (n <= 0 || n_blocks <= 0 || n % n_blocks != 0 || batch < 1 || !bytes_L || !bytes_C || !bytes_Linv)
+        return bad_shape("n must be a positive multiple of N_blocks, batch >= 1");
     const int64_t bs = n / n_blocks, bsp = 64 * next_pow2((bs + 63) / 64);
-    const int64_t blk = bsp * bsp * (int64_t)sizeof(double);
+    const int64_t blk = bsp * bsp * (int64_t)sizeof(double) * batch;
     *bytes_L = blk * n_blocks; *bytes_Linv = blk * n_blocks; *bytes_C = blk * std::max<int64_t>(n_blocks - 1, 1);
     return GMRF_OK;
 }
 
-gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, void* dev_L, void* dev_C, void* dev_Linv) {
-    if (!h || !dev_L || !dev_C || !dev_Linv) return bad_shape("null pointer");
+gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, int64_t batch, void* dev_L, void* dev_C,
+                                void* dev_Linv) {
+    if (!h || !dev_C || !dev_Linv) return bad_shape("null pointer");
+    if (batch != h->B) return bad_shape("storage batch differs from the handle's batch (gmrf_bt_set_batch first)");
+    if (!dev_L && h->keep_l) return bad_shape("dev_L may be NULL only after gmrf_bt_set_keep_l(h, 0)");
     HIPCHK(hipSetDevice(h->device));
     GCHK(set_shape(h, n, n_blocks));
+    HIPCHK(hipStreamSynchronize(h->stream));
     destroy_graphs(h);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
+    else if (!h->keep_l) free_dev(h->d_L);             // our one-block work buffer of an earlier set_storage
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W); free_dev(h->d_logdet);
     h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
     h->d_L = (double*)dev_L; h->d_C = (double*)dev_C; h->d_Linv = (double*)dev_Linv;
     h->external_storage = true;
-    return alloc_work(h);
-}
-
-gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
-    if (!h) return bad_shape("null handle");
-    HIPCHK(hipSetDevice(h->device));
-    GCHK(set_shape(h, n, n_blocks));
-    GCHK(alloc_factor(h));
-    h->factored = false;
+    h->factored = false; h->l_valid = false;          // whatever was factored lived in the old buffers
+    if (!h->keep_l) {                                  // one-block work buffer for L_i
+        HIPCHK(hipMalloc(&h->d_L, (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B));
+        HIPCHK(hipMemsetAsync(h->d_L, 0, (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B, h->stream));
+    }
+    if (!h->analyzed) GCHK(set_layout_dense(h));      // until a pattern is analysed / a layout adopted
+    // tiles strictly above the block diagonal of L / Linv are never written: keep them zero
+    const size_t blk = (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B;
+    if (h->keep_l) HIPCHK(hipMemsetAsync(h->d_L, 0, blk * h->N, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_Linv, 0, blk * h->N, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_C, 0, blk * std::max<int64_t>(h->N - 1, 1), h->stream));
+    h->c_dirty = false;
+    GCHK(alloc_work(h));
+    h->alloc_rm = h->rmax; h->alloc_wc = c_ld(h); h->alloc_keep_l = h->keep_l;
     HIPCHK(hipStreamSynchronize(h->stream));
     return GMRF_OK;
 }
 
-gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h) {
-    if (!h || !h->d_L) return bad_shape("no factor storage");
+gmrf_status gmrf_bt_set_keep_l(gmrf_handle* h, int32_t keep) {
+    if (!h) return bad_shape("null handle");
+    if ((keep != 0) == h->keep_l) return GMRF_OK;
+    if (h->external_storage) return bad_shape("choose gmrf_bt_set_keep_l before gmrf_bt_set_storage");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    destroy_graphs(h);
+    h->keep_l = keep != 0;
+    h->factored = false; h->l_valid = false;
+    return GMRF_OK;
+}
+
+// Layout of the stored coupling blocks: out = {cmin, rmax, n_row_tiles, kst[0 .. n_row_tiles)} (kst relative to cmin).
+gmrf_status gmrf_bt_get_layout(gmrf_handle* h, int64_t* out, int64_t cap, int64_t* count) {
+    if (!h || !count) return bad_shape("null pointer");
+    if (h->N <= 0 || h->kst.empty()) { g_last_error = "no shape"; return GMRF_ERR_NO_FACTOR; }
+    const int64_t nrt = h->rmax / 64;
+    *count = 3 + nrt;
+    if (!out) return GMRF_OK;
+    if (cap < 3 + nrt) return bad_shape("layout buffer too small");
+    out[0] = h->cmin; out[1] = h->rmax; out[2] = nrt;
+    for (int64_t t = 0; t < nrt; ++t) out[3 + t] = h->kst[(size_t)t];
+    return GMRF_OK;
+}
+
+// A rank that receives the factor by broadcast: shape + the root's layout (NULL: dense coupling blocks),
+// storage allocated (or the caller's, gmrf_bt_set_storage), nothing factored yet.
+gmrf_status gmrf_bt_adopt_layout(gmrf_handle* h, int64_t n, int64_t n_blocks, const int64_t* layout, int64_t count) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    GCHK(set_shape(h, n, n_blocks));
+    h->analyzed = false;                               // whatever pattern was analysed does not describe this factor
+    if (layout) {
+        if (count < 3 || layout[2] < 1 || count < 3 + layout[2] || layout[1] != 64 * layout[2]) return bad_shape("bad layout record");
+        std::vector<int64_t> first((size_t)layout[2]);
+        for (int64_t t = 0; t < layout[2]; ++t) first[(size_t)t] = layout[0] + layout[3 + t];
+        GCHK(set_layout(h, layout[0], layout[1], first));
+    } else {
+        GCHK(set_layout_dense(h));
+    }
+    GCHK(alloc_factor(h));
+    if (h->c_dirty) {
+        HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
+        h->c_dirty = false;
+    }
+    h->factored = false; h->l_valid = false;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
+    return gmrf_bt_adopt_layout(h, n, n_blocks, nullptr, 0);
+}
+
+// l_blocks_valid != 0: the caller also filled the L buffer (gmrf_bt_factor_buffer kind L), so F.chos / logdet work
+gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid) {
+    if (!h || !h->d_Linv) return bad_shape("no factor storage");
     h->factored = true;
+    h->l_valid = l_blocks_valid != 0 && h->keep_l;
     return GMRF_OK;
 }
 
 gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr, int64_t* bytes) {
     if (!h || !dev_ptr || !bytes) return bad_shape("null pointer");
-    if (!h->d_L) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
-    const int64_t blk = h->bsp * h->bsp * (int64_t)sizeof(double) * h->B;
-    if (kind == GMRF_BLOCK_L) { *dev_ptr = h->d_L; *bytes = blk * h->N; }
-    else if (kind == GMRF_BLOCK_C) { *dev_ptr = h->d_C; *bytes = blk * std::max<int64_t>(h->N - 1, 1); }
+    if (!h->d_Linv) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
+    const int64_t blk = blk_elems(h) * (int64_t)sizeof(double) * h->B;
+    if (kind == GMRF_BLOCK_L) {
+        if (!h->keep_l) { g_last_error = "L blocks are not kept (gmrf_bt_set_keep_l)"; return GMRF_ERR_NO_FACTOR; }
+        *dev_ptr = h->d_L; *bytes = blk * h->N;
+    }
+    else if (kind == GMRF_BLOCK_C) { *dev_ptr = h->d_C; *bytes = stride_pC(h) * (int64_t)sizeof(double) * h->B; }
     else if (kind == GMRF_BLOCK_LINV) { *dev_ptr = h->d_Linv; *bytes = blk * h->N; }
     else return bad_shape("bad block kind");
+    return GMRF_OK;
+}
+
+// Element ranges (in doubles, per problem) of blocks [i0, i1) inside the three factor buffers: what a
+// block-range broadcast moves.  C holds the coupling blocks i0-1 .. i1-2 (C_i couples blocks i and i+1).
+gmrf_status gmrf_bt_block_range(gmrf_handle* h, int32_t kind, int64_t i0, int64_t i1, int64_t* first_elem,
+                                int64_t* n_elems, int64_t* problem_stride) {
+    if (!h || !first_elem || !n_elems || !problem_stride) return bad_shape("null pointer");
+    if (h->N <= 0 || i0 < 0 || i1 > h->N || i0 > i1) return bad_shape("bad block range");
+    if (kind == GMRF_BLOCK_C) {
+        const int64_t c0 = std::max<int64_t>(i0 - 1, 0), c1 = std::max<int64_t>(i1 - 1, 0);
+        *first_elem = c0 * c_blk(h); *n_elems = (c1 - c0) * c_blk(h); *problem_stride = stride_pC(h);
+    } else if (kind == GMRF_BLOCK_LINV || kind == GMRF_BLOCK_L) {
+        if (kind == GMRF_BLOCK_L && !h->keep_l) { g_last_error = "L blocks are not kept"; return GMRF_ERR_NO_FACTOR; }
+        *first_elem = i0 * blk_elems(h); *n_elems = (i1 - i0) * blk_elems(h);
+        *problem_stride = kind == GMRF_BLOCK_L ? stride_pL(h) : stride_pX(h);
+    } else return bad_shape("bad block kind");
     return GMRF_OK;
 }
 
@@ -1077,13 +1289,22 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
     HIPCHK(hipSetDevice(h->device));
     const int64_t bs = h->bs, bsp = h->bsp;
     if (ld < bs) return bad_shape("ld < block_size");
+    // source window [rows][cols] with row stride lds, placed at (0, c0) of the logical block
     const double* src;
-    const int64_t pLX = h->sel * h->N * bsp * bsp, pCs = h->sel * std::max<int64_t>(h->N - 1, 1) * bsp * bsp;
-    if (kind == GMRF_BLOCK_L) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_L + pLX + i * bsp * bsp; }
-    else if (kind == GMRF_BLOCK_LINV) { if (i < 0 || i >= h->N) return bad_shape("block index"); src = h->d_Linv + pLX + i * bsp * bsp; }
-    else if (kind == GMRF_BLOCK_C) { if (i < 0 || i >= h->N - 1) return bad_shape("block index"); src = h->d_C + pCs + i * bsp * bsp; }
-    else return bad_shape("bad block kind");
-    std::vector<double> tmp((size_t)bsp * bsp);
+    int64_t rows = bsp, cols = bsp, lds = bsp, c0 = 0;
+    if (kind == GMRF_BLOCK_L) {
+        if (i < 0 || i >= h->N) return bad_shape("block index");
+        if (!h->l_valid) { g_last_error = "the L blocks of this factor are not resident (gmrf_bt_set_keep_l(h, 0), or a factor adopted without them)"; return GMRF_ERR_NO_FACTOR; }
+        src = h->d_L + h->sel * stride_pL(h) + i * blk_elems(h);
+    } else if (kind == GMRF_BLOCK_LINV) {
+        if (i < 0 || i >= h->N) return bad_shape("block index");
+        src = h->d_Linv + h->sel * stride_pX(h) + i * blk_elems(h);
+    } else if (kind == GMRF_BLOCK_C) {
+        if (i < 0 || i >= h->N - 1) return bad_shape("block index");
+        src = h->d_C + h->sel * stride_pC(h) + i * c_blk(h);
+        rows = h->rmax; cols = c_ld(h); lds = cols; c0 = h->cmin;
+    } else return bad_shape("bad block kind");
+    std::vector<double> tmp((size_t)rows * cols);
     HIPCHK(hipMemcpyAsync(tmp.data(), src, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     const bool dev_out = is_device_ptr(out);
@@ -1091,8 +1312,11 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
     double* dst = out;
     int64_t ldd = ld;
     if (dev_out) { cm.resize((size_t)bs * bs); dst = cm.data(); ldd = bs; }
-    for (int64_t r = 0; r < bs; ++r)
-        for (int64_t c = 0; c < bs; ++c) dst[c * ldd + r] = tmp[(size_t)r * bsp + c];   // row-major -> column-major
+    for (int64_t c = 0; c < bs; ++c)
+        for (int64_t r = 0; r < bs; ++r) {                 // row-major window -> column-major block
+            const bool in = r < rows && c >= c0 && c - c0 < cols;
+            dst[c * ldd + r] = in ? tmp[(size_t)r * lds + (c - c0)] : 0.0;
+        }
     if (dev_out) {
         HIPCHK(hipMemcpy2DAsync(out, ld * sizeof(double), cm.data(), bs * sizeof(double), bs * sizeof(double), bs, hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -1140,13 +1364,30 @@ gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes
     if (N <= 0 || bs <= 0 || n != N * bs) return bad_shape("bad shape in factor image");
     if (bytes < 64 + (int64_t)sizeof(double) * bs * bs * (3 * N - 1)) return bad_shape("factor image truncated");
     HIPCHK(hipSetDevice(h->device));
-    if (h->n != n || h->N != N || !h->d_L) {
-        if (h->B != 1) return bad_shape("a batched handle imports into an existing shape only");
-        GCHK(set_shape(h, n, N));
+    if (!h->keep_l) return bad_shape("import needs the L blocks kept (gmrf_bt_set_keep_l(h, 1))");
+    if ((h->n != n || h->N != N) && h->B != 1) return bad_shape("a batched handle imports into an existing shape only");
+    // The image holds dense blocks and says nothing about the coupling blocks' zero structure: the handle
+    // takes the dense layout (a pattern analysed earlier no longer describes the factor) and every
+    // problem's stored C window is re-laid out accordingly.
+    const bool relayout = (h->n != n || h->N != N || h->cmin != 0 || h->rmax != 64 * next_pow2((bs + 63) / 64) || !h->d_Linv);
+    if (relayout && h->B != 1 && h->factored) return bad_shape("a batched handle imports only into a dense-layout factor");
+    GCHK(set_shape(h, n, N));
+    h->analyzed = false;
+    if (relayout) {
+        GCHK(set_layout_dense(h));
         GCHK(alloc_factor(h));
+        if (h->c_dirty) {
+            HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
+            h->c_dirty = false;
+        }
+    } else {
+        std::vector<int64_t> z((size_t)(h->bsp / 64), 0);
+        bool dense_ks = true;
+        for (int v : h->kst) if (v != 0) dense_ks = false;
+        if (!dense_ks) GCHK(set_layout(h, 0, h->bsp, z));      // same window, staircase dropped
+        h->c_dirty = false;
     }
     const int64_t bsp = h->bsp, be = bs * bs;
-    const int64_t pLX = h->sel * N * bsp * bsp, pCs = h->sel * std::max<int64_t>(N - 1, 1) * bsp * bsp;
     std::vector<double> tmp((size_t)bsp * bsp);
     auto put = [&](const double* src, double* dst, bool unit_pad) -> gmrf_status {
         std::fill(tmp.begin(), tmp.end(), 0.0);
@@ -1159,12 +1400,197 @@ gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes
         return GMRF_OK;
     };
     const double* in = (const double*)((const char*)buf + 64);
-    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_L + pLX + i * bsp * bsp, true));
+    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_L + h->sel * stride_pL(h) + i * blk_elems(h), true));
     in += N * be;
-    for (int64_t i = 0; i + 1 < N; ++i) GCHK(put(in + i * be, h->d_C + pCs + i * bsp * bsp, false));
+    for (int64_t i = 0; i + 1 < N; ++i) GCHK(put(in + i * be, h->d_C + h->sel * stride_pC(h) + i * c_blk(h), false));
     in += (N - 1) * be;
-    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_Linv + pLX + i * bsp * bsp, true));
-    h->factored = true;
+    for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_Linv + h->sel * stride_pX(h) + i * blk_elems(h), true));
+    h->factored = true; h->l_valid = true;
+    return GMRF_OK;
+}
+
+// ------------------------------------------------------------------------------------ RCCL (xGMI)
+// One communicator per process and GPU.  librccl is opened at run time (dlopen) the first time a
+// communicator is asked for: a host that never shares a factor never loads it, and inside a PyTorch
+// process the copy PyTorch already mapped is the one that gets used (two RCCL images in one process
+// would both export the nccl* symbols).
+struct NcclUid { char b[128]; };
+struct RcclApi {
+    void* lib = nullptr;
+    int (*GetUniqueId)(NcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclUid, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+static RcclApi g_rccl;
+static std::mutex g_rccl_mu;
+
+static gmrf_status rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.lib) return GMRF_OK;
+    const char* env = getenv("GMRF_RCCL_PATH");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* lib = nullptr;
+    for (int pass = 0; pass < 2 && !lib; ++pass)          // pass 0: an image that is already mapped (PyTorch's)
+        for (const char* nm : names) {
+            if (!nm) continue;
+            lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+            if (lib) break;
+        }
+    if (!lib) { g_last_error = std::string("librccl not found (set GMRF_RCCL_PATH): ") + (dlerror() ? dlerror() : ""); return GMRF_ERR_RCCL; }
+#define GMRF_RCCL_SYM(field, name)                                                           \
+    g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(lib, name));               \
+    if (!g_rccl.field) { g_last_error = std::string("librccl lacks ") + name; return GMRF_ERR_RCCL; }
+    GMRF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") GMRF_RCCL_SYM(CommInitRank, "ncclCommInitRank")
+    GMRF_RCCL_SYM(CommDestroy, "ncclCommDestroy") GMRF_RCCL_SYM(Broadcast, "ncclBroadcast")
+    GMRF_RCCL_SYM(AllReduce, "ncclAllReduce") GMRF_RCCL_SYM(GroupStart, "ncclGroupStart")
+    GMRF_RCCL_SYM(GroupEnd, "ncclGroupEnd") GMRF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef GMRF_RCCL_SYM
+    g_rccl.lib = lib;
+    return GMRF_OK;
+}
+
+#define NCCLCHK(expr)                                                                       \
+    do {                                                                                    \
+        int _r = (expr);                                                                    \
+        if (_r != 0) {                                                                      \
+            g_last_error = std::string(#expr) + ": " + g_rccl.GetErrorString(_r);           \
+            return GMRF_ERR_RCCL;                                                           \
+        }                                                                                   \
+    } while (0)
+
+struct gmrf_comm {
+    int device = 0, rank = 0, world = 1;
+    void* comm = nullptr;
+    hipStream_t stream = nullptr;          // collectives run here, beside the handle's compute stream
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    void* d_small = nullptr;               // staging of small host records (layout, scalars)
+    size_t small_cap = 0;
+};
+
+gmrf_status gmrf_comm_unique_id(void* id128) {
+    if (!id128) return bad_shape("null pointer");
+    GCHK(rccl_load());
+    NcclUid u;
+    NCCLCHK(g_rccl.GetUniqueId(&u));
+    memcpy(id128, u.b, 128);
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_comm_create(int32_t device, int32_t rank, int32_t world, const void* id128, gmrf_comm** out) {
+    if (!out || !id128 || world < 1 || rank < 0 || rank >= world) return bad_shape("bad communicator arguments");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) {
+        (void)hipGetLastError();
+        g_last_error = "no HIP device visible";
+        return GMRF_ERR_NO_DEVICE;
+    }
+    GCHK(rccl_load());
+    HIPCHK(hipSetDevice(device));
+    gmrf_comm* c = new gmrf_comm();
+    c->device = device; c->rank = rank; c->world = world;
+    NcclUid u;
+    memcpy(u.b, id128, 128);
+    int r = g_rccl.CommInitRank(&c->comm, world, u, rank);
+    if (r != 0) { g_last_error = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete c; return GMRF_ERR_RCCL; }
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
+    *out = c;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_comm_destroy(gmrf_comm* c) {
+    if (!c) return GMRF_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) (void)g_rccl.CommDestroy(c->comm);
+    free_dev(c->d_small);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return GMRF_OK;
+}
+
+// Broadcast a small HOST record (layout, log-determinants ...) from `root`; synchronous.
+gmrf_status gmrf_comm_bcast_host(gmrf_comm* c, void* host_buf, int64_t bytes, int32_t root) {
+    if (!c || !host_buf || bytes <= 0 || root < 0 || root >= c->world) return bad_shape("bad broadcast arguments");
+    HIPCHK(hipSetDevice(c->device));
+    if ((size_t)bytes > c->small_cap) {
+        free_dev(c->d_small); c->d_small = nullptr; c->small_cap = 0;
+        HIPCHK(hipMalloc(&c->d_small, (size_t)bytes));
+        c->small_cap = (size_t)bytes;
+    }
+    if (c->rank == root) HIPCHK(hipMemcpyAsync(c->d_small, host_buf, (size_t)bytes, hipMemcpyHostToDevice, c->stream));
+    NCCLCHK(g_rccl.Broadcast(c->d_small, c->d_small, (size_t)bytes, /*ncclInt8*/ 0, root, c->comm, c->stream));
+    if (c->rank != root) HIPCHK(hipMemcpyAsync(host_buf, c->d_small, (size_t)bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return GMRF_OK;
+}
+
+// R2 of SURVEY 8e: sum of the ranks' variance accumulators (device buffer of `count` doubles), in place.
+// `stream_of`: a handle whose stream produced the buffer and consumes the result (may be NULL: synchronous).
+gmrf_status gmrf_comm_allreduce_sum(gmrf_comm* c, gmrf_handle* stream_of, double* dev_buf, int64_t count) {
+    if (!c || !dev_buf || count <= 0) return bad_shape("bad all-reduce arguments");
+    if (!is_device_ptr(dev_buf)) return bad_shape("all-reduce needs a device buffer");
+    HIPCHK(hipSetDevice(c->device));
+    if (stream_of) {
+        HIPCHK(hipEventRecord(c->ev_in, stream_of->stream));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    }
+    NCCLCHK(g_rccl.AllReduce(dev_buf, dev_buf, (size_t)count, /*ncclFloat64*/ 8, /*ncclSum*/ 0, c->comm, c->stream));
+    if (stream_of) {
+        HIPCHK(hipEventRecord(c->ev_out, c->stream));
+        HIPCHK(hipStreamWaitEvent(stream_of->stream, c->ev_out, 0));
+    } else {
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return GMRF_OK;
+}
+
+// R1 of SURVEY 8e: broadcast of the factor blocks [i0, i1) -- Linv_i and the stored windows of the coupling
+// blocks C_{i0-1} .. C_{i1-2}, for every problem of the batch; with_l != 0 also L_i -- from `root` to all
+// ranks, enqueued on the communicator's stream behind whatever the handle's stream holds at the time
+// of the call (root: the factorisation of these blocks; receivers: the sweeps of the previous job
+// that still read the buffers).  The root goes on factoring the next range meanwhile.
+gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t root, int64_t i0, int64_t i1, int32_t with_l) {
+    if (!h || !c) return bad_shape("null pointer");
+    if (!h->d_Linv || h->N <= 0) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
+    if (i0 < 0 || i1 > h->N || i0 >= i1 || root < 0 || root >= c->world) return bad_shape("bad block range / root");
+    if (with_l && !h->keep_l) return bad_shape("the L blocks are not kept on this handle");
+    if (c->device != h->device) return bad_shape("communicator and handle live on different devices");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(c->ev_in, h->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    NCCLCHK(g_rccl.GroupStart());
+    int rc = 0;
+    for (int kind = 0; kind < 3 && rc == 0; ++kind) {
+        if (kind == GMRF_BLOCK_L && !with_l) continue;
+        int64_t first = 0, cnt = 0, pstride = 0;
+        GCHK(gmrf_bt_block_range(h, kind, i0, i1, &first, &cnt, &pstride));
+        if (cnt == 0) continue;
+        double* base = kind == GMRF_BLOCK_L ? h->d_L : (kind == GMRF_BLOCK_C ? h->d_C : h->d_Linv);
+        for (int64_t p = 0; p < h->B && rc == 0; ++p) {
+            double* ptr = base + p * pstride + first;
+            rc = g_rccl.Broadcast(ptr, ptr, (size_t)cnt, /*ncclFloat64*/ 8, root, c->comm, c->stream);
+        }
+    }
+    const int rg = g_rccl.GroupEnd();
+    if (rc != 0 || rg != 0) { g_last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(rc ? rc : rg); return GMRF_ERR_RCCL; }
+    return GMRF_OK;
+}
+
+// The handle's stream waits for every transfer enqueued so far on the communicator's stream.
+gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c) {
+    if (!h || !c) return bad_shape("null pointer");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipEventRecord(c->ev_out, c->stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, c->ev_out, 0));
     return GMRF_OK;
 }
 
@@ -1210,6 +1636,8 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
         const int nsweeps = (mode == GMRF_SOLVE_FULL) ? 2 : 1;
         h->stats.sweep_ms = ms / nsweeps;
         h->stats.sweep_bytes = sweep_bytes(h, kc) * (double)nb;
+        h->stats.sweep_bytes_streamed = (8.0 * ((double)h->N * 0.5 * (double)h->bsp * (double)(h->bsp + 1) +
+                                                (double)(h->N - 1) * h->c_streamed) + 16.0 * (double)h->n_pad * kc) * (double)nb;
         if (h->profiling) prof_collect(h);
     }
     return GMRF_OK;
@@ -1313,11 +1741,15 @@ gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out) {
     if (!h || !out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "logdet before factor"; return GMRF_ERR_NO_FACTOR; }
     HIPCHK(hipSetDevice(h->device));
-    hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N), dim3(256), 0, h->stream,
-                       h->d_L + h->sel * h->N * h->bsp * h->bsp, h->bsp * h->bsp, h->bsp, (int)h->bs, h->d_logdet);
-    HIPCHK(hipGetLastError());
+    if (h->keep_l) {
+        if (!h->l_valid) { g_last_error = "the L blocks of this factor are not resident"; return GMRF_ERR_NO_FACTOR; }
+        hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N, 1), dim3(256), 0, h->stream,
+                           h->d_L + h->sel * stride_pL(h), blk_elems(h), h->bsp, (int)h->bs, h->d_logdet + h->sel * h->N,
+                           (int64_t)0, (int64_t)0);
+        HIPCHK(hipGetLastError());
+    }   // else: the factorisation left every block's part in d_logdet
     std::vector<double> part((size_t)h->N);
-    HIPCHK(hipMemcpyAsync(part.data(), h->d_logdet, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(part.data(), h->d_logdet + h->sel * h->N, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     double s = 0.0;
     for (double v : part) s += v;
@@ -1338,8 +1770,12 @@ gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_
     }
     HIPCHK(hipSetDevice(device));
     const int64_t nnz = rowptr[n_rows] - index_base;
+    if (nnz < 0 || rowptr[0] != index_base) return bad_shape("bad CSR row pointers");
     std::vector<int64_t> rp((size_t)n_rows + 1);
-    for (int64_t i = 0; i <= n_rows; ++i) rp[i] = rowptr[i] - index_base;
+    for (int64_t i = 0; i <= n_rows; ++i) {
+        rp[i] = rowptr[i] - index_base;
+        if (i > 0 && rp[i] < rp[i - 1]) return bad_shape("CSR row pointers must be non-decreasing");
+    }
     std::vector<int32_t> ci((size_t)nnz);
     for (int64_t p = 0; p < nnz; ++p) {
         const int64_t c = colidx[p] - index_base;
@@ -1351,31 +1787,42 @@ gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_
     m->tiles_ok = true;
     for (int64_t r = 0; r < n_rows; r += SPMV_ROWS)
         if (rp[std::min(n_rows, r + SPMV_ROWS)] - rp[r] > SPMV_CAP) { m->tiles_ok = false; break; }
-    if (stream) { m->stream = (hipStream_t)stream; } else { HIPCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
+    // from here on a failing HIP call releases what has been allocated so far
+#define CSRCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            g_last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            (void)gmrf_csr_destroy(m);                                                        \
+            return GMRF_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+    if (stream) { m->stream = (hipStream_t)stream; } else { CSRCHK(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking)); m->own_stream = true; }
     m->n_rows = n_rows; m->n_cols = n_cols; m->nnz = nnz;
-    HIPCHK(hipMalloc(&m->d_rowptr, sizeof(int64_t) * (n_rows + 1)));
-    HIPCHK(hipMalloc(&m->d_colidx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
-    HIPCHK(hipMemcpyAsync(m->d_rowptr, rp.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipMemcpyAsync(m->d_colidx, ci.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
+    CSRCHK(hipMalloc(&m->d_rowptr, sizeof(int64_t) * (n_rows + 1)));
+    CSRCHK(hipMalloc(&m->d_colidx, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    CSRCHK(hipMemcpyAsync(m->d_rowptr, rp.data(), sizeof(int64_t) * (n_rows + 1), hipMemcpyHostToDevice, m->stream));
+    CSRCHK(hipMemcpyAsync(m->d_colidx, ci.data(), sizeof(int32_t) * nnz, hipMemcpyHostToDevice, m->stream));
+    CSRCHK(hipStreamSynchronize(m->stream));
     if (values_f32) {
         std::vector<float> vf((size_t)nnz);
         for (int64_t p = 0; p < nnz; ++p) vf[p] = (float)vals[p];
-        HIPCHK(hipMalloc(&m->d_vals32, sizeof(float) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMemcpyAsync(m->d_vals32, vf.data(), sizeof(float) * nnz, hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
+        CSRCHK(hipMalloc(&m->d_vals32, sizeof(float) * std::max<int64_t>(nnz, 1)));
+        CSRCHK(hipMemcpyAsync(m->d_vals32, vf.data(), sizeof(float) * nnz, hipMemcpyHostToDevice, m->stream));
+        CSRCHK(hipStreamSynchronize(m->stream));
     } else {
-        HIPCHK(hipMalloc(&m->d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)));
-        HIPCHK(hipMemcpyAsync(m->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice, m->stream));
-        HIPCHK(hipStreamSynchronize(m->stream));
+        CSRCHK(hipMalloc(&m->d_vals, sizeof(double) * std::max<int64_t>(nnz, 1)));
+        CSRCHK(hipMemcpyAsync(m->d_vals, vals, sizeof(double) * nnz, hipMemcpyHostToDevice, m->stream));
+        CSRCHK(hipStreamSynchronize(m->stream));
     }
     if (n_rows == n_cols) {
-        HIPCHK(hipMalloc(&m->d_diag, sizeof(double) * n_rows));
+        CSRCHK(hipMalloc(&m->d_diag, sizeof(double) * n_rows));
         hipLaunchKernelGGL(csr_extract_diag, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, m->stream,
                            m->d_rowptr, m->d_colidx, m->d_vals, m->d_vals32, n_rows, m->d_diag);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(m->stream));
+        CSRCHK(hipGetLastError());
+        CSRCHK(hipStreamSynchronize(m->stream));
     }
+#undef CSRCHK
     *out = m;
     return GMRF_OK;
 }
@@ -1386,6 +1833,7 @@ gmrf_status gmrf_csr_destroy(gmrf_csr* m) {
     (void)hipStreamSynchronize(m->stream);
     free_dev(m->d_rowptr); free_dev(m->d_colidx); free_dev(m->d_vals); free_dev(m->d_vals32);
     free_dev(m->d_diag); free_dev(m->d_stage_x); free_dev(m->d_stage_y);
+    free_dev(m->d_tile_uptr); free_dev(m->d_ucols); free_dev(m->d_lidx);
     if (m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return GMRF_OK;
@@ -1429,6 +1877,105 @@ static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* 
     }
 #undef SPMM_LAUNCH
     HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+// Tile plan of csr_spmm_tiles: per SPMM_ROWS-row tile the ascending list of distinct columns and, per
+// entry, the 16-bit index of its column in that list.  Built once per matrix (host; the device
+// arrays of the matrix are read back), like the symbolic phase of the factor.
+static gmrf_status spmm_plan(gmrf_csr* m) {
+    if (m->plan_state != 0) return GMRF_OK;
+    const int64_t T = (m->n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
+    std::vector<int64_t> rp((size_t)m->n_rows + 1);
+    std::vector<int32_t> ci((size_t)std::max<int64_t>(m->nnz, 1));
+    HIPCHK(hipMemcpyAsync(rp.data(), m->d_rowptr, sizeof(int64_t) * (m->n_rows + 1), hipMemcpyDeviceToHost, m->stream));
+    if (m->nnz > 0) HIPCHK(hipMemcpyAsync(ci.data(), m->d_colidx, sizeof(int32_t) * m->nnz, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    std::vector<int64_t> uptr((size_t)T + 1, 0);
+    std::vector<int32_t> ucols;
+    std::vector<uint16_t> lidx((size_t)std::max<int64_t>(m->nnz, 1));
+    std::vector<int32_t> tmp;
+    ucols.reserve((size_t)(m->nnz / 3 + 16));
+    for (int64_t tix = 0; tix < T; ++tix) {
+        const int64_t r0 = tix * SPMM_ROWS, r1 = std::min(m->n_rows, r0 + SPMM_ROWS);
+        const int64_t a = rp[r0], b = rp[r1];
+        if (b - a > SPMM_CAP) { m->plan_state = -1; return GMRF_OK; }
+        tmp.assign(ci.begin() + a, ci.begin() + b);
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        if ((int64_t)tmp.size() > SPMM_UMAX) { m->plan_state = -1; return GMRF_OK; }
+        for (int64_t e = a; e < b; ++e)
+            lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), ci[(size_t)e]) - tmp.begin());
+        ucols.insert(ucols.end(), tmp.begin(), tmp.end());
+        uptr[(size_t)tix + 1] = (int64_t)ucols.size();
+    }
+    m->n_ucols = (int64_t)ucols.size();
+    HIPCHK(hipMalloc(&m->d_tile_uptr, sizeof(int64_t) * (T + 1)));
+    HIPCHK(hipMalloc(&m->d_ucols, sizeof(int32_t) * std::max<size_t>(ucols.size(), 1)));
+    HIPCHK(hipMalloc(&m->d_lidx, sizeof(uint16_t) * std::max<int64_t>(m->nnz, 1)));
+    HIPCHK(hipMemcpyAsync(m->d_tile_uptr, uptr.data(), sizeof(int64_t) * (T + 1), hipMemcpyHostToDevice, m->stream));
+    if (!ucols.empty()) HIPCHK(hipMemcpyAsync(m->d_ucols, ucols.data(), sizeof(int32_t) * ucols.size(), hipMemcpyHostToDevice, m->stream));
+    if (m->nnz > 0) HIPCHK(hipMemcpyAsync(m->d_lidx, lidx.data(), sizeof(uint16_t) * m->nnz, hipMemcpyHostToDevice, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->plan_state = 1;
+    return GMRF_OK;
+}
+
+// Y = S X with node-major device operands (X[col][rhs], Y[row][rhs]); vals_override: same pattern,
+// another problem's fp64 values.
+static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const double* d_X, int64_t ldx, double* d_Y,
+                                    int64_t ldy, int k, const double* vals_override = nullptr) {
+    gmrf_csr* m = const_cast<gmrf_csr*>(S);
+    GCHK(spmm_plan(m));
+    const bool aligned = (k % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)d_X) % 16 == 0);
+    if (m->plan_state == 1 && aligned) {
+        const dim3 grid((unsigned)((S->n_rows + SPMM_ROWS - 1) / SPMM_ROWS));
+        if (vals_override) hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, vals_override, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
+        else if (S->d_vals32) hipLaunchKernelGGL(csr_spmm_tiles<float>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, S->d_vals32, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
+        else hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, S->d_vals, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
+    } else {
+        const dim3 grid((unsigned)((S->n_rows + 15) / 16));
+        if (vals_override) hipLaunchKernelGGL(csr_spmm_rows<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_colidx, vals_override, S->n_rows, d_X, ldx, d_Y, ldy, k);
+        else if (S->d_vals32) hipLaunchKernelGGL(csr_spmm_rows<float>, grid, dim3(256), 0, st, S->d_rowptr, S->d_colidx, S->d_vals32, S->n_rows, d_X, ldx, d_Y, ldy, k);
+        else hipLaunchKernelGGL(csr_spmm_rows<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_colidx, S->d_vals, S->n_rows, d_X, ldx, d_Y, ldy, k);
+    }
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+// Y = S X with NODE-MAJOR operands: X is n_cols x k with the k values of a column index contiguous
+// (row stride ldx >= k), Y likewise (ldy >= k) -- in Julia terms the k x n matrices permutedims(X),
+// permutedims(Y).  This is the layout the LDS-tiled kernel wants (one gathered column index fetches
+// k contiguous doubles); host pointers are staged.
+gmrf_status gmrf_spmm_rows(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy) {
+    if (!S || !X || !Y) return bad_shape("null pointer");
+    if (k <= 0 || k > (1 << 20) || ldx < k || ldy < k) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(S->device));
+    gmrf_csr* m = const_cast<gmrf_csr*>(S);
+    const bool x_dev = is_device_ptr(X), y_dev = is_device_ptr(Y);
+    const double* d_X = X;
+    double* d_Y = Y;
+    int64_t lx = ldx, ly = ldy;
+    const int64_t kk = k + (k & 1);                       // staging keeps rows 16-byte aligned
+    const int64_t need = kk * std::max(S->n_rows, S->n_cols);
+    if ((!x_dev || !y_dev) && need > m->stage_cap) {
+        free_dev(m->d_stage_x); free_dev(m->d_stage_y);
+        m->d_stage_x = m->d_stage_y = nullptr;
+        HIPCHK(hipMalloc(&m->d_stage_x, sizeof(double) * need));
+        HIPCHK(hipMalloc(&m->d_stage_y, sizeof(double) * need));
+        m->stage_cap = need;
+    }
+    if (!x_dev) {
+        HIPCHK(hipMemcpy2DAsync(m->d_stage_x, kk * sizeof(double), X, ldx * sizeof(double), k * sizeof(double), S->n_cols,
+                                hipMemcpyHostToDevice, S->stream));
+        d_X = m->d_stage_x; lx = kk;
+    }
+    if (!y_dev) { d_Y = m->d_stage_y; ly = kk; }
+    GCHK(spmm_rows_device(S, S->stream, d_X, lx, d_Y, ly, (int)k));
+    if (!y_dev)
+        HIPCHK(hipMemcpy2DAsync(Y, ldy * sizeof(double), d_Y, kk * sizeof(double), k * sizeof(double), S->n_rows,
+                                hipMemcpyDeviceToHost, S->stream));
+    HIPCHK(hipStreamSynchronize(S->stream));
     return GMRF_OK;
 }
 
@@ -1667,17 +2214,22 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     // (all problems of a batch in lock step: problem strides on every operand; d_out is [B][n])
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp;
-    const int64_t pLX = bstride * h->N, pCm = bstride * std::max<int64_t>(h->N - 1, 1), pW = bstride;
+    const int64_t pX = stride_pX(h), pCm = stride_pC(h), pW = bstride;
+    const int cm = (int)h->cmin, rm = (int)h->rmax, wc = bsp - cm;
     double* Sg = h->d_S;     // current Sigma_{i+1,i+1}
     double* G = h->d_B;
     double* Hm = h->d_T;
     double* Sn = h->d_W;
+    // G = C_i Linv_i has the rows of C_i: those below rmax stay zero throughout
+    if (h->N > 1 && rm < bsp) HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * bstride * h->B, h->stream));
     for (int64_t i = h->N - 1; i >= 0; --i) {
         const double* X = h->d_Linv + i * bstride;
-        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, pLX, pLX, pW));
+        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, pX, pX, pW));
         if (i < h->N - 1) {
-            const double* C = h->d_C + i * bstride;
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, TRI_B_LOWER, 0, 1.0, C, ld, X, ld, 0.0, G, ld, pCm, pLX, pW));
+            // stored window of C_i: rows 0 .. rm, columns cm ..  ->  G[0:rm, :] = C_w * Linv_i[cm:, :]
+            const double* C = h->d_C + i * c_blk(h);
+            GCHK(gemm(h, false, true, rm, bsp, wc, 0, 0, 1.0, C, c_ld(h), X + (int64_t)cm * ld, ld, 0.0, G, ld, pCm, pX, pW,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, h->d_kst, nullptr, nullptr));
             GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld, pW, pW, pW));
             GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld, pW, pW, pW));
         }
@@ -1689,24 +2241,33 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     return GMRF_OK;
 }
 
+// One chunk of samples (panel p of d_Y, kc right-hand sides) -> node-major X[n][kcp] -> the RBMC / MC
+// accumulator: the samples leave the sweep as a panel (each right-hand side contiguous); the
+// transposing unpack puts the kc values of a node side by side, which is the layout the LDS-tiled
+// SpMM and the accumulator read with full 128-byte lines.
+static gmrf_status var_chunk(gmrf_handle* h, int method, int64_t p, int kc, const gmrf_csr* Q, const double* q_vals,
+                             const double* d_diag, double* d_acc) {
+    const int64_t n = h->n;
+    const int kp = pad_k(kc), kcp = kc + (kc & 1);
+    GCHK(ensure_stage(h, 2 * (int64_t)kcp * n));
+    double* Xr = h->d_stage;
+    double* QX = h->d_stage + (int64_t)kcp * n;
+    hipLaunchKernelGGL(unpack_panel_rows, dim3((unsigned)((n + 63) / 64), (unsigned)((kc + 63) / 64)), dim3(256), 0, h->stream,
+                       h->d_Y + p * kp * h->n_pad, h->n_pad, Xr, (int64_t)kcp, (int)h->bs, (int)h->bsp, n, kc);
+    HIPCHK(hipGetLastError());
+    if (method == GMRF_VAR_RBMC) GCHK(spmm_rows_device(Q, h->stream, Xr, kcp, QX, kcp, kc, q_vals));
+    hipLaunchKernelGGL(rbmc_accumulate_rows, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, h->stream, QX, Xr, (int64_t)kcp,
+                       d_diag, n, kc, d_acc, method == GMRF_VAR_RBMC ? 0 : 1);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
 static gmrf_status var_accumulate_dev(gmrf_handle* h, int method, int64_t first_id, int64_t k, uint64_t seed,
                                       const gmrf_csr* Q, double* d_acc) {
     for (int64_t c0 = 0; c0 < k; c0 += 64) {
         const int kc = (int)std::min<int64_t>(64, k - c0);
         GCHK(sample_chunk(h, seed, first_id + c0, kc, nullptr, 0, 0));
-        GCHK(ensure_stage(h, 2 * (int64_t)kc * h->n));
-        double* Xc = h->d_stage;
-        double* QX = h->d_stage + (int64_t)kc * h->n;
-        GCHK(launch_unpack(h, h->d_Y, Xc, h->n, kc, nullptr));
-        if (method == GMRF_VAR_RBMC) {
-            GCHK(spmm_device(Q, h->stream, Xc, h->n, QX, h->n, kc));
-            hipLaunchKernelGGL(rbmc_accumulate, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, QX, Xc,
-                               h->n, Q->d_diag, h->n, kc, d_acc);
-        } else {
-            hipLaunchKernelGGL(mc_accumulate, dim3((unsigned)((h->n + 255) / 256)), dim3(256), 0, h->stream, Xc, h->n,
-                               h->n, kc, d_acc);
-        }
-        HIPCHK(hipGetLastError());
+        GCHK(var_chunk(h, method, 0, kc, Q, nullptr, Q ? Q->d_diag : nullptr, d_acc));
     }
     return GMRF_OK;
 }
@@ -1799,37 +2360,24 @@ gmrf_status gmrf_bt_marginal_var_batch(gmrf_handle* h, int32_t method, int64_t k
     if (method == GMRF_VAR_RBMC) {
         if (!is_device_ptr(q_vals)) {
             HIPCHK(hipMalloc(&d_qv, sizeof(double) * Q->nnz * B));
-            HIPCHK(hipMemcpyAsync(d_qv, q_vals, sizeof(double) * Q->nnz * B, hipMemcpyHostToDevice, h->stream));
+            if (hipMemcpyAsync(d_qv, q_vals, sizeof(double) * Q->nnz * B, hipMemcpyHostToDevice, h->stream) != hipSuccess) {
+                free_dev(d_qv); g_last_error = "hipMemcpyAsync(q_vals) failed"; return GMRF_ERR_HIP;
+            }
             qv = d_qv;
         }
-        HIPCHK(hipMalloc(&d_diag, sizeof(double) * n * B));
+        if (hipMalloc(&d_diag, sizeof(double) * n * B) != hipSuccess) { free_dev(d_qv); g_last_error = "hipMalloc(diag) failed"; return GMRF_ERR_HIP; }
         for (int64_t p = 0; p < B; ++p)
             hipLaunchKernelGGL(csr_extract_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, Q->d_rowptr,
                                Q->d_colidx, qv + p * Q->nnz, (const float*)nullptr, n, d_diag + p * n);
-        HIPCHK(hipGetLastError());
+        if (hipGetLastError() != hipSuccess) { free_dev(d_qv); free_dev(d_diag); g_last_error = "csr_extract_diag launch failed"; return GMRF_ERR_HIP; }
     }
     gmrf_status st = GMRF_OK;
     for (int64_t c0 = 0; c0 < k && st == GMRF_OK; c0 += 64) {
         const int kc = (int)std::min<int64_t>(64, k - c0);
         st = sample_chunk(h, seed, c0, kc, nullptr, 0, k);          // every problem's chunk in one sweep
-        if (st == GMRF_OK) st = ensure_stage(h, 2 * (int64_t)kc * n);
-        double* Xc = h->d_stage;
-        double* QX = h->d_stage + (int64_t)kc * n;
-        const int kp = pad_k(kc);
-        for (int64_t p = 0; p < B && st == GMRF_OK; ++p) {
-            const int64_t total = n * (int64_t)kc;
-            hipLaunchKernelGGL(unpack_panel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, h->stream,
-                               h->d_Y + p * kp * h->n_pad, h->n_pad, Xc, n, (int)h->bs, (int)h->bsp, n, kc, kp,
-                               (const double*)nullptr);
-            if (method == GMRF_VAR_RBMC) {
-                st = spmm_device(Q, h->stream, Xc, n, QX, n, kc, qv + p * Q->nnz);
-                hipLaunchKernelGGL(rbmc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, QX, Xc, n,
-                                   d_diag + p * n, n, kc, h->d_acc + p * n);
-            } else {
-                hipLaunchKernelGGL(mc_accumulate, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, Xc, n, n, kc,
-                                   h->d_acc + p * n);
-            }
-        }
+        for (int64_t p = 0; p < B && st == GMRF_OK; ++p)
+            st = var_chunk(h, method, p, kc, Q, method == GMRF_VAR_RBMC ? qv + p * Q->nnz : nullptr,
+                           method == GMRF_VAR_RBMC ? d_diag + p * n : nullptr, h->d_acc + p * n);
     }
     if (st == GMRF_OK) {
         for (int64_t p = 0; p < B; ++p)
@@ -1989,7 +2537,8 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
     gmrf_handle* h = nullptr;
     GCHK(gmrf_bt_create(device, nullptr, &h));
     h->N = 1; h->n = bs; h->bs = bs; h->bsp = bs; h->n_pad = bs; h->B = 1;
-    gmrf_status s = alloc_factor(h);
+    gmrf_status s = set_layout_dense(h);
+    if (s == GMRF_OK) s = alloc_factor(h);
     unsigned long long* dst = nullptr;
     if (s == GMRF_OK && hipMalloc(&dst, 8 * sizeof(unsigned long long)) == hipSuccess) {
         (void)hipMemset(dst, 0, 8 * sizeof(unsigned long long));

@@ -120,8 +120,9 @@ struct BxtArgs {
     const double* vals;       // [problems][n_entries]
     int64_t n_entries;
     const double* X;          // previous block's inverse
-    double* C;
-    int64_t ld, pX, pC;
+    double* C;                // compact coupling block [rm][bsp - cm] (columns cm .. of the logical block)
+    int64_t ld, ldc, pX, pC;  // row strides of X and C, problem strides
+    const int* kst;           // staircase: row tile t (64 rows) of B is zero left of column cm + kst[t] (monotone)
     int cm, rm, bsp;
     int cw;                   // columns of C per workgroup (16, 32 or 64: enough workgroups for a lone problem)
 };
@@ -168,7 +169,12 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
     const int tid = (int)threadIdx.x;
     const int wr = tid >> 4, wc = tid & 15;        // write-out: 16 lanes per row, 16 rows per pass
     const int rbase = rc * 256;
+    // C[r][c] = sum_j B[r][j] X[c][j] with X lower triangular vanishes for c < the row's first column:
+    // the column groups left of the staircase of this row chunk are never written (they hold zeros
+    // from the allocation) -- neither C nor the rows of X they would gather are touched
+    const int cfirst = a.cm + (a.kst ? a.kst[rbase >> 6] : 0);
     for (int c = c0; c < c0 + a.cw; c += 16) {
+        if (c + 16 <= cfirst) continue;
         const double* xr = X + (int64_t)c * a.ld;
         double acc[16];
 #pragma unroll
@@ -185,7 +191,7 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
 #pragma unroll 4
         for (int p = 0; p < 16; ++p) {
             const int rr = p * 16 + wr;
-            if (rbase + rr < a.rm) C[(int64_t)(rbase + rr) * a.ld + c + wc] = ls[rr * 17 + wc];
+            if (rbase + rr < a.rm) C[(int64_t)(rbase + rr) * a.ldc + (c - a.cm) + wc] = ls[rr * 17 + wc];
         }
         __syncthreads();
     }
@@ -291,6 +297,168 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
     }
 }
 
+// SpMM with LDS-staged row tiles for right-hand sides stored NODE-MAJOR ("interleaved": X[col][rhs],
+// row stride ldx >= k -- the k values one gathered column index needs are contiguous):
+//     Y[r][:] = sum_e vals[e] * X[col[e]][:]
+// A workgroup owns SPMM_ROWS consecutive rows.  The host-side plan (built once per matrix, like the
+// symbolic phase of the factor) lists the DISTINCT columns of every tile and replaces each entry's
+// column by its 16-bit index into that list.  Per tile: (1) the entries (local index, value) are
+// staged in LDS with coalesced independent loads; (2) per chunk of 16 right-hand sides the distinct
+// rows of X are gathered ONCE into LDS -- a FEM / finite-difference tile of 64 rows touches ~3.4
+// rows of X per output row instead of ~15, and each gathered piece is one full 128-byte line;
+// (3) lane (row, rhs) walks its row's entries in CSR order (fixed summation order, the same as
+// csr_spmv_tiles) reading values, indices and X from LDS; (4) the 64 x 16 results leave as 128-byte
+// pieces.  fp32 values (config 5) are widened when staged; accumulation is fp64 either way.
+constexpr int SPMM_ROWS = 64;
+constexpr int SPMM_CAP = 2048;            // entries per tile
+constexpr int SPMM_UMAX = 288;            // distinct columns per tile
+constexpr int SPMM_KC = 16;               // right-hand sides per chunk (one 128-byte line per row of X)
+constexpr int SPMM_XLD = 18;              // LDS row stride of the staged X rows (16-byte aligned, spreads banks)
+
+template <typename VT>
+__global__ __launch_bounds__(256) void csr_spmm_tiles(const int64_t* __restrict__ rowptr,
+                                                      const uint16_t* __restrict__ lidx,
+                                                      const VT* __restrict__ vals,
+                                                      const int64_t* __restrict__ tile_uptr,
+                                                      const int32_t* __restrict__ ucols, int64_t n_rows,
+                                                      const double* __restrict__ X, int64_t ldx,
+                                                      double* __restrict__ Y, int64_t ldy, int k) {
+    __shared__ __attribute__((aligned(16))) double xs[SPMM_UMAX * SPMM_XLD];
+    __shared__ double vs[SPMM_CAP];
+    __shared__ uint16_t ls[SPMM_CAP];
+    __shared__ int uc[SPMM_UMAX];
+    __shared__ int rp[SPMM_ROWS + 1];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * SPMM_ROWS;
+    const int nr = (int)min((int64_t)SPMM_ROWS, n_rows - r0);
+    const int64_t e0 = rowptr[r0];
+    if (t <= SPMM_ROWS) rp[t] = (int)(rowptr[r0 + min(t, nr)] - e0);
+    const int64_t u0 = tile_uptr[blockIdx.x];
+    const int U = (int)(tile_uptr[blockIdx.x + 1] - u0);
+    for (int u = t; u < U; u += 256) uc[u] = ucols[u0 + u];
+    const int cnt = (int)(rowptr[r0 + nr] - e0);
+    for (int base = 0; base < cnt; base += 1024) {          // four independent loads per thread and pass
+        uint16_t li[4];
+        double v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = base + t + 256 * i;
+            const bool ok = e < cnt;
+            li[i] = ok ? lidx[e0 + e] : (uint16_t)0;
+            v[i] = ok ? (double)vals[e0 + e] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = base + t + 256 * i;
+            if (e < cnt) { ls[e] = li[i]; vs[e] = v[i]; }
+        }
+    }
+    __syncthreads();
+    const int seg = t & 7, ub = t >> 3;                      // gather: 8 threads x 16 B per row piece, 32 rows per pass
+    const int kl = t & 15, rsub = (t >> 4) & 3, wave = t >> 6;
+    for (int kc0 = 0; kc0 < k; kc0 += SPMM_KC) {
+        const bool seg_ok = kc0 + 2 * seg < k;               // k is even on this path (host checks)
+        for (int ubase = 0; ubase < U; ubase += 32 * 6) {
+            v2d g[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u = ubase + ub + 32 * i;
+                g[i] = (v2d){0.0, 0.0};
+                if (u < U && seg_ok) g[i] = *reinterpret_cast<const v2d*>(X + (int64_t)uc[u] * ldx + kc0 + 2 * seg);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int u = ubase + ub + 32 * i;
+                if (u < U) *reinterpret_cast<v2d*>(xs + u * SPMM_XLD + 2 * seg) = g[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = p * 16 + wave * 4 + rsub;
+            const int a = rp[row], b = rp[row + 1];          // rows past nr: a == b
+            double acc = 0.0;
+            int e = a;
+            for (; e + 4 <= b; e += 4) {
+                const double x0 = xs[ls[e] * SPMM_XLD + kl], x1 = xs[ls[e + 1] * SPMM_XLD + kl];
+                const double x2 = xs[ls[e + 2] * SPMM_XLD + kl], x3 = xs[ls[e + 3] * SPMM_XLD + kl];
+                acc = fma(vs[e], x0, acc); acc = fma(vs[e + 1], x1, acc);
+                acc = fma(vs[e + 2], x2, acc); acc = fma(vs[e + 3], x3, acc);
+            }
+            for (; e < b; ++e) acc = fma(vs[e], xs[ls[e] * SPMM_XLD + kl], acc);
+            if (row < nr && kc0 + kl < k) Y[(r0 + row) * ldy + kc0 + kl] = acc;
+        }
+        __syncthreads();
+    }
+}
+
+// Node-major right-hand sides without a tile plan (a tile with too many entries or distinct columns,
+// odd k / ldx): 16 lanes along the right-hand sides, 4 rows per wave, operands straight from global
+// memory; same summation order.
+template <typename VT>
+__global__ __launch_bounds__(256) void csr_spmm_rows(const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ colidx,
+                                                     const VT* __restrict__ vals, int64_t n_rows,
+                                                     const double* __restrict__ X, int64_t ldx,
+                                                     double* __restrict__ Y, int64_t ldy, int k) {
+    const int t = threadIdx.x;
+    const int kl = t & 15;
+    const int64_t row = (int64_t)blockIdx.x * 16 + (t >> 4);
+    if (row >= n_rows) return;
+    const int64_t a = rowptr[row], b = rowptr[row + 1];
+    for (int kc0 = 0; kc0 < k; kc0 += 16) {
+        const bool ok = kc0 + kl < k;
+        double acc = 0.0;
+        for (int64_t e = a; e < b; ++e) {
+            const double xv = ok ? X[(int64_t)colidx[e] * ldx + kc0 + kl] : 0.0;
+            acc = fma((double)vals[e], xv, acc);
+        }
+        if (ok) Y[row * ldy + kc0 + kl] = acc;
+    }
+}
+
+// panel P[rhs][n_pad] (each right-hand side contiguous, padded blocks) -> node-major X[n][k] through a
+// 64 x 64 LDS tile (both sides move 128-byte pieces); blockIdx.x = 64-dof tile, blockIdx.y = 64-rhs tile
+__global__ __launch_bounds__(256) void unpack_panel_rows(const double* __restrict__ P, int64_t n_pad,
+                                                         double* __restrict__ dst, int64_t ld, int bs, int bsp,
+                                                         int64_t n, int k) {
+    __shared__ double tile[64][65];
+    const int t = threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.x * 64;
+    const int r0 = blockIdx.y * 64;
+    for (int i = t; i < 4096; i += 256) {
+        const int r = i >> 6, jj = i & 63;
+        const int64_t j = j0 + jj;
+        double v = 0.0;
+        if (r0 + r < k && j < n) v = P[(int64_t)(r0 + r) * n_pad + (j / bs) * bsp + (j % bs)];
+        tile[r][jj] = v;
+    }
+    __syncthreads();
+    for (int i = t; i < 4096; i += 256) {
+        const int jj = i >> 6, r = i & 63;
+        if (r0 + r < k && j0 + jj < n) dst[(j0 + jj) * ld + r0 + r] = tile[r][jj];
+    }
+}
+
+// acc[i] += sum_s ((QX[i][s] - d_i X[i][s]) / d_i)^2 with node-major QX, X (row stride ld): 16 lanes per node
+__global__ __launch_bounds__(256) void rbmc_accumulate_rows(const double* __restrict__ QX, const double* __restrict__ X,
+                                                            int64_t ld, const double* __restrict__ diag, int64_t n, int k,
+                                                            double* __restrict__ acc, int plain_mc) {
+    const int kl = threadIdx.x & 15;
+    const int64_t i = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    double s = 0.0;
+    if (i < n) {
+        const double d = plain_mc ? 1.0 : diag[i];
+        for (int r = kl; r < k; r += 16) {
+            const double o = plain_mc ? X[i * ld + r] : (QX[i * ld + r] - d * X[i * ld + r]) / d;
+            s = fma(o, o, s);
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    if (i < n && kl == 0) acc[i] += s;
+}
+
 // ------------------------------------------------------------------------------- variances
 // acc[i] += sum_s ((QX[s][i] - d_i X[s][i]) / d_i)^2     (RBMC off-diagonal term)
 __global__ void rbmc_accumulate(const double* __restrict__ QX, const double* __restrict__ X,
@@ -339,11 +507,12 @@ __global__ void var_finish(const double* __restrict__ acc, const double* __restr
     out[i] = (diag ? 1.0 / diag[i] : 0.0) + acc[i] * scale;
 }
 
-// sum over the diagonal of log(L[j][j]) for every block; one workgroup per block,
-// fixed-order tree so the result is reproducible.
+// sum over the diagonal of log(L[j][j]) for every block; one workgroup per block (blockIdx.x) and
+// problem (blockIdx.y), fixed-order tree so the result is reproducible.
 __global__ __launch_bounds__(256) void logdet_blocks(const double* __restrict__ L, int64_t blk_stride,
-                                                     int64_t ld, int bs, double* __restrict__ out) {
-    const double* Lb = L + (int64_t)blockIdx.x * blk_stride;
+                                                     int64_t ld, int bs, double* __restrict__ out,
+                                                     int64_t pL, int64_t pout) {
+    const double* Lb = L + (int64_t)blockIdx.y * pL + (int64_t)blockIdx.x * blk_stride;
     double s = 0.0;
     for (int j = threadIdx.x; j < bs; j += 256) s += log(Lb[(int64_t)j * ld + j]);
     __shared__ double red[256];
@@ -353,7 +522,7 @@ __global__ __launch_bounds__(256) void logdet_blocks(const double* __restrict__ 
         if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) out[(int64_t)blockIdx.y * pout + blockIdx.x] = red[0];
 }
 
 // diag(S) of a dense block into out (selected inversion output)

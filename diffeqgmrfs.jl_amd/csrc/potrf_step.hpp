@@ -338,7 +338,7 @@ struct StepArgs {
     int nt;               // tiles per dimension
     int* info;
     int blk;              // block id reported on a non-positive pivot (1-based)
-    int64_t pS, pLX;      // per-problem strides of S and of L / X (blockIdx.y)
+    int64_t pS, pL, pX;   // per-problem strides of S, L and X (blockIdx.y); L may be a one-block work buffer
     int blk_per_problem;  // reported id = blk + blockIdx.y * blk_per_problem
     int cend;             // potrf_update: column tiles j+1 .. cend-1 only (nt: the whole trailing block)
     unsigned long long* dbg;   // diagnostic stamps of workgroup 1 of step 0 (tests), else nullptr
@@ -353,8 +353,8 @@ struct StepArgs {
 template <bool UNUSED>
 __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
-    sa.L += (int64_t)blockIdx.y * sa.pLX;
-    sa.X += (int64_t)blockIdx.y * sa.pLX;
+    sa.L += (int64_t)blockIdx.y * sa.pL;
+    sa.X += (int64_t)blockIdx.y * sa.pX;
     sa.blk += (int)blockIdx.y * sa.blk_per_problem;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ts = smem;
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
 // permutation as in gemm_f64.hpp); each wave owns a 16-row strip of the 64x64 tile.
 __global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
-    sa.L += (int64_t)blockIdx.y * sa.pLX;
-    sa.X += (int64_t)blockIdx.y * sa.pLX;
+    sa.L += (int64_t)blockIdx.y * sa.pL;
+    sa.X += (int64_t)blockIdx.y * sa.pX;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
 
 __global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
-    sa.L += (int64_t)blockIdx.y * sa.pLX;
+    sa.L += (int64_t)blockIdx.y * sa.pL;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;

@@ -28,6 +28,10 @@ struct SweepArgs {
     int kdim;                           // length of the sums (TRI: rows == kdim)
     int sub;
     int64_t pMat, pXin, pBin, pOut;     // per-problem strides (blockIdx.z)
+    // staircase of a coupling block (non-triangular kernels only; nullptr: dense).  Per 64-wide tile:
+    // TRANS = false: row tile t sums over k >= kst[t];  TRANS = true: output tile u sums over k < mend[u].
+    const int* kst = nullptr;
+    const int* mend = nullptr;
 };
 
 __device__ __forceinline__ void sweep_select_problem(SweepArgs& s, int p) {
@@ -48,6 +52,9 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
     int kb = 0, ke = s.kdim;
     if (TRI) {
         if (!TRANS) ke = m0 + 16; else kb = m0;
+    } else {
+        if (!TRANS && s.kst) kb = s.kst[m0 >> 6];
+        if (TRANS && s.mend) ke = s.mend[m0 >> 6];
     }
     // split [kb, ke) over the 4 waves in multiples of 8
     const int total = ke - kb;
@@ -130,12 +137,13 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= s.rows) return;
     const int ke = TRI ? (row + 1) : s.kdim;
+    const int kb = (!TRI && s.kst) ? s.kst[row >> 6] : 0;      // staircase: the row is zero left of kb
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
     const double* __restrict__ x = s.Xin;
     double sum0 = 0.0, sum1 = 0.0;
     const int ke2 = ke & ~1;
     // all loads of a chunk of 8 strides are issued before the first fma consumes one
-    int k = lane * 2;
+    int k = kb + lane * 2;
     for (; k + 7 * 128 < ke2; k += 8 * 128) {
         v2d mv[8], xv[8];
 #pragma unroll
@@ -176,11 +184,12 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
     const int c = t & 15, gidx = t >> 4;
     const int col0 = blockIdx.x * 16;
     const int kb = TRI ? col0 : 0;          // lower triangular: rows >= column
+    const int ke = (!TRI && s.mend) ? s.mend[col0 >> 6] : s.kdim;   // staircase: the columns are zero below row ke
     const double* __restrict__ x = s.Xin;
     const double* __restrict__ mp = s.Mat + col0 + c;
     double sum = 0.0;
 #pragma unroll 16
-    for (int k = kb + gidx; k < s.kdim; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
+    for (int k = kb + gidx; k < ke; k += 16) sum = fma(mp[(int64_t)k * s.ld], x[k], sum);
     __shared__ double red[16][17];
     red[gidx][c] = sum;
     __syncthreads();

@@ -3,13 +3,19 @@ sweep), k_s samples (1 backward sweep), optionally marginal variances -- the per
 /root/reference/scripts/darcy/solve_darcy_gmrf-fem.jl:176-198 (`condition_on_observations`,
 `mean`, `rand`, `std`) on the block-tridiagonal path.
 
-Sharding across the GPUs of one node (one process per GPU, torch.distributed; backend "nccl"
-is RCCL on ROCm, "gloo" on CPU for the tests):
+Sharding across the GPUs of one node (one process per GPU):
   * samples are independent: rank r draws the sample ids [r*k_s, (r+1)*k_s) -- Philox keyed
     by (seed, sample id, dof), so a sample does not depend on the number of ranks;
-  * the factor is shared: rank 0 factors block ranges and broadcasts each finished range of
-    L / C / Linv blocks while the next range is being factored (the only collective on the
-    data path); the variance accumulators are summed with one all-reduce.
+  * the factor is shared: rank 0 factors block ranges and each finished range of Linv / C blocks
+    (what the sweeps read; the L blocks stay on rank 0) is broadcast while the next range is being
+    factored -- the only collective on the data path; variance accumulators are summed with one
+    all-reduce.
+
+Two transports move the factor, both RCCL on a GPU box:
+  * "cabi"  : the library's own communicator (gmrf_comm_*, include/gmrf_hip.h) -- what a Julia host
+              uses; broadcasts run on the communicator's stream beside the factorisation;
+  * "torch" : torch.distributed broadcasts of caller-owned storage tensors (gmrf_bt_set_storage);
+              backend "nccl" is RCCL, "gloo" serves the CPU tests.
 
 The engine object does the numerics.  `HipEngine` drives libgmrf_hip.so; the CPU tests plug an
 oracle-backed engine into the same driver to cover the N > 1 control flow without a GPU.
@@ -33,12 +39,14 @@ def block_groups(n_blocks: int, group: int) -> List[Tuple[int, int]]:
 
 
 class HipEngine:
-    """libgmrf_hip.so behind the driver protocol; factor storage lives in torch tensors so that
-    torch.distributed can broadcast it in place."""
+    """libgmrf_hip.so behind the driver protocol."""
 
-    def __init__(self, pkg, workload, device_index: int = 0, batch: int = 1, values=None, rhs=None):
+    def __init__(self, pkg, workload, device_index: int = 0, batch: int = 1, values=None, rhs=None,
+                 keep_l: bool = True, transport: str = "torch", comm=None):
         """`values` (batch, nnz) / `rhs` (batch, n): one row per independent problem on the
-        workload's sparsity pattern (default: the workload itself, repeated)."""
+        workload's sparsity pattern (default: the workload itself, repeated).  `keep_l` False: the L
+        blocks are not retained (gmrf_bt_set_keep_l).  `transport` / `comm`: see the module docstring
+        (`comm` = an api.Comm for "cabi")."""
         import torch
         self.torch = torch
         self.pkg = pkg
@@ -48,6 +56,12 @@ class HipEngine:
         torch.cuda.set_device(self.dev)
         self.stream = torch.cuda.current_stream(self.dev)
         self.F = pkg.TridiagonalCholeskyFactor(device=device_index, stream=self.stream.cuda_stream, batch=batch)
+        if not keep_l:
+            self.F.set_keep_l(False)
+        self.keep_l = keep_l
+        self.transport, self.comm = transport, comm
+        if transport == "cabi" and comm is None:
+            raise ValueError('transport "cabi" needs an api.Comm')
         if values is None:
             values = np.tile(np.ascontiguousarray(workload.Q.data), (batch, 1))
         if rhs is None:
@@ -56,30 +70,49 @@ class HipEngine:
         self.nz = torch.from_numpy(self.values_host).to(self.dev)
         self.rhs = torch.from_numpy(np.ascontiguousarray(rhs, dtype=np.float64).reshape(batch, 1, -1)).to(self.dev)
         self.buffers = None
-        self._analysed = False
+        self._pending = []
 
-    # --- storage shared with torch
+    # --- storage shared with torch (transport "torch")
     def _attach_storage(self):
         import ctypes as C
         lib = self.pkg._cabi.load()
         bl, bc, bi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        self.pkg._cabi.check(lib.gmrf_bt_storage_bytes(self.w.n, self.w.n_blocks, C.byref(bl), C.byref(bc), C.byref(bi)))
+        self.pkg._cabi.check(lib.gmrf_bt_storage_bytes(self.w.n, self.w.n_blocks, self.batch, C.byref(bl), C.byref(bc),
+                                                       C.byref(bi)))
         t = self.torch
-        self.buffers = [t.zeros(b.value // 8, dtype=t.float64, device=self.dev) for b in (bl, bc, bi)]
-        self.pkg._cabi.check(lib.gmrf_bt_set_storage(self.F._h, self.w.n, self.w.n_blocks,
+        # (C at its dense upper bound: the layout is not known on the receiving ranks yet)
+        self.buffers = [t.zeros(b.value // 8, dtype=t.float64, device=self.dev) if (i > 0 or self.keep_l) else None
+                        for i, b in enumerate((bl, bc, bi))]
+        self.pkg._cabi.check(lib.gmrf_bt_set_storage(self.F._h, self.w.n, self.w.n_blocks, self.batch,
                                                      *[self.pkg._cabi.ptr(b) for b in self.buffers]))
-        self.block_elems = [self.buffers[0].numel() // self.w.n_blocks] * 3
         self.F._set_shape(self.w.n, self.w.n_blocks)
 
-    def prepare(self, is_root: bool, shared_storage: bool):
-        """Untimed set-up: symbolic analysis (root), storage, graph capture."""
-        if shared_storage:
-            self._attach_storage()
-        if is_root or not shared_storage:
+    def prepare(self, is_root: bool, shared_storage: bool, dist=None):
+        """Untimed set-up: symbolic analysis (root), the layout of the stored coupling blocks to every
+        rank, storage, graph capture."""
+        if not shared_storage:
             self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)   # analyse + first numeric factor
-            self._analysed = True
-        elif not shared_storage:
-            self.F.adopt_shape(self.w.n, self.w.n_blocks)
+            return
+        if self.transport == "torch":
+            self._attach_storage()
+        if is_root:
+            self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)
+            layout = self.F.get_layout()
+        else:
+            layout = None
+        # the layout record (a few int64) travels once, before the timed region
+        if self.transport == "cabi":
+            cnt = np.array([0 if layout is None else layout.size], dtype=np.int64)
+            self.comm.bcast_host(cnt, 0)
+            if layout is None:
+                layout = np.zeros(int(cnt[0]), dtype=np.int64)
+            self.comm.bcast_host(layout, 0)
+        else:
+            box = [layout]
+            dist.broadcast_object_list(box, src=0)
+            layout = np.asarray(box[0], dtype=np.int64)
+        if not is_root:
+            self.F.adopt_layout(self.w.n, self.w.n_blocks, layout)
 
     # --- numeric phases
     def factor(self):
@@ -94,16 +127,31 @@ class HipEngine:
         self.F.factor_end()
 
     def adopt_commit(self):
-        self.F.adopt_commit()
+        self.F.adopt_commit(False)
 
-    def slices(self, i0: int, i1: int):
-        """The tensors holding blocks [i0, i1) of L, C (blocks i0-1 .. i1-2) and Linv."""
-        e = self.block_elems[0]
-        out = [self.buffers[0][i0 * e:i1 * e], self.buffers[2][i0 * e:i1 * e]]
-        c0, c1 = max(i0 - 1, 0), max(i1 - 1, 0)
-        if c1 > c0:
-            out.append(self.buffers[1][c0 * e:c1 * e])
+    def _range_tensors(self, i0: int, i1: int):
+        """Views of the storage tensors that hold blocks [i0, i1) of Linv and C for every problem."""
+        out = []
+        for kind, buf in ((self.pkg._cabi.BLOCK_LINV, self.buffers[2]), (self.pkg._cabi.BLOCK_C, self.buffers[1])):
+            first, cnt, pstride = self.F.block_range(kind, i0, i1)
+            if cnt:
+                out.extend(buf[p * pstride + first:p * pstride + first + cnt] for p in range(self.batch))
         return out
+
+    def share_range(self, dist, i0: int, i1: int):
+        """Enqueue the broadcast of the finished blocks [i0, i1) from rank 0 (every rank calls this)."""
+        if self.transport == "cabi":
+            self.comm.bcast_blocks_async(self.F, i0, i1, root=0, with_l=False)
+        else:
+            self._pending.extend(dist.broadcast(t, src=0, async_op=True) for t in self._range_tensors(i0, i1))
+
+    def share_finish(self):
+        if self.transport == "cabi":
+            self.comm.wait(self.F)
+        else:
+            for hnd in self._pending:
+                hnd.wait()
+            self._pending = []
 
     def mean(self):
         """(batch, n) posterior means."""
@@ -128,7 +176,7 @@ class ShardedPosterior:
         self.groups = block_groups(engine.w.n_blocks, group)
 
     def prepare(self):
-        self.e.prepare(is_root=(self.rank == 0), shared_storage=not self.replicate)
+        self.e.prepare(is_root=(self.rank == 0), shared_storage=not self.replicate, dist=self.dist)
         if self.dist is not None and self.world > 1:
             self.dist.barrier()
 
@@ -136,14 +184,11 @@ class ShardedPosterior:
         if self.replicate:
             self.e.factor()
             return
-        handles = []
         for gi, (i0, i1) in enumerate(self.groups):
             if self.rank == 0:
                 self.e.factor_range_async(i0, i1, first=(gi == 0))
-            for t in self.e.slices(i0, i1):
-                handles.append(self.dist.broadcast(t, src=0, async_op=True))
-        for hnd in handles:
-            hnd.wait()
+            self.e.share_range(self.dist, i0, i1)
+        self.e.share_finish()
         if self.rank == 0:
             self.e.factor_end()
         else:
@@ -159,10 +204,10 @@ class ShardedPosterior:
         return mu, X
 
     def solves_per_step(self) -> int:
-        """Posterior solves of one step over all ranks.  Shared factor (broadcast): one mean and
-        k samples per rank.  Replicated / independent problems: every rank handles its own batch
-        of problems, each with its own mean and k samples."""
+        """Posterior solves of one step over all ranks.  Shared factor (broadcast): per problem one
+        mean and k samples per rank.  Replicated / independent problems: every rank handles its own
+        batch of problems, each with its own mean and k samples."""
         nb = getattr(self.e, "batch", 1)
         if self.replicate:
             return self.world * nb * (1 + self.k)
-        return 1 + self.k * self.world
+        return nb * (1 + self.k * self.world)

@@ -41,7 +41,8 @@ enum {
     GMRF_ERR_HIP = -4,         /* a HIP runtime call failed (gmrf_last_error has the text)  */
     GMRF_ERR_NO_FACTOR = -5,   /* solve/sample before a successful factor                    */
     GMRF_ERR_NO_DEVICE = -6,   /* no gfx950 device visible                                   */
-    GMRF_ERR_ALLOC = -7
+    GMRF_ERR_ALLOC = -7,
+    GMRF_ERR_RCCL = -8         /* librccl missing or a collective failed (gmrf_last_error)  */
 };
 
 enum { GMRF_SOLVE_FULL = 0, GMRF_SOLVE_FORWARD = 1, GMRF_SOLVE_BACKWARD = 2 };
@@ -50,6 +51,7 @@ enum { GMRF_BLOCK_L = 0, GMRF_BLOCK_C = 1, GMRF_BLOCK_LINV = 2 };
 
 typedef struct gmrf_handle gmrf_handle;   /* block-tridiagonal factor context  */
 typedef struct gmrf_csr gmrf_csr;         /* device-resident CSR matrix (K6)   */
+typedef struct gmrf_comm gmrf_comm;       /* RCCL communicator of this process */
 
 /* One sparse block in compressed-sparse-row or -column form, as extract_blocks
  * (scripts/solve_burger.jl:240-247) returns them: `ptr` has dim+1 entries. */
@@ -66,10 +68,10 @@ typedef struct {
     double solve_ms;           /* last gmrf_bt_solve (device part)                          */
     double sample_ms;          /* last gmrf_bt_sample                                       */
     double factor_flops;       /* N bs^3/3 + (N-1) 2 bs^3 (LAPACK counts, logical bs)       */
-    double sweep_bytes;        /* 8 [N bs(bs+1)/2 + (N-1) bs^2] + 16 n k of the last sweep   */
+    double sweep_bytes;        /* 8 [N bs(bs+1)/2 + (N-1) bs^2] + 16 n k of the last sweep (the reference's dense blocks) */
     double sweep_ms;           /* duration of the last single sweep                         */
     int64_t n, n_blocks, block_size, block_size_padded;
-    int64_t factor_bytes;      /* device bytes held by L, C, Linv                           */
+    int64_t factor_bytes;      /* device bytes held by L (if kept), C (stored window), Linv */
     /* per-kernel accounting, filled when profiling is on (gmrf_bt_set_profiling); one class per
      * kernel symbol so that a class compares with one row of a rocprofv3 kernel trace:
      *  0 / 11 / 12 gemm_f64_mfma<false,false> / <false,true> / <true,*> (64 x 64 tile GEMM: G2,
@@ -85,6 +87,7 @@ typedef struct {
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];
     int64_t kernel_launches[GMRF_KERNEL_CLASSES];
+    double sweep_bytes_streamed;  /* bytes the last sweep really read: Linv triangles + C inside the staircase + 16 n k */
 } gmrf_stats;
 
 /* ------------------------------------------------------------------ life cycle */
@@ -180,23 +183,66 @@ gmrf_status gmrf_bt_export_size(gmrf_handle* h, int64_t* bytes);
 gmrf_status gmrf_bt_export_factor(gmrf_handle* h, void* host_buf, int64_t bytes);
 gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* host_buf, int64_t bytes);
 
-/* Device buffers of the factor, the unit of the RCCL broadcast: kind L / C / LINV gives
- * the base pointer and byte count of that contiguous array of padded row-major blocks. */
+/* Storage of the factor on the device (all fp64, row-major blocks padded to bsp = 64 * 2^p):
+ *   LINV  [batch][N][bsp][bsp]      Linv_i = inv(chos[i].L), lower triangular -- what the sweeps stream
+ *   C     [batch][N-1][rmax][bsp - cmin]   the non-zero WINDOW of Cs[i]: rows 0 .. rmax, columns cmin ..
+ *         (a FEM coupling block is zero outside it; inside, row tile t is zero left of cmin + kst[t]).
+ *         The layout record {cmin, rmax, n_row_tiles, kst[...]} comes from the symbolic phase
+ *         (gmrf_bt_get_layout) and travels with a broadcast factor (gmrf_bt_adopt_layout).
+ *   L     [batch][N][bsp][bsp]      chos[i].L -- only F.chos / export / logdet read it.  With
+ *         gmrf_bt_set_keep_l(h, 0) L_i lives in a one-block work buffer (log-determinant parts are taken
+ *         during the factorisation): darcy256 1.60 -> 0.84 GB per posterior; F.chos is then unavailable.
+ * gmrf_bt_factor_buffer gives base pointer and byte count of one array; gmrf_bt_block_range the element
+ * range (per problem, plus the problem stride) that holds blocks [i0, i1) -- the unit of a block-range
+ * broadcast (for kind C: the coupling blocks i0-1 .. i1-2). */
 gmrf_status gmrf_bt_factor_buffer(gmrf_handle* h, int32_t kind, void** dev_ptr,
                                   int64_t* bytes);
+gmrf_status gmrf_bt_block_range(gmrf_handle* h, int32_t kind, int64_t i0, int64_t i1,
+                                int64_t* first_elem, int64_t* n_elems, int64_t* problem_stride);
+gmrf_status gmrf_bt_set_keep_l(gmrf_handle* h, int32_t keep);
+gmrf_status gmrf_bt_get_layout(gmrf_handle* h, int64_t* out, int64_t cap, int64_t* count);
 
-/* Caller-owned factor storage (e.g. torch tensors that RCCL broadcasts): sizes for a shape,
- * then the three device buffers.  Must be set before the first factor / adopt_shape of that
- * shape; the buffers must outlive the handle's use of them. */
-gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t* bytes_L,
+/* Caller-owned factor storage (e.g. torch tensors that RCCL broadcasts): upper bounds of the sizes
+ * for a shape and batch (C at its dense size), then the three device buffers (dev_L may be NULL after
+ * gmrf_bt_set_keep_l(h, 0)).  `batch` must equal the handle's batch.  Must be set before the first
+ * factor / adopt of that shape; the buffers must outlive the handle's use of them; whatever the
+ * handle had factored before is dropped. */
+gmrf_status gmrf_bt_storage_bytes(int64_t n, int64_t n_blocks, int64_t batch, int64_t* bytes_L,
                                   int64_t* bytes_C, int64_t* bytes_Linv);
-gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, void* dev_L,
-                                void* dev_C, void* dev_Linv);
+gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, int64_t batch,
+                                void* dev_L, void* dev_C, void* dev_Linv);
 
-/* Allocate factor storage for a given shape WITHOUT factoring (a rank that receives the
- * factor by broadcast), then mark it valid once the buffers have been filled. */
+/* A rank that RECEIVES the factor (broadcast): shape plus the root's layout record (adopt_shape =
+ * dense coupling blocks), storage allocated WITHOUT factoring; once the buffers have been filled
+ * adopt_commit marks the factor valid (l_blocks_valid != 0: the L buffer was filled too). */
+gmrf_status gmrf_bt_adopt_layout(gmrf_handle* h, int64_t n, int64_t n_blocks,
+                                 const int64_t* layout, int64_t count);
 gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks);
-gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h);
+gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid);
+
+/* ------------------------------------------------------------------ multi-GPU (RCCL over xGMI)
+ * One process per GPU.  The factor is shared, right-hand sides / samples are sharded:
+ * rank 0 factors block ranges (gmrf_bt_factor_begin_csc / _step_async) and each finished range is
+ * broadcast (R1) while the next one is being factored; every rank then solves / samples its own
+ * sample ids; variance accumulators are summed with one all-reduce (R2).
+ *   rank 0:  gmrf_comm_unique_id(id)  -> ship the 128 bytes to the other processes by any means
+ *   all:     gmrf_comm_create(device, rank, world, id, &c)
+ *   ranks>0: gmrf_bt_adopt_layout(h, n, N, layout)   (layout: gmrf_bt_get_layout on rank 0, moved with
+ *            gmrf_comm_bcast_host)
+ *   per job, for each block range:  rank 0: gmrf_bt_factor_step_async(h, i0, i1);
+ *                                   all:    gmrf_bt_bcast_blocks_async(h, c, 0, i0, i1, 0)
+ *            then  all: gmrf_comm_wait(h, c);  rank 0: gmrf_bt_factor_end;  ranks>0: gmrf_bt_adopt_commit(h, 0)
+ * librccl is opened with dlopen on first use (GMRF_RCCL_PATH overrides the search). */
+gmrf_status gmrf_comm_unique_id(void* id128);
+gmrf_status gmrf_comm_create(int32_t device, int32_t rank, int32_t world, const void* id128,
+                             gmrf_comm** out);
+gmrf_status gmrf_comm_destroy(gmrf_comm* c);
+gmrf_status gmrf_comm_bcast_host(gmrf_comm* c, void* host_buf, int64_t bytes, int32_t root);
+gmrf_status gmrf_comm_allreduce_sum(gmrf_comm* c, gmrf_handle* stream_of, double* dev_buf,
+                                    int64_t count);
+gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t root, int64_t i0,
+                                       int64_t i1, int32_t with_l);
+gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c);
 
 /* Pipelined factorisation (factor block ranges so a broadcast of finished blocks can
  * overlap): begin uploads the matrix, step_async enqueues blocks [i0, i1) and returns,
@@ -221,7 +267,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
 /* bit 0: plain stream launches instead of replaying captured HIP graphs; bit 1: three-launch
  * panel step also for batch 1; bit 2: keep 64-multiples of right-hand sides on sweep_mm;
  * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse; bit 4: second
- * branch in the captured factor graph (inverse assembly beside the panel chain; experiment). */
+ * branch in the captured factor graph (inverse assembly beside the panel chain; experiment); bit 5:
+ * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 
@@ -237,6 +284,14 @@ gmrf_status gmrf_csr_destroy(gmrf_csr* m);
 /* Y = S X ;  X: n_cols x k, Y: n_rows x k, column-major with leading dimensions ldx, ldy. */
 gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k,
                       int64_t ldx, int64_t ldy);
+/* The same product with NODE-MAJOR operands: X is n_cols x k with the k values of one column index
+ * contiguous (row stride ldx >= k), Y likewise -- in Julia the k x n matrices permutedims(X),
+ * permutedims(Y).  This is the layout of the LDS-tiled kernel (csr_spmm_tiles): one gathered column
+ * index fetches k contiguous doubles, and the distinct rows of X a 64-row tile needs are staged in
+ * LDS once (the RBMC estimator of `std(x)` runs on it: 50 samples x Q * x,
+ * scripts/darcy/solve_darcy_gmrf-fem.jl:100,192). */
+gmrf_status gmrf_spmm_rows(const gmrf_csr* S, const double* X, double* Y, int64_t k,
+                           int64_t ldx, int64_t ldy);
 
 /* ------------------------------------------------------------------ posterior assembly
  * The step before the factorisation in the reference's Gauss-Newton loop

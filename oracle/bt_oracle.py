@@ -205,22 +205,25 @@ def sample(F: TridiagonalCholeskyFactor, mean: np.ndarray, Z: np.ndarray) -> np.
     return X + (mean[:, None] if Z.ndim == 2 else mean)
 
 
-def marginal_variances_exact(F: TridiagonalCholeskyFactor) -> np.ndarray:
+def marginal_variances_exact(F: TridiagonalCholeskyFactor, last_blocks: int = 0) -> np.ndarray:
     """diag(A^-1) by block-tridiagonal selected inversion:
-    S_NN = L_N^-T L_N^-1,  S_ii = L_i^-T (I + C_i^T S_{i+1,i+1} C_i) L_i^-1   (C_i = Cs[i])."""
+    S_NN = L_N^-T L_N^-1,  S_ii = L_i^-T (I + C_i^T S_{i+1,i+1} C_i) L_i^-1   (C_i = Cs[i]).
+    The recursion runs from the last block upwards; `last_blocks` > 0 stops after that many blocks and
+    returns their variances only (the tail of the vector) -- enough to pin a large case cheaply."""
     N, bs = F.n_blocks, F.block_size
+    stop = 0 if last_blocks <= 0 else max(0, N - last_blocks)
     out = np.empty(F.N)
     eye = np.eye(bs)
     Li = _chol_forward(F.chos[N - 1], eye)
-    S = Li.T @ Li
+    S = _mm(Li, Li, True)
     out[(N - 1) * bs:] = np.diag(S)
-    for i in range(N - 2, -1, -1):
+    for i in range(N - 2, stop - 1, -1):
         C = F.Cs[i]
         Li = _chol_forward(F.chos[i], eye)
-        S = Li.T @ (eye + C.T @ S @ C) @ Li
+        S = _mm(Li, _mm(eye + _mm(C, _mm(S, C), True), Li), True)
         S = 0.5 * (S + S.T)
         out[i * bs:(i + 1) * bs] = np.diag(S)
-    return out
+    return out[stop * bs:]
 
 
 def marginal_variances_rbmc(Q, X: np.ndarray) -> np.ndarray:

@@ -17,8 +17,9 @@ class OracleEngine:
         self.F = None
         self.calls = []
 
-    def prepare(self, is_root, shared_storage):
+    def prepare(self, is_root, shared_storage, dist=None):
         self.calls.append(("prepare", is_root, shared_storage))
+        self._pending = []
 
     def _factor_all(self):
         F = O.tridiagonal_cholesky(self.w.Q, self.w.n_blocks)
@@ -41,16 +42,23 @@ class OracleEngine:
         self.adopt_commit()
 
     def adopt_commit(self):
+        # like the HIP path, only Linv and C travel: every rank (the root too, so that all ranks hold
+        # bitwise the same factor) rebuilds the triangular blocks from the inverses it holds
         N = self.w.n_blocks
-        self.F = O.TridiagonalCholeskyFactor(self.w.n, [self.L[i].numpy() for i in range(N)],
+        self.F = O.TridiagonalCholeskyFactor(self.w.n, [np.linalg.inv(self.Li[i].numpy()) for i in range(N)],
                                              [self.C[i].numpy() for i in range(N - 1)])
 
-    def slices(self, i0, i1):
-        out = [self.L[i0:i1], self.Li[i0:i1]]
+    def share_range(self, dist, i0, i1):
+        ts = [self.Li[i0:i1]]
         c0, c1 = max(i0 - 1, 0), max(i1 - 1, 0)
         if c1 > c0:
-            out.append(self.C[c0:c1])
-        return out
+            ts.append(self.C[c0:c1])
+        self._pending.extend(dist.broadcast(t, src=0, async_op=True) for t in ts)
+
+    def share_finish(self):
+        for hnd in self._pending:
+            hnd.wait()
+        self._pending = []
 
     batch = 1
 

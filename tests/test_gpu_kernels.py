@@ -153,3 +153,17 @@ def test_microbench_rates(lib, pkg):
     pkg._cabi.check(lib.gmrf_test_hbm_rate(0, 1 << 30, C.byref(gb)))
     print(f"\nmeasured fp64 MFMA rate {tf.value:.1f} TFLOP/s, HBM read {gb.value:.0f} GB/s")
     assert tf.value > 20.0 and gb.value > 1000.0
+
+
+def test_multi_rank_rehearsal_on_one_gpu(rehearsal):
+    """The N > 1 path on real device buffers (tests/conftest.py ran tools/rehearse_driver.py before this
+    process touched the GPU): two ranks on cuda:0 over gloo -- rank 0 factors block ranges, the Linv / C
+    ranges of a BATCH of two problems are broadcast into rank 1's caller-owned storage, both ranks take
+    the mean and draw their own sample ids, one all-reduce -- and the library's RCCL communicator
+    (gmrf_comm_*, the path a Julia host takes) with a world of one rank."""
+    assert rehearsal, "the rehearsal did not run (no GPU visible at session start?)"
+    res = rehearsal.get("result")
+    assert res is not None, rehearsal.get("tail")
+    assert res.get("two_ranks_rc") == 0, res.get("two_ranks.log")
+    assert res.get("single_rc") == 0, res.get("single.log")
+    assert res["ok"], res["checks"]

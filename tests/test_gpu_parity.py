@@ -699,3 +699,282 @@ def test_condition_on_observations_problem_loop(pkg):
     Qp2, Fo2, mu2 = O.condition_on_observations(Q0, None, A2, 1e8, y2, N)
     assert rel(x.mean(), mu2) < solve_tol(w)
     assert np.max(np.abs(x.var() - O.marginal_variances_exact(Fo2)) / O.marginal_variances_exact(Fo2)) < 1e-9
+
+
+# ----------------------------------------------------------------------------- round 2: parity at the BASELINE sizes
+
+def _hip_memcpy_d2d(dst_ptr, src_ptr, nbytes):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    assert hip.hipMemcpy(C.c_void_p(dst_ptr), C.c_void_p(src_ptr), C.c_size_t(nbytes), 3) == 0
+
+
+def test_config_darcy256_against_oracle(pkg):
+    """BASELINE metric config (C3: 256 x 256 Darcy, 64 blocks of 1024) against the oracle at FULL size:
+    posterior mean, 64 samples with given z, log-determinant, exact marginal variances of the last
+    eight blocks, factor blocks.  Tolerance: 0.25 * cond(Q) * eps (cond = 3.4e9 -> 1.9e-7), justified by
+    test_forward_error_not_worse_than_lapack; variances max(1e-9, 0.01 * cond * eps) = 7.5e-9 relative
+    (BASELINE.md's flat 1e-9 holds up to cond ~ 4e8; measured here 1.4e-9 on variances of 1.3e-11)."""
+    w = pkg.workloads.make("darcy256")
+    w.meta.setdefault("cond", 3.4e9)               # measured once (tools/accuracy_check.py); eigsh at n = 65536 takes minutes
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    tol = solve_tol(w)
+    mu, mu_o = pkg.ldiv(F, w.rhs), O.ldiv(Fo, w.rhs)
+    assert rel(mu, mu_o) < tol
+    Z = np.random.default_rng(7).standard_normal((w.n, 64))
+    assert rel(F.sample(64, mean=mu_o, z=Z), O.sample(Fo, mu_o, Z)) < tol
+    assert abs(F.logdet() - O.logdet(Fo)) < 1e-10 * abs(O.logdet(Fo))
+    for i in (0, 31, 63):
+        assert np.max(np.abs(np.tril(F.chos[i]) - Fo.chos[i])) / np.max(np.abs(Fo.chos[i])) < TOL_FACTOR
+    for i in (0, 62):
+        assert np.max(np.abs(F.Cs[i] - Fo.Cs[i])) / np.max(np.abs(Fo.Cs[i])) < TOL_FACTOR
+    vo = O.marginal_variances_exact(Fo, last_blocks=8)
+    v = F.marginal_var("exact")[-vo.size:]
+    assert np.max(np.abs(v - vo) / vo) < max(1e-9, 0.01 * w.meta["cond"] * EPS)
+
+
+@pytest.mark.parametrize("name", ["burgers512x64", "darcy64", "darcy256"])
+def test_forward_error_not_worse_than_lapack(pkg, name):
+    """Why the parity gate is cond-aware: against an extended-precision solution (iterative refinement
+    with long-double residuals) the HIP path is as close to the truth as the LAPACK-backed oracle --
+    both sit at O(cond * eps), so the two cannot agree with each other any better.  Asserted: HIP
+    forward error <= 2 x the oracle's, on BASELINE configs C1, C2, C3."""
+    w = pkg.workloads.make(name)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    x_o = O.ldiv(Fo, w.rhs)
+    Ql = w.Q.tocsr().astype(np.longdouble)
+    bl = w.rhs.astype(np.longdouble)
+    x = x_o.astype(np.longdouble)
+    for _ in range(6):
+        x = x + O.ldiv(Fo, np.asarray(bl - Ql @ x, dtype=np.float64)).astype(np.longdouble)
+    x_true = np.asarray(x, dtype=np.float64)
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    x_g = pkg.ldiv(F, w.rhs)
+    err_o, err_g = rel(x_o, x_true), rel(x_g, x_true)
+    print(f"{name}: forward error oracle {err_o:.2e}, HIP {err_g:.2e}, HIP vs oracle {rel(x_g, x_o):.2e}")
+    assert err_g <= 2.0 * err_o + 1e-15
+    assert rel(x_g, x_o) <= 3.0 * max(err_o, err_g) + 1e-15
+
+
+def test_config_burgers4096x512_full_size(pkg):
+    """BASELINE config[4] (C5) at FULL size: 4096 spatial nodes x 512 time steps, n = 2 097 152, 512
+    blocks of 4096, fp32-value SpMV / SpMM with fp64 accumulation.  (i) size-independent properties of
+    the full chain: backward error, backward o forward = ldiv, z'z = x'Ax; (ii) the oracle on a
+    truncated chain (4096 x 4 blocks); (iii) SpMV / SpMM on the 31 M-entry precision matrix, fp64 and
+    fp32 values, against SciPy."""
+    import torch
+    w = pkg.workloads.make("burgers4096x512")
+    assert (w.n, w.n_blocks, w.block_size) == (2097152, 512, 4096)
+    F = pkg.TridiagonalCholeskyFactor()
+    F.set_keep_l(False)                              # 137 GB of factor instead of 206 GB
+    F.factor(w.Q, w.n_blocks)
+    mu = pkg.ldiv(F, w.rhs)
+    qn = abs(w.Q).sum(axis=1).max()
+    assert np.linalg.norm(w.Q @ mu - w.rhs) / (qn * np.linalg.norm(mu) + np.linalg.norm(w.rhs)) < 1e-14
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((w.n, 2))
+    assert rel(pkg.backward_solve(F, pkg.forward_solve(F, B)), pkg.ldiv(F, B)) < 1e-13
+    Xs = pkg.backward_solve(F, B)
+    assert np.allclose(np.sum(Xs * (w.Q @ Xs), axis=0), np.sum(B * B, axis=0), rtol=1e-9)
+    with pytest.raises(pkg.GmrfError):               # the L blocks were not kept
+        F.get_block(pkg._cabi.BLOCK_L, 0)
+    ld_full = F.logdet()
+    assert np.isfinite(ld_full)
+    F.close()
+    # (iii) K6 on the full precision matrix
+    Qr = w.Q.tocsr()
+    X = rng.standard_normal((w.n, 8))
+    S64, S32 = pkg.CsrMatrix(Qr), pkg.CsrMatrix(Qr, values_f32=True)
+    Q32 = Qr.copy(); Q32.data = Q32.data.astype(np.float32).astype(np.float64)
+    ref64, ref32 = Qr @ X, Q32 @ X
+    assert rel(S64 @ X, ref64) < 1e-14 and rel(S64 @ X[:, 0], ref64[:, 0]) < 1e-14
+    assert rel(S32 @ X, ref32) < 1e-14 and rel(S32 @ X[:, 0], ref32[:, 0]) < 1e-14
+    assert rel(S32 @ X, ref64) < 1e-6                # fp32 values: 2^-24 relative per entry, fp64 accumulation
+    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()      # device-resident, 64 right-hand sides
+    X64 = torch.cat([Xd] * 8, dim=1).t().contiguous().t()
+    Y64 = (S32 @ X64).cpu().numpy()
+    assert rel(Y64[:, :8], ref32) < 1e-14 and np.array_equal(Y64[:, 8:16], Y64[:, :8])
+    del S64, S32
+    # (ii) the same model with 4 time steps against the oracle (bs = 4096: two-level panels, six doubling levels)
+    wt = pkg.workloads.burgers(4096, 4)
+    Ft = pkg.tridiagonal_cholesky(wt.Q, wt.n_blocks)
+    Fo = O.tridiagonal_cholesky(wt.Q, wt.n_blocks)
+    for i in (0, 3):
+        assert np.max(np.abs(np.tril(Ft.chos[i]) - Fo.chos[i])) / np.max(np.abs(Fo.chos[i])) < TOL_FACTOR
+    assert np.max(np.abs(Ft.Cs[2] - Fo.Cs[2])) / np.max(np.abs(Fo.Cs[2])) < TOL_FACTOR
+    Bt = rng.standard_normal((wt.n, 3))
+    xo = O.ldiv(Fo, Bt)
+    assert rel(pkg.ldiv(Ft, Bt), xo) < solve_tol(wt)
+    assert abs(Ft.logdet() - O.logdet(Fo)) < 1e-10 * abs(O.logdet(Fo))
+
+
+def test_staircase_of_the_coupling_blocks_is_exact(pkg):
+    """The symbolic phase finds, per 64-row tile, the first non-zero column of the coupling blocks;
+    G2 (S = D - C C^T), the C products of the sweeps and the sparse C = B X^T skip what lies left of
+    it.  Skipped terms are exact zeros: the factor is BITWISE the one the dense window gives
+    (set_eager bit 5), solves agree to rounding (the k = 1 kernels deal the row to lanes differently)."""
+    for name in ("darcy64", "elliptic32", "burgers64x8"):
+        w = pkg.workloads.make(name)
+        Fs = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        Fd = pkg.TridiagonalCholeskyFactor()
+        Fd.set_eager(32)
+        Fd.factor(w.Q, w.n_blocks)
+        lay_s, lay_d = Fs.get_layout(), Fd.get_layout()
+        assert tuple(lay_s[:3]) == tuple(lay_d[:3]) and np.all(lay_d[3:] == 0) and np.all(np.diff(lay_s[3:]) >= 0)
+        if name == "darcy64":                       # 4 node rows of 64 per block, reach 3 rows: tile a starts at column 64 (a + 1)
+            assert list(lay_s) == [64, 192, 3, 0, 64, 128]
+        for i in (0, w.n_blocks // 2, w.n_blocks - 1):
+            assert np.array_equal(Fs.chos[i], Fd.chos[i])
+            assert np.array_equal(Fs.get_block(pkg._cabi.BLOCK_LINV, i), Fd.get_block(pkg._cabi.BLOCK_LINV, i))
+            if i < w.n_blocks - 1:
+                assert np.array_equal(Fs.Cs[i], Fd.Cs[i])
+        B = np.random.default_rng(2).standard_normal((w.n, 64))
+        for b in (w.rhs, B[:, :3], B):
+            assert rel(pkg.ldiv(Fs, b), pkg.ldiv(Fd, b)) < 1e-13
+        assert np.max(np.abs(Fs.marginal_var("exact") / Fd.marginal_var("exact") - 1.0)) < 1e-12
+    # a batch takes the GEMM route for 64 right-hand sides: staircase bounds per tile of the GEMM
+    w = pkg.workloads.make("darcy64")
+    vals = np.tile(w.Q.data, (32, 1))
+    Fb = pkg.TridiagonalCholeskyFactor(batch=32).factor(w.Q, w.n_blocks, values=vals)
+    Bm = np.random.default_rng(3).standard_normal((32, 64, w.n))
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    for mode, fo in ((pkg._cabi.SOLVE_FULL, O.ldiv), (pkg._cabi.SOLVE_FORWARD, O.forward_solve), (pkg._cabi.SOLVE_BACKWARD, O.backward_solve)):
+        Y = Fb.solve_batch(Bm, mode)
+        assert rel(Y[5].T, fo(Fo, Bm[5].T)) < solve_tol(w)
+
+
+def test_without_the_l_blocks(pkg):
+    """gmrf_bt_set_keep_l(h, 0): the triangular blocks live in a one-block work buffer; solves, samples,
+    variances and the log-determinant are bitwise those of a handle that keeps them; F.chos raises."""
+    w = pkg.workloads.make("darcy64")
+    F1 = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    F0 = pkg.TridiagonalCholeskyFactor()
+    F0.set_keep_l(False)
+    F0.factor(w.Q, w.n_blocks)
+    assert np.array_equal(pkg.ldiv(F0, w.rhs), pkg.ldiv(F1, w.rhs))
+    assert np.array_equal(F0.sample(8, seed=3), F1.sample(8, seed=3))
+    assert np.array_equal(F0.marginal_var("exact"), F1.marginal_var("exact"))
+    assert F0.logdet() == F1.logdet()
+    assert np.array_equal(F0.Cs[3], F1.Cs[3])
+    with pytest.raises(pkg.GmrfError) as e:
+        F0.chos[0]
+    assert e.value.status == pkg._cabi.ERR_NO_FACTOR
+    with pytest.raises(pkg.GmrfError):
+        F0.export_factor()
+    assert F0.stats()["factor_bytes"] < 0.6 * F1.stats()["factor_bytes"]
+    # a batch, re-factored with new values
+    vals = np.stack([w.Q.data, 2.0 * w.Q.data])
+    Fb = pkg.TridiagonalCholeskyFactor(batch=2)
+    Fb.set_keep_l(False)
+    Fb.factor(w.Q, w.n_blocks, values=vals)
+    Fb.select_problem(1)
+    assert abs(Fb.logdet() - (F1.logdet() + w.n * np.log(2.0))) < 1e-10 * abs(F1.logdet())
+    F0.set_keep_l(True)                               # back: the next factorisation keeps them again
+    F0.factor(w.Q, w.n_blocks)
+    assert np.array_equal(F0.chos[2], F1.chos[2])
+
+
+def test_external_storage_with_a_batch_and_refresh(pkg, lib):
+    """Caller-owned factor storage (torch tensors) for a BATCH of problems: sizes scale with the batch
+    (gmrf_bt_storage_bytes), a mismatching batch is refused, nothing is written past the buffers
+    (guard words), and attaching storage drops whatever the handle had factored."""
+    import ctypes as C
+    import torch
+    w = pkg.workloads.make("darcy32")
+    B = 3
+    vals = np.stack([w.Q.data * (1.0 + p) for p in range(B)])
+    rhs = np.stack([w.rhs] * B)
+    F = pkg.TridiagonalCholeskyFactor(batch=B)
+    F.factor(w.Q, w.n_blocks, values=vals)
+    ref = F.solve_batch(rhs[:, None, :])
+    bl, bc, bi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    pkg._cabi.check(lib.gmrf_bt_storage_bytes(w.n, w.n_blocks, B, C.byref(bl), C.byref(bc), C.byref(bi)))
+    guard = 1024
+    bufs = [torch.full((b.value // 8 + guard,), 777.0, dtype=torch.float64, device="cuda") for b in (bl, bc, bi)]
+    assert lib.gmrf_bt_set_storage(F._h, w.n, w.n_blocks, 1, *[pkg._cabi.ptr(b) for b in bufs]) == pkg._cabi.ERR_BAD_SHAPE
+    pkg._cabi.check(lib.gmrf_bt_set_storage(F._h, w.n, w.n_blocks, B, *[pkg._cabi.ptr(b) for b in bufs]))
+    with pytest.raises(pkg.GmrfError) as e:           # the old factor is gone with the old buffers
+        F.solve_batch(rhs[:, None, :])
+    assert e.value.status == pkg._cabi.ERR_NO_FACTOR
+    F.factor(w.Q, w.n_blocks, values=vals)
+    assert np.array_equal(F.solve_batch(rhs[:, None, :]), ref)
+    for b in bufs:
+        assert bool((b[-guard:] == 777.0).all())
+    F.select_problem(2)
+    Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+    assert np.max(np.abs(np.tril(F.chos[1]) - np.sqrt(3.0) * Fo.chos[1])) / np.max(np.abs(Fo.chos[1])) < 1e-11
+
+
+def test_factor_moves_between_handles_with_its_layout(pkg):
+    """What a rank that receives the factor by broadcast does: adopt the root's layout record, fill the
+    Linv and C buffers (device copies here), commit -- into a handle that had analysed a DIFFERENT
+    coupling pattern before.  And the import of a factor image into such a handle."""
+    wa = pkg.workloads.make("darcy32")                             # stencil coupling: window + staircase
+    wb = pkg.workloads.random_block_tridiagonal(wa.n_blocks, wa.block_size, seed=5, density=0.05)   # scattered coupling: dense window
+    assert wb.n == wa.n
+    Fa = pkg.tridiagonal_cholesky(wa.Q, wa.n_blocks)               # analysed pattern a ...
+    Fb = pkg.tridiagonal_cholesky(wb.Q, wb.n_blocks)
+    xb = pkg.ldiv(Fb, wb.rhs)
+    assert list(Fa.get_layout()[:2]) != list(Fb.get_layout()[:2])
+    # ... then receives factor b: layout, buffers, commit
+    Fa.adopt_layout(wb.n, wb.n_blocks, Fb.get_layout())
+    for kind in (pkg._cabi.BLOCK_LINV, pkg._cabi.BLOCK_C):
+        (src, nb), (dst, nd) = Fb.factor_buffer(kind), Fa.factor_buffer(kind)
+        assert nb == nd
+        _hip_memcpy_d2d(dst, src, nb)
+    Fa.adopt_commit(False)
+    assert np.array_equal(pkg.ldiv(Fa, wb.rhs), xb)
+    assert np.array_equal(Fa.sample(4, seed=2), Fb.sample(4, seed=2))
+    assert np.array_equal(Fa.marginal_var("exact"), Fb.marginal_var("exact"))     # sweeps and variances see the same C
+    with pytest.raises(pkg.GmrfError):
+        Fa.chos[0]                                                  # the L blocks did not travel
+    with pytest.raises(pkg.GmrfError):
+        Fa.refactor(wa.Q.data)                                      # pattern a no longer describes this handle
+    # import of a dense image into a handle that analysed pattern a (window + staircase)
+    Fc = pkg.tridiagonal_cholesky(wa.Q, wa.n_blocks)
+    Fc.import_factor(Fb.export_factor())
+    assert np.array_equal(pkg.ldiv(Fc, wb.rhs), xb)
+    assert np.array_equal(Fc.marginal_var("exact"), Fb.marginal_var("exact"))
+    assert list(Fc.get_layout()[:2]) == [0, 64 * ((wb.block_size + 63) // 64)]
+    Fc.factor(wa.Q, wa.n_blocks)                                    # and back to its own pattern
+    assert np.array_equal(pkg.ldiv(Fc, wa.rhs), pkg.ldiv(pkg.tridiagonal_cholesky(wa.Q, wa.n_blocks), wa.rhs))
+
+
+def test_spmm_node_major_lds_tiles(pkg):
+    """K6 with node-major right-hand sides (the k values of a node contiguous): the LDS-tiled kernel
+    (tile plan: distinct columns per 64-row tile, 16-bit local indices; X rows staged in LDS once per
+    tile) for even k, the plain node-major kernel for odd k and for tiles beyond the LDS image;
+    fp64 and fp32 values; against SciPy and against the column-major kernel."""
+    import torch
+    w = pkg.workloads.make("darcy64")
+    Qr = w.Q.tocsr()
+    S64, S32 = pkg.CsrMatrix(Qr), pkg.CsrMatrix(Qr, values_f32=True)
+    Q32 = Qr.copy(); Q32.data = Q32.data.astype(np.float32).astype(np.float64)
+    rng = np.random.default_rng(4)
+    for k in (2, 16, 50, 64, 70, 5):
+        X = rng.standard_normal((w.n, k))                       # C-contiguous = node-major
+        assert rel(S64 @ X, Qr @ X) < 1e-14
+        assert rel(S32 @ X, Q32 @ X) < 1e-14
+        Xd = torch.from_numpy(X).cuda()
+        Yd = S64 @ Xd
+        assert Yd.is_cuda and Yd.shape == (w.n, k) and np.array_equal(Yd.cpu().numpy(), S64 @ X)
+        assert rel(S64 @ np.asfortranarray(X), Qr @ X) < 1e-14   # column-major operand: the lane-group kernel
+    # every right-hand side of the tiled kernel sums its row in entry order, like the one-vector kernel
+    X = rng.standard_normal((w.n, 16))
+    Y = S64 @ X
+    assert np.array_equal(Y[:, 3], S64 @ np.ascontiguousarray(X[:, 3]))
+    # ragged: empty rows, a row count that is no multiple of the tile, rectangular, a tile with too many
+    # distinct columns (falls back to the plain node-major kernel), a dense-ish matrix beyond the entry cap
+    A = sp.random(1000, 700, density=0.01, random_state=rng, data_rvs=rng.standard_normal).tolil()
+    A[5, :] = 0.0; A[999, :] = 0.0
+    A = A.tocsr(); A.eliminate_zeros()
+    Xa = rng.standard_normal((700, 8))
+    assert rel(pkg.CsrMatrix(A) @ Xa, A @ Xa) < 1e-14
+    D = sp.random(200, 300, density=0.5, random_state=rng, data_rvs=rng.standard_normal).tocsr()
+    Xd2 = rng.standard_normal((300, 4))
+    assert rel(pkg.CsrMatrix(D) @ Xd2, D @ Xd2) < 1e-13
+    # the banded FEM case keeps the plan: a 1-D chain with 3 couplings per row
+    T = sp.diags([1.0, -2.5, 1.0], [-1, 0, 1], shape=(5000, 5000)).tocsr()
+    Xt = rng.standard_normal((5000, 32))
+    assert rel(pkg.CsrMatrix(T) @ Xt, T @ Xt) < 1e-14

@@ -41,11 +41,14 @@ def test_no_gpu_means_loud_failure_not_fallback(pkg, lib):
 
 def test_storage_size_query_needs_no_gpu(pkg, lib):
     a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-    assert lib.gmrf_bt_storage_bytes(65536, 64, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert lib.gmrf_bt_storage_bytes(65536, 64, 1, C.byref(a), C.byref(b), C.byref(c)) == 0
     assert a.value == 64 * 1024 * 1024 * 8 and b.value == 63 * 1024 * 1024 * 8 and c.value == a.value
-    assert lib.gmrf_bt_storage_bytes(600, 2, C.byref(a), C.byref(b), C.byref(c)) == 0
+    assert lib.gmrf_bt_storage_bytes(65536, 64, 3, C.byref(a), C.byref(b), C.byref(c)) == 0      # a batch scales every array
+    assert a.value == 3 * 64 * 1024 * 1024 * 8 and b.value == 3 * 63 * 1024 * 1024 * 8
+    assert lib.gmrf_bt_storage_bytes(600, 2, 1, C.byref(a), C.byref(b), C.byref(c)) == 0
     assert a.value == 2 * 512 * 512 * 8                            # 300 -> padded to 64 * 8 = 512
-    assert lib.gmrf_bt_storage_bytes(10, 3, C.byref(a), C.byref(b), C.byref(c)) == pkg._cabi.ERR_BAD_SHAPE
+    assert lib.gmrf_bt_storage_bytes(10, 3, 1, C.byref(a), C.byref(b), C.byref(c)) == pkg._cabi.ERR_BAD_SHAPE
+    assert lib.gmrf_bt_storage_bytes(64, 1, 0, C.byref(a), C.byref(b), C.byref(c)) == pkg._cabi.ERR_BAD_SHAPE
 
 
 def test_argument_validation_in_python_layer(pkg):

@@ -13,7 +13,7 @@ for spec in (sys.argv[2] if len(sys.argv) > 2 else "1x8,2x4,2x8,4x4").split(",")
     for t in range(T):
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
-            eng = post.HipEngine(pkg, w, batch=B)
+            eng = post.HipEngine(pkg, w, batch=B, keep_l=os.environ.get('GMRF_KEEP_L', '1') != '0')
             job = post.ShardedPosterior(eng, k_samples=64, replicate_factor=True)
             if os.environ.get('GMRF_EAGER_FLAGS'): eng.F.set_eager(int(os.environ['GMRF_EAGER_FLAGS']))
             job.prepare()
