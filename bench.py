@@ -1,31 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- GMRF posterior solves/sec (mean + samples) on the 256x256 Darcy posterior.
 
-One step = one pass of the hot path over one batch of synthetic input: B independent 256^2
-Darcy posteriors per GPU (same mesh and sparsity pattern, B coefficient fields -- the per-problem
-loop of scripts/darcy/solve_darcy_gmrf-fem.jl:176-198), each one: numeric factorisation of
-Q_post (values already in HBM; the pattern is analysed once before the timed region, like the
-reference re-uses its permutation, :166-174), the posterior mean (forward + backward sweep) and
-64 posterior samples (backward sweep of 64 right-hand sides).  The B problems advance in lock
-step (problem = one more grid dimension of every kernel): the factorisation is a chain of
-latency-bound launches that fills <= 121 of the 256 CUs, a batch fills the rest.
-value = n_gpus * B * (1 + 64) * steps / time.
+N = 1 (the BASELINE metric config C3).  One step = one pass of the hot path over one batch of
+synthetic input: T x B independent 256^2 Darcy posteriors (same mesh and sparsity pattern, different
+coefficient fields -- the per-problem loop of scripts/darcy/solve_darcy_gmrf-fem.jl:176-198), each
+one: numeric factorisation of Q_post (values already in HBM; the pattern is analysed once before
+the timed region, like the reference re-uses its permutation, :166-174), the posterior mean (forward
++ backward sweep) and 64 posterior samples (backward sweep of 64 right-hand sides).  B problems
+advance in lock step on one handle (problem = one more grid dimension of every kernel); T handles
+run on T HIP streams driven by T host threads (the latency-bound launches of one chain leave CUs to
+the others).  value = T * B * (1 + 64) * steps / time.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU).  Headline = the north-star split:
+ONE factor shared by all ranks -- rank 0 factors a batch of posteriors block-range by block-range,
+every finished range of Linv / C blocks is broadcast over RCCL (the library's own communicator,
+gmrf_comm_*; torch.distributed if that cannot be set up) while the next range is being factored --
+and the samples sharded: every rank takes the means and draws ITS OWN 64 samples per posterior.
+value = B_shared * (1 + 64 N) * steps / time.  Beside it, in the same run: the independent-problems
+mode of the N = 1 line (no data-path collective) and BASELINE config C4 (elliptic 512^2, 256 samples
+sharded over the ranks).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
-
-N > 1, default (--mode problems): every rank handles its own batch of problems, no data-path
-collective (weak scaling).  --mode shared-factor: ONE problem; rank 0 factors and broadcasts the
-factor block-range by block-range over RCCL while factoring the next range; every rank draws
-its own 64 samples of the shared posterior.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -50,10 +56,18 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
 }
 
 
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
+                              timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
 def cpu_sparse_direct(w, k_samples: int):
     """Secondary CPU comparator: a general sparse direct solver on the same posterior
     precision -- what the reference's scripts really call (CHOLMOD there; SuperLU via SciPy here,
-    CHOLMOD bindings are not installed).  1 factorisation + (1 + k) solves, single thread."""
+    CHOLMOD bindings are not installed).  1 factorisation + (1 + k) solves, single thread, single shot."""
     import numpy as np
     import scipy.sparse.linalg as spla
     Z = np.random.default_rng(0).standard_normal((w.n, k_samples))
@@ -64,32 +78,150 @@ def cpu_sparse_direct(w, k_samples: int):
     lu.solve(Z)
     t2 = time.perf_counter()
     return {"value": (1 + k_samples) / (t2 - t0), "unit": "solves/s", "cores": 1,
-            "kind": "scipy.sparse.linalg.splu (SuperLU, MMD_AT_PLUS_A, symmetric mode)",
+            "kind": "scipy.sparse.linalg.splu (SuperLU, MMD_AT_PLUS_A, symmetric mode), single shot",
             "sample": f"1 factorisation {t1 - t0:.2f} s + {1 + k_samples} solves {t2 - t1:.2f} s"}
 
 
-def cpu_baseline(w, k_samples: int):
-    """The oracle (LAPACK-backed NumPy/SciPy restatement of the reference algorithm) timed on
-    this box's host cores on ONE full job of the same workload: factor + mean + k samples."""
+def cpu_baseline(w, k_samples: int, sample_blocks: int = 8):
+    """The oracle (LAPACK-backed NumPy/SciPy restatement of the reference algorithm) timed on this box's
+    host cores on a BOUNDED sample of the workload: the leading `sample_blocks` blocks of the chain
+    (same block size, same arithmetic per block: factor + mean + k samples), scaled to the full chain by
+    n_blocks / sample_blocks.  Protocol of SURVEY 8d: thread-count sweep (1 warm-up + 2 timed runs each),
+    then 1 warm-up + median of 5 at the best count."""
     import numpy as np
     from oracle import bt_oracle as O
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    Z = np.random.default_rng(0).standard_normal((w.n, k_samples))
+    from threadpoolctl import threadpool_limits
+    nb = min(sample_blocks, w.n_blocks)
+    ns = nb * w.block_size
+    Qs = w.Q.tocsr()[:ns, :ns].tocsc()
+    rhs = w.rhs[:ns]
+    Z = np.random.default_rng(0).standard_normal((ns, k_samples))
+
+    def job():
+        t0 = time.perf_counter()
+        F = O.tridiagonal_cholesky(Qs, nb)
+        t1 = time.perf_counter()
+        mu = O.ldiv(F, rhs)
+        X = O.sample(F, mu, Z)
+        return time.perf_counter() - t0, t1 - t0, (mu, X)
+
+    ncpu = os.cpu_count() or 1
+    counts = sorted({c for c in (4, 8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    sweep = {}
+    for c in counts:
+        with threadpool_limits(limits=c):
+            job()
+            sweep[c] = min(job()[0] for _ in range(2))
+    best = min(sweep, key=sweep.get)
+    with threadpool_limits(limits=best):
+        job()
+        runs = [job() for _ in range(5)]
+    runs.sort(key=lambda r: r[0])
+    t_med, t_fac, res = runs[2]
+    scale = w.n_blocks / nb
+    return {"value": (1 + k_samples) / (t_med * scale), "unit": "solves/s", "cores": int(best), "kind": "port",
+            "sample": f"leading {nb} of {w.n_blocks} blocks of {w.name} (n={ns}, block size {w.block_size}): factor + mean + "
+                      f"{k_samples} samples, median of 5 after a warm-up = {t_med:.3f} s (factor {t_fac:.3f} s), scaled x{scale:g}; "
+                      f"SciPy/OpenBLAS with {best} threads (sweep, best of 2: "
+                      + ", ".join(f"{c}: {v:.3f} s" for c, v in sweep.items()) + ")",
+            }, (Qs, nb, rhs, Z, res)
+
+
+class ProblemsJob:
+    """T handles x batch B of independent posteriors on T streams / host threads (no collective)."""
+
+    def __init__(self, pkg, post, w, torch, local, config, batch, n_streams, samples, rank, keep_l):
+        import numpy as np
+        self.torch, self.samples, self.batch, self.n_streams = torch, samples, batch, n_streams
+        total = batch * n_streams
+        vals, rhss = [w.Q.data], [w.rhs]
+        for p in range(1, min(total, 8)):            # coefficient fields on the same mesh: same pattern, different values
+            same = False
+            if config.startswith("darcy"):
+                wp = pkg.workloads.darcy(int(config[5:]), seed=523802340 + 1000 * rank + p)
+                same = wp.Q.nnz == w.Q.nnz and np.array_equal(wp.Q.indices, w.Q.indices)
+            if same:
+                vals.append(wp.Q.data); rhss.append(wp.rhs)
+            else:
+                vals.append(w.Q.data * (1.0 + 0.01 * p)); rhss.append(w.rhs)
+        self.jobs = []
+        for t in range(n_streams):
+            st_t = torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream()
+            idx = [(t * batch + p) % len(vals) for p in range(batch)]
+            with torch.cuda.stream(st_t):
+                e_t = post.HipEngine(pkg, w, device_index=local, batch=batch, values=np.stack([vals[i] for i in idx]),
+                                     rhs=np.stack([rhss[i] for i in idx]), keep_l=keep_l)
+                j_t = post.ShardedPosterior(e_t, k_samples=samples, replicate_factor=True)
+                j_t.prepare()
+            self.jobs.append((st_t, e_t, j_t))
+        self.eng, self.job = self.jobs[0][1], self.jobs[0][2]
+
+    def solves_per_step(self):
+        return self.n_streams * self.batch * (1 + self.samples)
+
+    def run(self, first, count):
+        torch = self.torch
+
+        def worker(st_t, j_t):
+            with torch.cuda.stream(st_t):
+                for s in range(count):
+                    j_t.step(first + s)
+                st_t.synchronize()
+        if len(self.jobs) == 1:
+            worker(self.jobs[0][0], self.jobs[0][2])
+            return
+        ths = [threading.Thread(target=worker, args=(st_t, j_t)) for st_t, _, j_t in self.jobs]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+
+    def close(self):
+        for _, e, _ in self.jobs:
+            e.F.close()
+        self.jobs = []
+        self.torch.cuda.empty_cache()
+
+
+def timed(run, sync, dist, torch, first, steps):
+    sync()
     t0 = time.perf_counter()
-    F = O.tridiagonal_cholesky(w.Q, w.n_blocks)
-    t1 = time.perf_counter()
-    mu = O.ldiv(F, w.rhs)
-    X = O.sample(F, mu, Z)
-    t2 = time.perf_counter()
-    total = t2 - t0
-    return {"value": (1 + k_samples) / total, "unit": "solves/s", "cores": int(cores), "kind": "port",
-            "sample": f"1 full job of {w.name} (n={w.n}, {w.n_blocks} blocks of {w.block_size}): factor "
-                      f"{t1 - t0:.2f} s + mean and {k_samples} samples {t2 - t1:.2f} s, SciPy/OpenBLAS",
-            "factor_s": t1 - t0, "sweeps_s": t2 - t1}, (mu, X, Z)
+    run(first, steps)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def spmm_roofline(pkg, torch):
+    """K6 on the 31 M-entry precision matrix of BASELINE config C5 (burgers 4096 x 512): k = 1 (LDS-staged row
+    tiles) and k = 64 node-major (LDS-tiled SpMM), fp64 and fp32 values; device-resident operands, HIP events on
+    the stream the kernels run on.  bytes = nnz (vbytes + 4) + 8 (n + 1) + 16 n k."""
+    w = pkg.workloads.make("burgers4096x512")
+    out = {"matrix": f"{w.name}: n={w.n}, nnz={w.Q.nnz}", "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "cases": {}}
+    st = torch.cuda.current_stream()
+    for f32 in (False, True):
+        S = pkg.CsrMatrix(w.Q, values_f32=f32, stream=st.cuda_stream)
+        for k in (1, 64):
+            X = torch.randn(w.n, dtype=torch.float64, device="cuda") if k == 1 else torch.randn(w.n, k, dtype=torch.float64, device="cuda")
+            for _ in range(3):
+                S @ X
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record(st)
+            for _ in range(reps):
+                S @ X
+            e1.record(st)
+            e1.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            b = w.Q.nnz * ((4 if f32 else 8) + 4) + 8 * (w.n + 1) + 16 * w.n * k
+            out["cases"][f"{'fp32' if f32 else 'fp64'}_k{k}"] = {"us": us, "achieved": b / us / 1e3, "frac": b / us / 1e3 / PEAK_HBM_GBPS,
+                                                                  "algorithmic_bytes": b}
+        del S
+    return out
 
 
 def main():
@@ -100,18 +232,27 @@ def main():
     ap.add_argument("--config", default="darcy256")
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--batch", type=int, default=32, help="independent problems per handle and step")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent batched handles per GPU, each on its own HIP stream and host thread")
-    ap.add_argument("--mode", choices=["problems", "shared-factor"], default="problems")
+    ap.add_argument("--mode", choices=["auto", "problems", "shared-factor"], default="auto",
+                    help="auto: problems on one GPU, shared-factor on several")
+    ap.add_argument("--shared-batch", type=int, default=8, help="posteriors per step whose factor is shared (N > 1)")
     ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
+    ap.add_argument("--keep-l", action="store_true", help="retain the L blocks (F.chos); default: only Linv and C are stored")
+    ap.add_argument("--transport", choices=["auto", "cabi", "torch"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-problem", action="store_true",
                     help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
+    ap.add_argument("--no-spmm", action="store_true", help="skip the K6 roofline leg (burgers4096x512 matrix)")
+    ap.add_argument("--no-side-legs", action="store_true", help="N > 1: skip the problems-mode and C4 legs")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import __graft_entry__ as g
     pkg = g.load_package()
+    from importlib import import_module
+    post = import_module(g.PKG_NAME + ".posterior")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -120,7 +261,8 @@ def main():
     # Rehearsal of the N > 1 control flow on a one-GPU box: GMRF_BENCH_BACKEND=gloo with
     # GMRF_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 (gloo moves CUDA tensors through the host).
     backend = os.environ.get("GMRF_BENCH_BACKEND", "nccl")
-    if os.environ.get("GMRF_BENCH_ONE_DEVICE") == "1" and backend == "gloo":
+    one_device = os.environ.get("GMRF_BENCH_ONE_DEVICE") == "1" and backend == "gloo"
+    if one_device:
         local = 0
     if world > 1:
         import torch.distributed as dist
@@ -130,40 +272,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
-
-    import numpy as np
-    w = pkg.workloads.make(args.config)
-    from importlib import import_module
-    post = import_module(g.PKG_NAME + ".posterior")
-    import threading
-    shared = (args.mode == "shared-factor" and world > 1)
-    batch = 1 if shared else args.batch
-    n_streams = 1 if shared else max(1, args.streams)
-    # coefficient fields on the same mesh: same pattern, different values
-    total_problems = batch * n_streams
-    vals, rhss = [w.Q.data], [w.rhs]
-    for p in range(1, min(total_problems, 8)):
-        if args.config.startswith("darcy"):
-            wp = pkg.workloads.darcy(int(args.config[5:]), seed=523802340 + 1000 * rank + p)
-            same = wp.Q.nnz == w.Q.nnz and np.array_equal(wp.Q.indices, w.Q.indices)
-        else:
-            same = False
-        if same:
-            vals.append(wp.Q.data); rhss.append(wp.rhs)
-        else:
-            vals.append(w.Q.data * (1.0 + 0.01 * p)); rhss.append(w.rhs)
-    jobs = []
-    for t in range(n_streams):
-        st_t = torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream()
-        idx = [(t * batch + p) % len(vals) for p in range(batch)]
-        with torch.cuda.stream(st_t):
-            e_t = post.HipEngine(pkg, w, device_index=local, batch=batch, values=np.stack([vals[i] for i in idx]),
-                                 rhs=np.stack([rhss[i] for i in idx]))
-            j_t = post.ShardedPosterior(e_t, dist=dist if shared else None, rank=rank, world=world if shared else 1,
-                                        k_samples=args.samples, group=args.group, replicate_factor=not shared)
-            j_t.prepare()
-        jobs.append((st_t, e_t, j_t))
-    eng, job = jobs[0][1], jobs[0][2]
+    mode = args.mode if args.mode != "auto" else ("shared-factor" if world > 1 else "problems")
+    shared = mode == "shared-factor" and world > 1
+    keep_l = bool(args.keep_l)
 
     def sync():
         torch.cuda.synchronize()
@@ -171,135 +282,224 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def run_steps(first, count):
-        """`count` steps on every handle; with several handles each one is driven by its own host
-        thread on its own stream (the C ABI releases the GIL) so that their launch chains overlap."""
-        def worker(st_t, j_t):
-            with torch.cuda.stream(st_t):
-                for s in range(count):
-                    j_t.step(first + s)
-                st_t.synchronize()
-        if len(jobs) == 1:
-            worker(jobs[0][0], jobs[0][2])
-            return
-        ths = [threading.Thread(target=worker, args=(st_t, j_t)) for st_t, _, j_t in jobs]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-
-    run_steps(0, args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    run_steps(args.warmup, args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
+    w = pkg.workloads.make(args.config)
     out = None
+    extra = {}
+
+    # ------------------------------------------------------------------ transport of a shared factor
+    comm, transport = None, "torch"
+    if shared:
+        want = args.transport
+        if want in ("auto", "cabi") and not one_device:
+            try:
+                box = [pkg.api.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = pkg.api.Comm(local, rank, world, box[0])
+                transport = "cabi"
+            except Exception as e:      # noqa: BLE001 -- any failure: RCCL through torch.distributed instead
+                extra["cabi_comm_error"] = repr(e)[:300]
+                comm, transport = None, "torch"
+            ok = torch.tensor([1 if transport == "cabi" else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm, transport = None, "torch"
+
+    def shared_job(wl, batch, k_per_rank, values=None, rhs=None):
+        eng = post.HipEngine(pkg, wl, device_index=local, batch=batch, values=values, rhs=rhs, keep_l=keep_l,
+                             transport=transport, comm=comm)
+        job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group)
+        job.prepare()
+        return eng, job
+
+    if shared:
+        B = max(1, args.shared_batch)
+        vals = np.stack([w.Q.data * (1.0 + 0.01 * p) for p in range(B)])
+        rhs = np.stack([w.rhs] * B)
+        eng, job = shared_job(w, B, args.samples, vals, rhs)
+
+        def run(first, count):
+            for s in range(count):
+                job.step(first + s)
+        run(0, args.warmup)
+        elapsed = timed(run, sync, dist, torch, args.warmup, args.steps)
+        per_step = job.solves_per_step()
+        workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored by rank 0, "
+                    f"Linv / C ranges of {args.group} blocks broadcast to {world} ranks beside the factorisation, every rank: "
+                    f"{B} mean(s) + {args.samples} samples per posterior")
+        sharding = f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), samples sharded by Philox sample id"
+    else:
+        pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
+        eng, job = pj.eng, pj.job
+        pj.run(0, args.warmup)
+        elapsed = timed(pj.run, sync, dist, torch, args.warmup, args.steps)
+        per_step = world * pj.solves_per_step()
+        workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; {pj.n_streams * pj.batch} independent "
+                    f"posterior(s) per GPU and step ({pj.n_streams} stream(s) x batch {pj.batch}), each factor + mean + {args.samples} samples")
+        sharding = "independent problems per rank, no data-path collective"
+
     if rank == 0:
-        per_step = job.solves_per_step() if shared else world * n_streams * batch * (1 + args.samples)
-        solves = per_step * args.steps
-        st = eng.F.stats()
         out = {
             "metric": "GMRF posterior solves/sec (mean+samples), 256^2 Darcy",
-            "value": solves / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
+            "value": per_step * args.steps / elapsed, "unit": "solves/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; "
-                                   f"{n_streams * batch} independent posterior(s) per GPU and step ({n_streams} stream(s) x "
-                                   f"batch {batch}), each factor + mean + {args.samples} samples",
-                       "problems_per_gpu_per_step": n_streams * batch, "streams": n_streams, "batch": batch,
-                       "samples_per_problem": args.samples,
-                       "sharding": "independent problems per rank, no data-path collective" if job.replicate
-                       else f"one shared factor, rccl broadcast in {args.group}-block ranges, samples sharded"},
+            "config": {"workload": workload, "mode": mode, "samples_per_problem_per_rank": args.samples, "sharding": sharding,
+                       "l_blocks_kept": keep_l},
         }
-    if rank == 0:
         free_b, total_b = torch.cuda.mem_get_info(local)
         out["hbm_used_gb"] = round((total_b - free_b) / 1e9, 1)
-    # ---- per-kernel roofline + parity + CPU baseline: rank 0, outside the timed region
+        out.update(extra)
+
+    # ------------------------------------------------------------------ N > 1: the other legs, same run
+    if shared and not args.no_side_legs:
+        # (a) the same job on ONE rank (no broadcast): what sharing the factor is compared with
+        side = {}
+        if rank == 0:
+            e1 = post.HipEngine(pkg, w, device_index=local, batch=eng.batch, values=eng.values_host, rhs=eng.rhs[:, 0, :].cpu().numpy(), keep_l=keep_l)
+            j1 = post.ShardedPosterior(e1, k_samples=args.samples, replicate_factor=True)
+            j1.prepare()
+            j1.step(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for s in range(3):
+                j1.step(1 + s)
+            torch.cuda.synchronize()
+            t1 = (time.perf_counter() - t0) / 3
+            side["one_rank_same_job"] = {"ms_per_step": 1e3 * t1, "value": e1.batch * (1 + args.samples) / t1,
+                                         "note": "rank 0 alone: factor + mean + 64 samples per posterior, no broadcast"}
+            e1.F.close()
+        eng.F.close()
+        sync()
+        # (b) C4: elliptic 512^2, 256 samples sharded over the ranks, one shared factor
+        try:
+            w4 = pkg.workloads.make("elliptic512")
+            k4 = max(1, 256 // world)
+            e4, j4 = shared_job(w4, 1, k4)
+
+            def run4(first, count):
+                for s in range(count):
+                    j4.step(first + s)
+            run4(0, 1)
+            el4 = timed(run4, sync, dist, torch, 1, 3)
+            if rank == 0:
+                side["c4_elliptic512"] = {"ms_per_job": 1e3 * el4 / 3, "value": (1 + k4 * world) * 3 / el4, "unit": "solves/s",
+                                          "samples_total": k4 * world, "samples_per_rank": k4,
+                                          "workload": f"{w4.name}: n={w4.n}, {w4.n_blocks} blocks x {w4.block_size}"}
+            e4.F.close()
+        except Exception as e:      # noqa: BLE001
+            if rank == 0:
+                side["c4_elliptic512"] = {"error": repr(e)[:300]}
+        sync()
+        # (c) independent problems per rank (the N = 1 line's mode): no data-path collective
+        pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
+        pj.run(0, 1)
+        steps_p = max(2, args.steps // 4)
+        elp = timed(pj.run, sync, dist, torch, 1, steps_p)
+        if rank == 0:
+            side["problems_mode"] = {"value": world * pj.solves_per_step() * steps_p / elp, "unit": "solves/s",
+                                     "ms_per_step": 1e3 * elp / steps_p, "steps": steps_p,
+                                     "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
+            out["side_legs"] = side
+        pj.close()
+
+    # ------------------------------------------------------------------ N = 1: per-kernel roofline + parity + CPU baseline
     if rank == 0 and world == 1:
-        import numpy as np
         eng.F.set_profiling(1)
-        with torch.cuda.stream(jobs[0][0]):
+        with torch.cuda.stream(pj.jobs[0][0]):
             job.step(10_000)
         torch.cuda.synchronize()
         st = eng.F.stats()
         eng.F.set_profiling(0)
         ms, work, cnt = st["kernel_ms"], st["kernel_work"], st["kernel_launches"]
-        # the kernel with the largest time; classes within 15 % of it count as tied and the first in
-        # KERNEL_CLASSES order is named, so that the roofline object does not flip between the two
-        # operand layouts of the same GEMM kernel from run to run
-        top = max(ms[c] for c in KERNEL_CLASSES)
-        dom = next(c for c in KERNEL_CLASSES if ms[c] >= 0.85 * top)
+        # dominant kernel = the class with the largest time in one instrumented step of one handle (HIP events on the
+        # handle's stream around every launch); both symbols of the 64 x 64 GEMM kernel are also reported together
+        dom = max(KERNEL_CLASSES, key=lambda c: ms[c])
         name, bound = KERNEL_CLASSES[dom]
         if bound == "mfma":
-            achieved = work[dom] / (ms[dom] * 1e-3) / 1e12
-            peak, unit = PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
+            achieved, peak, unit = work[dom] / (ms[dom] * 1e-3) / 1e12, PEAK_FP64_MFMA_TFLOPS, "TFLOP/s"
         else:
-            achieved = work[dom] / (ms[dom] * 1e-3) / 1e9
-            peak, unit = PEAK_HBM_GBPS, "GB/s"
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes of this workload
-        # (profiles/README.md); null when the profile has no row for it
+            achieved, peak, unit = work[dom] / (ms[dom] * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
         traffic, traffic_src = None, None
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
             key = next((k for k in prof["kernels"] if k.replace(" ", "").startswith(name.replace(" ", "").rstrip(">"))), None)
-            if key and w.name == "darcy256" and batch == 32:
+            if key and w.name == "darcy256" and eng.batch == prof.get("batch", 32):
                 traffic = prof["kernels"][key]["read_bytes_per_launch"] + prof["kernels"][key]["write_bytes_per_launch"]
-                traffic_src = "profiles/r01_hbm_traffic.json: " + key
+                traffic_src = (f"snapshot: profiles/r02_hbm_traffic.json ({key}; rocprofv3 --pmc passes taken at commit "
+                               f"{prof.get('head', '?')}, this run is {git_head()})")
         except Exception:
             pass
+        gemm_cls = [c for c in (0, 11) if ms[c] > 0]
+        tw = sum(work[c] for c in gemm_cls) / max(sum(ms[c] for c in gemm_cls), 1e-9) / 1e9 if gemm_cls else 0.0
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                            "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel": name,
-                           "launches_per_step": int(cnt[dom]), "avg_launch_us": 1e3 * ms[dom] / max(cnt[dom], 1)}
-        # the HBM-bound leg of the path (north_star: sweep HBM GB/s against the 8 TB/s roofline): the k = 1
-        # GEMV sweep kernels of the same instrumented step; bytes = the reference's dense L / C blocks
+                           "launches_per_step": int(cnt[dom]), "avg_launch_us": 1e3 * ms[dom] / max(cnt[dom], 1),
+                           "work": "executed flops (structurally skipped K ranges not counted)",
+                           "gemm_f64_mfma_both_symbols_time_weighted": {"achieved": tw, "frac": tw / PEAK_FP64_MFMA_TFLOPS,
+                                                                        "ms_per_step": sum(ms[c] for c in gemm_cls)}}
+        # the HBM-bound leg of the path (north_star: sweep HBM GB/s against the 8 TB/s roofline): the k = 1 GEMV
+        # sweep kernels of the same instrumented step, on the bytes they stream (Linv triangles + C inside its staircase)
         if ms[3] > 0:
             g3 = work[3] / (ms[3] * 1e-3) / 1e9
             out["roofline_sweep"] = {"bound": "hbm", "achieved": g3, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                      "frac": g3 / PEAK_HBM_GBPS, "kernel": "sweep_gemv_n / sweep_gemv_t",
                                      "launches_per_step": int(cnt[3]), "avg_launch_us": 1e3 * ms[3] / max(cnt[3], 1),
-                                     "note": "algorithmic bytes of the dense blocks (SURVEY 8d); the kernels read only the non-zero part of C"}
+                                     "bytes": "streamed: lower triangle of Linv_i, C_i inside its staircase window"}
         out["kernels"] = {KERNEL_CLASSES[c][0]: {"ms_per_step": ms[c], "launches": int(cnt[c]),
                                                   ("tflops" if KERNEL_CLASSES[c][1] == "mfma" else "gbps"):
                                                   (work[c] / (ms[c] * 1e-3) / (1e12 if KERNEL_CLASSES[c][1] == "mfma" else 1e9)) if ms[c] > 0 else 0.0}
                           for c in KERNEL_CLASSES}
-        # phase times of the un-instrumented path (whole batch)
+        executed = sum(work[c] for c in KERNEL_CLASSES if KERNEL_CLASSES[c][1] == "mfma")
+        # phase times of the un-instrumented path (whole batch of one handle)
         eng.F.refactor(eng.nz)
         mu = eng.mean()
         s1 = eng.F.stats()
-        Xs = eng.sample(args.samples, mu, 0x5EED, 0)
+        eng.sample(args.samples, mu, 0x5EED, 0)
         s2 = eng.F.stats()
         out["phases_ms"] = {"factor": s1["factor_ms"], "mean_2_sweeps": s1["solve_ms"], "samples_1_sweep": s2["sample_ms"]}
-        out["factor_tflops"] = st["factor_flops"] / (s1["factor_ms"] * 1e-3) / 1e12
-        out["sweep_k1_gbps"] = s1["sweep_bytes"] / (0.5 * s1["solve_ms"] * 1e-3) / 1e9
+        out["factor_tflops_lapack_count"] = st["factor_flops"] / (s1["factor_ms"] * 1e-3) / 1e12
+        out["whole_job_executed_tflops"] = executed * pj.n_streams / (1e-3 * out["ms_per_step"]) / 1e12
+        out["sweep_k1_gbps"] = {"reference_dense_blocks": s1["sweep_bytes"] / (0.5 * s1["solve_ms"] * 1e-3) / 1e9,
+                                "streamed": s1["sweep_bytes_streamed"] / (0.5 * s1["solve_ms"] * 1e-3) / 1e9}
+        out["factor_bytes_per_posterior_gb"] = s1["factor_bytes"] / eng.batch / 1e9
+        pj.close()
         if not args.no_single_problem:
-            # latency of ONE problem (batch 1) on the same GPU, for reference
-            F1 = pkg.TridiagonalCholeskyFactor(device=local, stream=eng.stream.cuda_stream).factor(w.Q, w.n_blocks)
-            nz1 = eng.nz[0].contiguous(); rhs1 = eng.rhs[0, 0].contiguous()
-            for _ in range(2):
+            # latency of ONE problem (batch 1) on the same GPU: what tridiagonal_cholesky(A, N) as the reference
+            # defines it (one matrix) delivers
+            F1 = pkg.TridiagonalCholeskyFactor(device=local, stream=torch.cuda.current_stream().cuda_stream).factor(w.Q, w.n_blocks)
+            nz1 = torch.from_numpy(w.Q.data).cuda(); rhs1 = torch.from_numpy(w.rhs).cuda()
+            lat, fms = [], []
+            for _ in range(4):
                 torch.cuda.synchronize(); t1 = time.perf_counter()
-                F1.refactor(nz1); mu1 = pkg.ldiv(F1, rhs1); X1 = F1.sample(args.samples, mean=mu1, seed=1, like=rhs1)
-                torch.cuda.synchronize(); lat = time.perf_counter() - t1
-            out["single_problem"] = {"latency_ms": 1e3 * lat, "solves_per_s": (1 + args.samples) / lat}
-            if not args.no_cpu_baseline:
-                base, (mu_o, X_o, Z) = cpu_baseline(w, args.samples)
-                out["cpu_baseline"] = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
-                out["speedup_vs_cpu"] = out["value"] / base["value"]
-                out["cpu_sparse_direct"] = cpu_sparse_direct(w, args.samples)
-                mu_h = mu1.cpu().numpy()
-                Xh = F1.sample(args.samples, mean=mu_o, z=Z)
-                cond_eps = 3.4e9 * 2.2e-16 if w.name == "darcy256" else None
-                out["parity"] = {"mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
-                                 "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o)),
-                                 "bound_0.1_cond_eps": 0.1 * cond_eps if cond_eps else None}
+                F1.refactor(nz1); mu1 = pkg.ldiv(F1, rhs1); F1.sample(args.samples, mean=mu1, seed=1, like=rhs1)
+                torch.cuda.synchronize(); lat.append(time.perf_counter() - t1)
+                fms.append(F1.stats()["factor_ms"])
+            lat1, f1 = min(lat[1:]), min(fms[1:])
+            out["single_problem"] = {"latency_ms": 1e3 * lat1, "solves_per_s": (1 + args.samples) / lat1, "factor_ms": f1,
+                                     "factor_tflops_lapack_count": F1.stats()["factor_flops"] / (f1 * 1e-3) / 1e12}
             F1.close()
+        if not args.no_spmm:
+            try:
+                out["roofline_spmm"] = spmm_roofline(pkg, torch)
+            except Exception as e:      # noqa: BLE001
+                out["roofline_spmm"] = {"error": repr(e)[:300]}
+        if not args.no_cpu_baseline:
+            base, (Qs, nbs, rhs_s, Z, (mu_o, X_o)) = cpu_baseline(w, args.samples)
+            out["cpu_baseline"] = base
+            out["speedup_vs_cpu"] = out["value"] / base["value"]
+            out["cpu_sparse_direct"] = cpu_sparse_direct(w, args.samples)
+            # parity of the HIP path on the CPU sample (the full-size oracle comparison lives in tests/test_gpu_parity.py)
+            Fs = pkg.tridiagonal_cholesky(Qs, nbs)
+            mu_h = pkg.ldiv(Fs, rhs_s)
+            Xh = Fs.sample(args.samples, mean=mu_o, z=Z)
+            out["parity"] = {"on": f"the CPU sample (leading {nbs} blocks)",
+                             "mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
+                             "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o))}
+            Fs.close()
     if rank == 0:
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

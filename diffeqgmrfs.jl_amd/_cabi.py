@@ -95,7 +95,7 @@ def load() -> C.CDLL:
         "gmrf_bt_factor_csc": [vp, i64, i64, vp, vp, vp, i32, P(i32)],
         "gmrf_bt_factor_blocks": [vp, i64, i64, vp, vp, i32, i32, P(i32)],
         "gmrf_bt_refactor_values": [vp, vp, P(i32)],
-        "gmrf_bt_solve": [vp, vp, vp, i64, i64, i32],
+        "gmrf_bt_solve": [vp, vp, vp, i64, i64, i64, i32],
         "gmrf_bt_sample": [vp, u64, i64, i64, vp, vp, vp, i64],
         "gmrf_bt_normals": [vp, u64, i64, i64, vp, i64],
         "gmrf_bt_marginal_var": [vp, i32, i64, u64, vp, vp],

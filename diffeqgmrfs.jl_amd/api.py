@@ -354,7 +354,7 @@ class TridiagonalCholeskyFactor:
         else:
             b = np.ascontiguousarray(b, dtype=np.float64)
             out = np.empty_like(b)
-        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(b), _cabi.ptr(out), k, n, mode))
+        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(b), _cabi.ptr(out), k, n, n, mode))
         return out
 
     def sample_batch(self, k: int, mean=None, seed: int = 0x5EED, first_id: int = 0, like=None):
@@ -447,7 +447,7 @@ class TridiagonalCholeskyFactor:
             store, view = _alloc_like(xa, self.N, k, one_d)
         else:
             store, view = out, out
-        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(xa), _cabi.ptr(store), k, ld, mode))
+        _cabi.check(self._lib.gmrf_bt_solve(self._h, _cabi.ptr(xa), _cabi.ptr(store), k, ld, self.N, mode))
         return view
 
     def get_block(self, kind: int, i: int) -> np.ndarray:

@@ -93,6 +93,7 @@ struct gmrf_csr {
     int32_t* d_ucols = nullptr;        // distinct columns of every tile, ascending
     uint16_t* d_lidx = nullptr;        // per entry: index of its column in the tile's list
     int64_t n_ucols = 0;
+    int plan_rows = 0, plan_ucap = 0, plan_ecap = 0;   // rows per tile, LDS capacities (distinct columns, entries)
 };
 
 // ------------------------------------------------------------------------------------ handle
@@ -1594,10 +1595,11 @@ gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c) {
     return GMRF_OK;
 }
 
-gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k, int64_t ld, int32_t mode) {
+gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k, int64_t ldb, int64_t ldy, int32_t mode) {
     if (!h || !b || !y) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "solve before factor"; return GMRF_ERR_NO_FACTOR; }
-    if (k <= 0 || ld < h->n || mode < 0 || mode > 2) return bad_shape("bad k / ld / mode");
+    if (k <= 0 || ldb < h->n || ldy < h->n || mode < 0 || mode > 2) return bad_shape("bad k / ldb / ldy / mode");
+    if (b == y && ldb != ldy) return bad_shape("in place (y == b) needs ldb == ldy");
     HIPCHK(hipSetDevice(h->device));
     if (h->B > 1 && k > KP_CHUNK) return bad_shape("with a batch of problems k is limited to 128 per call");
     const bool b_dev = is_device_ptr(b), y_dev = is_device_ptr(y);
@@ -1607,26 +1609,26 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
         const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
         const int kp = pad_k(kc);
         GCHK(ensure_panels(h, kp));
-        const double* bsrc = b + c0 * ld;
-        double* ydst = y + c0 * ld;
+        const double* bsrc = b + c0 * ldb;
+        double* ydst = y + c0 * ldy;
         const double* d_b = bsrc;
         if (!b_dev || !y_dev) GCHK(ensure_stage(h, (int64_t)kc * h->n * nb));
         if (!b_dev) {
-            HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), bsrc, ld * sizeof(double),
+            HIPCHK(hipMemcpy2DAsync(h->d_stage, h->n * sizeof(double), bsrc, ldb * sizeof(double),
                                     h->n * sizeof(double), kc * nb, hipMemcpyHostToDevice, h->stream));
             d_b = h->d_stage;
         }
-        GCHK(launch_pack(h, d_b, b_dev ? ld : h->n, kc, kp));
+        GCHK(launch_pack(h, d_b, b_dev ? ldb : h->n, kc, kp));
         HIPCHK(hipEventRecord(h->ev0, h->stream));
         GCHK(run_sweeps(h, mode, kp));
         HIPCHK(hipEventRecord(h->ev1, h->stream));
         const double* result = (mode == GMRF_SOLVE_FULL) ? h->d_P : h->d_Y;
         if (y_dev) {
-            GCHK(launch_unpack(h, result, ydst, ld, kc, nullptr));
+            GCHK(launch_unpack(h, result, ydst, ldy, kc, nullptr));
             HIPCHK(hipStreamSynchronize(h->stream));
         } else {
             GCHK(launch_unpack(h, result, h->d_stage, h->n, kc, nullptr));
-            HIPCHK(hipMemcpy2DAsync(ydst, ld * sizeof(double), h->d_stage, h->n * sizeof(double),
+            HIPCHK(hipMemcpy2DAsync(ydst, ldy * sizeof(double), h->d_stage, h->n * sizeof(double),
                                     h->n * sizeof(double), kc * nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
@@ -1885,39 +1887,54 @@ static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* 
 // arrays of the matrix are read back), like the symbolic phase of the factor.
 static gmrf_status spmm_plan(gmrf_csr* m) {
     if (m->plan_state != 0) return GMRF_OK;
-    const int64_t T = (m->n_rows + SPMM_ROWS - 1) / SPMM_ROWS;
     std::vector<int64_t> rp((size_t)m->n_rows + 1);
     std::vector<int32_t> ci((size_t)std::max<int64_t>(m->nnz, 1));
     HIPCHK(hipMemcpyAsync(rp.data(), m->d_rowptr, sizeof(int64_t) * (m->n_rows + 1), hipMemcpyDeviceToHost, m->stream));
     if (m->nnz > 0) HIPCHK(hipMemcpyAsync(ci.data(), m->d_colidx, sizeof(int32_t) * m->nnz, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    std::vector<int64_t> uptr((size_t)T + 1, 0);
+    std::vector<int64_t> uptr;
     std::vector<int32_t> ucols;
     std::vector<uint16_t> lidx((size_t)std::max<int64_t>(m->nnz, 1));
     std::vector<int32_t> tmp;
-    ucols.reserve((size_t)(m->nnz / 3 + 16));
-    for (int64_t tix = 0; tix < T; ++tix) {
-        const int64_t r0 = tix * SPMM_ROWS, r1 = std::min(m->n_rows, r0 + SPMM_ROWS);
-        const int64_t a = rp[r0], b = rp[r1];
-        if (b - a > SPMM_CAP) { m->plan_state = -1; return GMRF_OK; }
-        tmp.assign(ci.begin() + a, ci.begin() + b);
-        std::sort(tmp.begin(), tmp.end());
-        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-        if ((int64_t)tmp.size() > SPMM_UMAX) { m->plan_state = -1; return GMRF_OK; }
-        for (int64_t e = a; e < b; ++e)
-            lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), ci[(size_t)e]) - tmp.begin());
-        ucols.insert(ucols.end(), tmp.begin(), tmp.end());
-        uptr[(size_t)tix + 1] = (int64_t)ucols.size();
+    // the tallest tile whose LDS image (distinct rows of X for 16 right-hand sides + the entries) lets three
+    // workgroups share a CU; a matrix whose 16-row tiles do not fit keeps the plain kernel
+    const size_t lds_budget = 52 * 1024;
+    m->plan_state = -1;
+    for (int R : {64, 32, 16}) {
+        const int64_t T = (m->n_rows + R - 1) / R;
+        uptr.assign((size_t)T + 1, 0);
+        ucols.clear();
+        ucols.reserve((size_t)(m->nnz / 3 + 16));
+        int64_t umax = 0, emax = 0;
+        bool ok = true;
+        for (int64_t tix = 0; tix < T && ok; ++tix) {
+            const int64_t r0 = tix * R, r1 = std::min(m->n_rows, r0 + R);
+            const int64_t a = rp[r0], b = rp[r1];
+            tmp.assign(ci.begin() + a, ci.begin() + b);
+            std::sort(tmp.begin(), tmp.end());
+            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+            umax = std::max<int64_t>(umax, (int64_t)tmp.size()); emax = std::max(emax, b - a);
+            if ((int64_t)tmp.size() > 32 * SPMM_NG || b - a > 8192) { ok = false; break; }
+            for (int64_t e = a; e < b; ++e)
+                lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), ci[(size_t)e]) - tmp.begin());
+            ucols.insert(ucols.end(), tmp.begin(), tmp.end());
+            uptr[(size_t)tix + 1] = (int64_t)ucols.size();
+        }
+        if (!ok) continue;
+        const int ucap = (int)std::max<int64_t>(32, (umax + 31) / 32 * 32), ecap = (int)std::max<int64_t>(256, (emax + 255) / 256 * 256);
+        if (spmm_tile_lds_bytes(R, ucap, ecap) > lds_budget) continue;
+        m->plan_rows = R; m->plan_ucap = ucap; m->plan_ecap = ecap;
+        m->n_ucols = (int64_t)ucols.size();
+        HIPCHK(hipMalloc(&m->d_tile_uptr, sizeof(int64_t) * (T + 1)));
+        HIPCHK(hipMalloc(&m->d_ucols, sizeof(int32_t) * std::max<size_t>(ucols.size(), 1)));
+        HIPCHK(hipMalloc(&m->d_lidx, sizeof(uint16_t) * std::max<int64_t>(m->nnz, 1)));
+        HIPCHK(hipMemcpyAsync(m->d_tile_uptr, uptr.data(), sizeof(int64_t) * (T + 1), hipMemcpyHostToDevice, m->stream));
+        if (!ucols.empty()) HIPCHK(hipMemcpyAsync(m->d_ucols, ucols.data(), sizeof(int32_t) * ucols.size(), hipMemcpyHostToDevice, m->stream));
+        if (m->nnz > 0) HIPCHK(hipMemcpyAsync(m->d_lidx, lidx.data(), sizeof(uint16_t) * m->nnz, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        m->plan_state = 1;
+        break;
     }
-    m->n_ucols = (int64_t)ucols.size();
-    HIPCHK(hipMalloc(&m->d_tile_uptr, sizeof(int64_t) * (T + 1)));
-    HIPCHK(hipMalloc(&m->d_ucols, sizeof(int32_t) * std::max<size_t>(ucols.size(), 1)));
-    HIPCHK(hipMalloc(&m->d_lidx, sizeof(uint16_t) * std::max<int64_t>(m->nnz, 1)));
-    HIPCHK(hipMemcpyAsync(m->d_tile_uptr, uptr.data(), sizeof(int64_t) * (T + 1), hipMemcpyHostToDevice, m->stream));
-    if (!ucols.empty()) HIPCHK(hipMemcpyAsync(m->d_ucols, ucols.data(), sizeof(int32_t) * ucols.size(), hipMemcpyHostToDevice, m->stream));
-    if (m->nnz > 0) HIPCHK(hipMemcpyAsync(m->d_lidx, lidx.data(), sizeof(uint16_t) * m->nnz, hipMemcpyHostToDevice, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    m->plan_state = 1;
     return GMRF_OK;
 }
 
@@ -1927,12 +1944,14 @@ static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const dou
                                     int64_t ldy, int k, const double* vals_override = nullptr) {
     gmrf_csr* m = const_cast<gmrf_csr*>(S);
     GCHK(spmm_plan(m));
-    const bool aligned = (k % 2 == 0) && (ldx % 2 == 0) && (((uintptr_t)d_X) % 16 == 0);
+    const bool aligned = (k % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_X) % 16 == 0) && (((uintptr_t)d_Y) % 16 == 0);
     if (m->plan_state == 1 && aligned) {
-        const dim3 grid((unsigned)((S->n_rows + SPMM_ROWS - 1) / SPMM_ROWS));
-        if (vals_override) hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, vals_override, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
-        else if (S->d_vals32) hipLaunchKernelGGL(csr_spmm_tiles<float>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, S->d_vals32, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
-        else hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_lidx, S->d_vals, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k);
+        const int R = m->plan_rows, uc = m->plan_ucap, ec = m->plan_ecap;
+        const dim3 grid((unsigned)((S->n_rows + R - 1) / R));
+        const size_t lds = spmm_tile_lds_bytes(R, uc, ec);
+        if (vals_override) hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, vals_override, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
+        else if (S->d_vals32) hipLaunchKernelGGL(csr_spmm_tiles<float>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, S->d_vals32, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
+        else hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, S->d_vals, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
     } else {
         const dim3 grid((unsigned)((S->n_rows + 15) / 16));
         if (vals_override) hipLaunchKernelGGL(csr_spmm_rows<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_colidx, vals_override, S->n_rows, d_X, ldx, d_Y, ldy, k);

@@ -300,93 +300,130 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
 // SpMM with LDS-staged row tiles for right-hand sides stored NODE-MAJOR ("interleaved": X[col][rhs],
 // row stride ldx >= k -- the k values one gathered column index needs are contiguous):
 //     Y[r][:] = sum_e vals[e] * X[col[e]][:]
-// A workgroup owns SPMM_ROWS consecutive rows.  The host-side plan (built once per matrix, like the
-// symbolic phase of the factor) lists the DISTINCT columns of every tile and replaces each entry's
-// column by its 16-bit index into that list.  Per tile: (1) the entries (local index, value) are
-// staged in LDS with coalesced independent loads; (2) per chunk of 16 right-hand sides the distinct
-// rows of X are gathered ONCE into LDS -- a FEM / finite-difference tile of 64 rows touches ~3.4
-// rows of X per output row instead of ~15, and each gathered piece is one full 128-byte line;
-// (3) lane (row, rhs) walks its row's entries in CSR order (fixed summation order, the same as
-// csr_spmv_tiles) reading values, indices and X from LDS; (4) the 64 x 16 results leave as 128-byte
-// pieces.  fp32 values (config 5) are widened when staged; accumulation is fp64 either way.
-constexpr int SPMM_ROWS = 64;
-constexpr int SPMM_CAP = 2048;            // entries per tile
-constexpr int SPMM_UMAX = 288;            // distinct columns per tile
+// A workgroup owns R consecutive rows (R = 64, 32 or 16, chosen by the host-side plan so that three
+// workgroups fit a CU's LDS).  The plan (built once per matrix, like the symbolic phase of the
+// factor) lists the DISTINCT columns of every tile and replaces each entry's column by its 16-bit
+// index into that list.  Per tile: (1) the entries (local index, value) are staged in LDS with
+// coalesced independent loads; (2) per chunk of 16 right-hand sides the distinct rows of X are
+// gathered ONCE -- a FEM / finite-difference tile of 64 rows touches ~3.4 rows of X per output row
+// instead of ~15, each gathered piece one full 128-byte line -- into registers while the previous
+// chunk is being multiplied, then into LDS; (3) lane (row, rhs) walks its row's entries in CSR
+// order (fixed summation order, the same as csr_spmv_tiles) reading values, indices and X from
+// LDS; (4) the R x 16 results leave as 128-byte pieces.  fp32 values (config 5) are widened when
+// staged; accumulation is fp64 either way.
 constexpr int SPMM_KC = 16;               // right-hand sides per chunk (one 128-byte line per row of X)
 constexpr int SPMM_XLD = 18;              // LDS row stride of the staged X rows (16-byte aligned, spreads banks)
+constexpr int SPMM_NG = 10;               // gather loads per thread and chunk: up to 320 distinct columns per tile
 
+inline size_t spmm_tile_lds_bytes(int R, int ucap, int ecap) {
+    return (size_t)ucap * SPMM_XLD * 8 + (size_t)ecap * 8 + (size_t)ecap * 2 + (size_t)ucap * 4 + (size_t)(R + 1) * 4 + 16;
+}
+
+constexpr int SPMM_THREADS = 256;
+
+// LDS traffic decides this kernel (rocprofv3: HBM bytes = the algorithmic ones, the re-gathered rows of X
+// come from L2): a lane owns FOUR right-hand sides of one row, so the index and value of an entry are
+// read once per 4 products and the X values as 16-byte pieces -- 12 LDS cycles per 256 products instead
+// of 6 per 64 with one right-hand side per lane.
 template <typename VT>
-__global__ __launch_bounds__(256) void csr_spmm_tiles(const int64_t* __restrict__ rowptr,
-                                                      const uint16_t* __restrict__ lidx,
-                                                      const VT* __restrict__ vals,
-                                                      const int64_t* __restrict__ tile_uptr,
-                                                      const int32_t* __restrict__ ucols, int64_t n_rows,
-                                                      const double* __restrict__ X, int64_t ldx,
-                                                      double* __restrict__ Y, int64_t ldy, int k) {
-    __shared__ __attribute__((aligned(16))) double xs[SPMM_UMAX * SPMM_XLD];
-    __shared__ double vs[SPMM_CAP];
-    __shared__ uint16_t ls[SPMM_CAP];
-    __shared__ int uc[SPMM_UMAX];
-    __shared__ int rp[SPMM_ROWS + 1];
+__global__ __launch_bounds__(SPMM_THREADS) void csr_spmm_tiles(const int64_t* __restrict__ rowptr,
+                                                               const uint16_t* __restrict__ lidx,
+                                                               const VT* __restrict__ vals,
+                                                               const int64_t* __restrict__ tile_uptr,
+                                                               const int32_t* __restrict__ ucols, int64_t n_rows,
+                                                               const double* __restrict__ X, int64_t ldx,
+                                                               double* __restrict__ Y, int64_t ldy, int k,
+                                                               int R, int ucap, int ecap) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs = smem;                                       // [ucap][SPMM_XLD]
+    double* vs = xs + (size_t)ucap * SPMM_XLD;               // [ecap]
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + ecap);   // [ecap]
+    int* uc = reinterpret_cast<int*>(ls + ecap + (ecap & 1));  // [ucap]
+    int* rp = uc + ucap;                                     // [R + 1]
     const int t = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * SPMM_ROWS;
-    const int nr = (int)min((int64_t)SPMM_ROWS, n_rows - r0);
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nr = (int)min((int64_t)R, n_rows - r0);
     const int64_t e0 = rowptr[r0];
-    if (t <= SPMM_ROWS) rp[t] = (int)(rowptr[r0 + min(t, nr)] - e0);
+    if (t <= R) rp[t] = (int)(rowptr[r0 + min(t, nr)] - e0);
     const int64_t u0 = tile_uptr[blockIdx.x];
     const int U = (int)(tile_uptr[blockIdx.x + 1] - u0);
-    for (int u = t; u < U; u += 256) uc[u] = ucols[u0 + u];
+    for (int u = t; u < U; u += SPMM_THREADS) uc[u] = ucols[u0 + u];
     const int cnt = (int)(rowptr[r0 + nr] - e0);
-    for (int base = 0; base < cnt; base += 1024) {          // four independent loads per thread and pass
+    for (int base = 0; base < cnt; base += 4 * SPMM_THREADS) {     // four independent loads per thread and pass
         uint16_t li[4];
         double v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = base + t + 256 * i;
+            const int e = base + t + SPMM_THREADS * i;
             const bool ok = e < cnt;
             li[i] = ok ? lidx[e0 + e] : (uint16_t)0;
             v[i] = ok ? (double)vals[e0 + e] : 0.0;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int e = base + t + 256 * i;
+            const int e = base + t + SPMM_THREADS * i;
             if (e < cnt) { ls[e] = li[i]; vs[e] = v[i]; }
         }
     }
     __syncthreads();
     const int seg = t & 7, ub = t >> 3;                      // gather: 8 threads x 16 B per row piece, 32 rows per pass
-    const int kl = t & 15, rsub = (t >> 4) & 3, wave = t >> 6;
-    for (int kc0 = 0; kc0 < k; kc0 += SPMM_KC) {
+    const int kq = t & 3, rsub = t >> 2;                     // multiply: 4 lanes x 4 right-hand sides per row, 64 rows per pass
+    // this thread's pieces of the distinct rows of X: row offsets once, the loads per chunk
+    int64_t goff[SPMM_NG];
+#pragma unroll
+    for (int i = 0; i < SPMM_NG; ++i) {
+        const int u = ub + 32 * i;
+        goff[i] = (u < U) ? (int64_t)uc[u] * ldx + 2 * seg : (int64_t)-1;
+    }
+    v2d g[SPMM_NG];
+    auto gather = [&](int kc0) {
         const bool seg_ok = kc0 + 2 * seg < k;               // k is even on this path (host checks)
-        for (int ubase = 0; ubase < U; ubase += 32 * 6) {
-            v2d g[6];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int u = ubase + ub + 32 * i;
-                g[i] = (v2d){0.0, 0.0};
-                if (u < U && seg_ok) g[i] = *reinterpret_cast<const v2d*>(X + (int64_t)uc[u] * ldx + kc0 + 2 * seg);
-            }
+        for (int i = 0; i < SPMM_NG; ++i) {
+            g[i] = (v2d){0.0, 0.0};
+            if (goff[i] >= 0 && seg_ok) g[i] = *reinterpret_cast<const v2d*>(X + goff[i] + kc0);
+        }
+    };
+    gather(0);
+    for (int kc0 = 0; kc0 < k; kc0 += SPMM_KC) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const int u = ubase + ub + 32 * i;
-                if (u < U) *reinterpret_cast<v2d*>(xs + u * SPMM_XLD + 2 * seg) = g[i];
-            }
+        for (int i = 0; i < SPMM_NG; ++i) {
+            const int u = ub + 32 * i;
+            if (u < U) *reinterpret_cast<v2d*>(xs + u * SPMM_XLD + 2 * seg) = g[i];
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = p * 16 + wave * 4 + rsub;
-            const int a = rp[row], b = rp[row + 1];          // rows past nr: a == b
-            double acc = 0.0;
-            int e = a;
-            for (; e + 4 <= b; e += 4) {
-                const double x0 = xs[ls[e] * SPMM_XLD + kl], x1 = xs[ls[e + 1] * SPMM_XLD + kl];
-                const double x2 = xs[ls[e + 2] * SPMM_XLD + kl], x3 = xs[ls[e + 3] * SPMM_XLD + kl];
-                acc = fma(vs[e], x0, acc); acc = fma(vs[e + 1], x1, acc);
-                acc = fma(vs[e + 2], x2, acc); acc = fma(vs[e + 3], x3, acc);
+        if (kc0 + SPMM_KC < k) gather(kc0 + SPMM_KC);        // in flight while this chunk is multiplied
+        for (int p = 0; p < R; p += 64) {
+            const int row = p + rsub;
+            int e = rp[min(row, R)];
+            const int end = rp[min(row + 1, R)];
+            v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
+            const double* xk = xs + 4 * kq;
+            for (; e + 2 <= end; e += 2) {
+                const int i0 = ls[e], i1 = ls[e + 1];
+                const double v0 = vs[e], v1 = vs[e + 1];
+                const v2d x0a = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD), x0b = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD + 2);
+                const v2d x1a = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD), x1b = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD + 2);
+                a01.x = fma(v0, x0a.x, a01.x); a01.y = fma(v0, x0a.y, a01.y); a23.x = fma(v0, x0b.x, a23.x); a23.y = fma(v0, x0b.y, a23.y);
+                a01.x = fma(v1, x1a.x, a01.x); a01.y = fma(v1, x1a.y, a01.y); a23.x = fma(v1, x1b.x, a23.x); a23.y = fma(v1, x1b.y, a23.y);
             }
-            for (; e < b; ++e) acc = fma(vs[e], xs[ls[e] * SPMM_XLD + kl], acc);
-            if (row < nr && kc0 + kl < k) Y[(r0 + row) * ldy + kc0 + kl] = acc;
+            if (e < end) {
+                const int i0 = ls[e];
+                const double v0 = vs[e];
+                const v2d x0a = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD), x0b = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD + 2);
+                a01.x = fma(v0, x0a.x, a01.x); a01.y = fma(v0, x0a.y, a01.y); a23.x = fma(v0, x0b.x, a23.x); a23.y = fma(v0, x0b.y, a23.y);
+            }
+            if (row < nr) {
+                double* yp = Y + (r0 + row) * ldy + kc0 + 4 * kq;
+                if (kc0 + 4 * kq + 4 <= k && (ldy & 1) == 0) {
+                    *reinterpret_cast<v2d*>(yp) = a01; *reinterpret_cast<v2d*>(yp + 2) = a23;
+                } else {
+                    if (kc0 + 4 * kq < k) yp[0] = a01.x;
+                    if (kc0 + 4 * kq + 1 < k) yp[1] = a01.y;
+                    if (kc0 + 4 * kq + 2 < k) yp[2] = a23.x;
+                    if (kc0 + 4 * kq + 3 < k) yp[3] = a23.y;
+                }
+            }
         }
         __syncthreads();
     }

@@ -126,9 +126,10 @@ gmrf_status gmrf_bt_refactor_values(gmrf_handle* h, const double* nzval, int32_t
  * mode FULL:     y = A^-1 b           ldiv!/ldiv      (:54-63)
  * mode FORWARD:  y = L^-1 b           forward_solve   (:43-52)
  * mode BACKWARD: y = L^-T b           backward_solve  (:24-33)
- * b, y: n x k column-major, leading dimension ld; b == y allowed. */
+ * b, y: n x k column-major with leading dimensions ldb, ldy (a strided Julia view and a dense
+ * result may differ); b == y (in place, as ldiv! allows) needs ldb == ldy. */
 gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
-                          int64_t ld, int32_t mode);
+                          int64_t ldb, int64_t ldy, int32_t mode);
 
 /* k samples  x_s = mean + L^-T z_s  (rand(rng, x_cond), solve_darcy_gmrf-fem.jl:191).
  * z == NULL: z_s[dof] is Philox4x32-10(key = seed, counter = (dof, first_id + s)) through

@@ -293,14 +293,20 @@ def test_c_abi_leading_dimensions_in_place_and_mixed_k(pkg, lib):
         B = rng.standard_normal((n, k))
         buf = np.full((k, ld), np.nan)                    # k columns of length ld, column-major n x k inside
         buf[:, :n] = B.T
-        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(buf), pkg._cabi.ptr(buf), k, ld, pkg._cabi.SOLVE_FULL))
+        buf0 = buf.copy()
+        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(buf), pkg._cabi.ptr(buf), k, ld, ld, pkg._cabi.SOLVE_FULL))
         assert rel(buf[:, :n].T, O.ldiv(Fo, B)) < 1e-12 and np.all(np.isnan(buf[:, n:]))
         dev = torch.full((k, ld), float("nan"), dtype=torch.float64, device="cuda")
         dev[:, :n] = torch.from_numpy(B.T.copy()).cuda()
         out = torch.zeros_like(dev)
-        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(dev), pkg._cabi.ptr(out), k, ld, pkg._cabi.SOLVE_BACKWARD))
+        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(dev), pkg._cabi.ptr(out), k, ld, ld, pkg._cabi.SOLVE_BACKWARD))
         assert rel(out[:, :n].T.cpu().numpy(), O.backward_solve(Fo, B)) < 1e-12
         assert float(out[:, n:].abs().sum()) == 0.0       # the padding of the output is not written
+        # different leading dimensions on the two sides (a strided view in, a dense matrix out)
+        dense = np.empty((k, n))
+        pkg._cabi.check(lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(buf0), pkg._cabi.ptr(dense), k, ld, n, pkg._cabi.SOLVE_FORWARD))
+        assert rel(dense.T, O.forward_solve(Fo, B)) < 1e-12
+        assert lib.gmrf_bt_solve(F._h, pkg._cabi.ptr(dense), pkg._cabi.ptr(dense), k, n, ld, 0) == pkg._cabi.ERR_BAD_SHAPE
     # export the factor of problem 1 of a batch
     Fb = pkg.TridiagonalCholeskyFactor(batch=2).factor(w.Q, 5, values=np.stack([w.Q.data, 4.0 * w.Q.data]))
     Fb.select_problem(1)
@@ -791,10 +797,12 @@ def test_config_burgers4096x512_full_size(pkg):
     assert rel(S64 @ X, ref64) < 1e-14 and rel(S64 @ X[:, 0], ref64[:, 0]) < 1e-14
     assert rel(S32 @ X, ref32) < 1e-14 and rel(S32 @ X[:, 0], ref32[:, 0]) < 1e-14
     assert rel(S32 @ X, ref64) < 1e-6                # fp32 values: 2^-24 relative per entry, fp64 accumulation
-    Xd = torch.from_numpy(np.ascontiguousarray(X.T)).cuda().t()      # device-resident, 64 right-hand sides
-    X64 = torch.cat([Xd] * 8, dim=1).t().contiguous().t()
-    Y64 = (S32 @ X64).cpu().numpy()
-    assert rel(Y64[:, :8], ref32) < 1e-14 and np.array_equal(Y64[:, 8:16], Y64[:, :8])
+    X64h = np.tile(X, (1, 8))                                         # 64 right-hand sides, device resident
+    Xc = torch.from_numpy(np.ascontiguousarray(X64h.T)).cuda().t()   # column-major (each right-hand side contiguous)
+    Yc = (S32 @ Xc).cpu().numpy()
+    assert rel(Yc[:, :8], ref32) < 1e-14 and np.array_equal(Yc[:, 56:], Yc[:, :8])
+    Yr = (S32 @ torch.from_numpy(X64h).cuda()).cpu().numpy()         # node-major: the LDS-tiled kernel
+    assert rel(Yr[:, :8], ref32) < 1e-14 and np.array_equal(Yr[:, 56:], Yr[:, :8])
     del S64, S32
     # (ii) the same model with 4 time steps against the oracle (bs = 4096: two-level panels, six doubling levels)
     wt = pkg.workloads.burgers(4096, 4)

@@ -104,14 +104,10 @@ def test_posterior_assembler_symbolic_phase_without_gpu(pkg, lib):
         pkg.PosteriorAssembler(gn["Q"], J[:, :-1], device=-1)
 
 
-def test_julia_shim_ccalls_match_the_header():
-    """The Julia shim cannot be executed here (no Julia in the image): check statically that every
-    `ccall` names an exported function with the same number of arguments and compatible C types."""
-    src = open(os.path.join(ROOT, "julia", "DiffEqGMRFsHIP.jl")).read()
-    hdr = open(os.path.join(ROOT, "include", "gmrf_hip.h")).read()
+def _check_julia_ccalls(src, hdr, min_calls):
     calls = re.findall(r"ccall\(\(:(\w+),\s*libgmrf\),\s*(\w+),\s*\(([^)]*)\)", src, flags=re.S)
     protos = {m.group(1): m.group(2) for m in re.finditer(r"gmrf_status\s+(gmrf_\w+)\s*\(([^;]*?)\);", hdr, flags=re.S)}
-    assert len(calls) >= 12
+    assert len(calls) >= min_calls
 
     def c_kind(a):
         a = a.strip()
@@ -127,8 +123,48 @@ def test_julia_shim_ccalls_match_the_header():
         if name == "gmrf_last_error":
             assert ret == "Cstring"
             continue
+        if name == "gmrf_version":
+            assert ret == "Int32" and not args.strip()
+            continue
         assert name in protos, name
         assert ret == "Int32"                                  # gmrf_status
         jt = [j_kind(a) for a in args.split(",") if a.strip()]
         ct = [c_kind(a) for a in protos[name].split(",") if a.strip() and a.strip() != "void"]
         assert jt == ct, (name, jt, ct)
+    return {name for name, _, _ in calls}
+
+
+def test_julia_shim_ccalls_match_the_header():
+    """The Julia shim cannot be executed here (no Julia in the image): check statically that every
+    `ccall` names an exported function with the same number of arguments and compatible C types, and
+    that EVERY non-test export of the header is bound by the shim."""
+    src = open(os.path.join(ROOT, "julia", "DiffEqGMRFsHIP.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "gmrf_hip.h")).read()
+    bound = _check_julia_ccalls(src, hdr, 40)
+    declared = set(re.findall(r"\b(gmrf_[a-z0-9_]+)\(", hdr)) - {"gmrf_status"}
+    missing = sorted(s for s in declared if not s.startswith("gmrf_test_") and s not in bound)
+    assert not missing, missing
+    # struct mirrors: same number of fields as the C structs
+    stats_fields = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} gmrf_stats;", hdr, flags=re.S).group(1)
+    stats_fields = re.sub(r"/\*.*?\*/", "", stats_fields, flags=re.S)
+    n_c = len(re.findall(r"^\s*(?:double|int64_t)\s+[^;]+;", stats_fields, flags=re.M))
+    jl = re.search(r"struct GmrfStats(.*?)\nend", src, flags=re.S).group(1)
+    c_names = [n.strip().split("[")[0] for line in re.findall(r"^\s*(?:double|int64_t)\s+([^;]+);", stats_fields, flags=re.M) for n in line.split(",")]
+    j_names = re.findall(r"(\w+)::", jl)
+    assert c_names == j_names, (c_names, j_names)
+    assert n_c >= 6
+
+
+def test_julia_solver_blueprint_ccalls_match_the_shim():
+    """julia/BlockTridiagonalSolver.jl (the GaussianMarkovRandomFields.jl solver blueprint)
+    goes through the shim only: no ccall of its own, and every shim function it uses exists."""
+    src = open(os.path.join(ROOT, "julia", "BlockTridiagonalSolver.jl")).read()
+    shim = open(os.path.join(ROOT, "julia", "DiffEqGMRFsHIP.jl")).read()
+    assert "ccall(" not in src
+    used = set(re.findall(r"\bHIP\.(\w+!?)", src)) - {"jl"}          # ("DiffEqGMRFsHIP.jl" in comments)
+    assert used, "the adapter must call the shim"
+    defined = set(re.findall(r"^(?:function\s+)?(\w+!?)\(", shim, flags=re.M)) | set(re.findall(r"^(?:mutable\s+)?struct\s+(\w+)", shim, flags=re.M)) \
+        | set(re.findall(r"^const\s+([\w, ]+)=", shim, flags=re.M)) | set(re.findall(r"^(\w+!?)\(.*\)\s*=", shim, flags=re.M))
+    consts = {c.strip() for grp in re.findall(r"^const\s+([\w, ]+?)\s*=", shim, flags=re.M) for c in grp.split(",")}
+    missing = sorted(u for u in used if u not in defined and u not in consts)
+    assert not missing, missing

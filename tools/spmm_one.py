@@ -1,0 +1,16 @@
+"""One SpMM shape for profiler runs: burgers4096x512 precision matrix, node-major k = 64 (and k = 1), fp64."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import __graft_entry__ as g
+pkg = g.load_package()
+w = pkg.workloads.make(sys.argv[1] if len(sys.argv) > 1 else "burgers4096x512")
+f32 = len(sys.argv) > 2 and sys.argv[2] == "fp32"
+S = pkg.CsrMatrix(w.Q, values_f32=f32)
+X = torch.randn(w.n, 64, dtype=torch.float64, device="cuda")
+x = torch.randn(w.n, dtype=torch.float64, device="cuda")
+for _ in range(6):
+    Y = S @ X
+    y = S @ x
+torch.cuda.synchronize()
+print("ok", float(Y.abs().sum()), float(y.abs().sum()))
