@@ -808,9 +808,16 @@ def test_config_burgers4096x512_full_size(pkg):
     wt = pkg.workloads.burgers(4096, 4)
     Ft = pkg.tridiagonal_cholesky(wt.Q, wt.n_blocks)
     Fo = O.tridiagonal_cholesky(wt.Q, wt.n_blocks)
+    # two backward-stable factorisations of an ill-conditioned 4096 x 4096 block agree to cond * eps, not to
+    # 1e-11 (measured 9.5e-10 of max|L|): the blocks are held to the solve tolerance, and block 0 to the
+    # backward-error bound  || L L' - D || <= c n eps || D ||  that both must meet
+    ftol = max(TOL_FACTOR, solve_tol(wt))
     for i in (0, 3):
-        assert np.max(np.abs(np.tril(Ft.chos[i]) - Fo.chos[i])) / np.max(np.abs(Fo.chos[i])) < TOL_FACTOR
-    assert np.max(np.abs(Ft.Cs[2] - Fo.Cs[2])) / np.max(np.abs(Fo.Cs[2])) < TOL_FACTOR
+        assert np.max(np.abs(np.tril(Ft.chos[i]) - Fo.chos[i])) / np.max(np.abs(Fo.chos[i])) < ftol
+    assert np.max(np.abs(Ft.Cs[2] - Fo.Cs[2])) / np.max(np.abs(Fo.Cs[2])) < ftol
+    D0 = wt.Q.tocsr()[:4096, :4096].toarray()
+    L0 = np.tril(Ft.chos[0])
+    assert np.linalg.norm(L0 @ L0.T - D0) / np.linalg.norm(D0) < 4096 * EPS
     Bt = rng.standard_normal((wt.n, 3))
     xo = O.ldiv(Fo, Bt)
     assert rel(pkg.ldiv(Ft, Bt), xo) < solve_tol(wt)
