@@ -245,6 +245,8 @@ def main():
                     help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-spmm", action="store_true", help="skip the K6 roofline leg (burgers4096x512 matrix)")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: skip the problems-mode and C4 legs")
+    ap.add_argument("--force-shared", action="store_true",
+                    help="rehearsal: run the shared-factor code (process group, communicator, broadcasts) with a world of one rank")
     args = ap.parse_args()
 
     import numpy as np
@@ -264,16 +266,17 @@ def main():
     one_device = os.environ.get("GMRF_BENCH_ONE_DEVICE") == "1" and backend == "gloo"
     if one_device:
         local = 0
-    if world > 1:
+    if world > 1 or args.force_shared:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     mode = args.mode if args.mode != "auto" else ("shared-factor" if world > 1 else "problems")
-    shared = mode == "shared-factor" and world > 1
+    shared = mode == "shared-factor" and (world > 1 or args.force_shared)
     keep_l = bool(args.keep_l)
 
     def sync():
@@ -307,7 +310,8 @@ def main():
     def shared_job(wl, batch, k_per_rank, values=None, rhs=None):
         eng = post.HipEngine(pkg, wl, device_index=local, batch=batch, values=values, rhs=rhs, keep_l=keep_l,
                              transport=transport, comm=comm)
-        job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group)
+        job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group,
+                                    force_shared=args.force_shared)
         job.prepare()
         return eng, job
 
@@ -403,7 +407,7 @@ def main():
         pj.close()
 
     # ------------------------------------------------------------------ N = 1: per-kernel roofline + parity + CPU baseline
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not shared:
         eng.F.set_profiling(1)
         with torch.cuda.stream(pj.jobs[0][0]):
             job.step(10_000)

@@ -169,10 +169,12 @@ class ShardedPosterior:
     """One posterior job across `world` ranks (see module docstring)."""
 
     def __init__(self, engine, dist=None, rank: int = 0, world: int = 1, k_samples: int = 64,
-                 seed: int = 0x5EED, group: int = 8, replicate_factor: bool = False):
+                 seed: int = 0x5EED, group: int = 8, replicate_factor: bool = False, force_shared: bool = False):
+        """`force_shared`: run the shared-factor protocol (ranged factorisation, broadcasts, commit) even
+        with a world of one rank -- rehearsals of the multi-GPU path on a one-GPU box."""
         self.e, self.dist, self.rank, self.world = engine, dist, rank, world
         self.k, self.seed, self.group = k_samples, seed, group
-        self.replicate = replicate_factor or world == 1
+        self.replicate = replicate_factor or (world == 1 and not force_shared)
         self.groups = block_groups(engine.w.n_blocks, group)
 
     def prepare(self):

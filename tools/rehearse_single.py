@@ -35,8 +35,7 @@ lay = np.arange(5, dtype=np.int64)
 comm.bcast_host(lay, 0)
 assert list(lay) == [0, 1, 2, 3, 4]
 eng = post.HipEngine(pkg, w, device_index=0, batch=2, values=vals, rhs=rhs, keep_l=False, transport="cabi", comm=comm)
-job = post.ShardedPosterior(eng, rank=0, world=1, k_samples=6, seed=42, group=5)
-job.replicate = False                      # force the shared-factor protocol with a world of one
+job = post.ShardedPosterior(eng, rank=0, world=1, k_samples=6, seed=42, group=5, force_shared=True)
 job.prepare()
 for step in range(2):
     mu_c, X_c = job.step(step)
