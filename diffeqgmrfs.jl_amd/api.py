@@ -203,6 +203,52 @@ class PosteriorAssembler:
         return out
 
 
+class DarcyP1Assembler:
+    """Darcy stiffness matrix and load vector on the device (first piece):
+    `assemble_darcy_diff_matrix` of /root/reference/src/problems/darcy.jl:5-63 on the structured P1 mesh
+    (nx x ny nodes, x fastest, quads cut by the diagonal n00 - n11, one quadrature point per cell), the
+    coefficient looked up by nearest grid point (src/datasets/darcy.jl:30-34), Dirichlet rows / columns
+    applied.  `pattern` is the CSR matrix (values 1) whose `.data` order `assemble()` fills -- the `J`
+    of `PosteriorAssembler`.  device = -1: pattern only (no GPU needed)."""
+
+    def __init__(self, nx: int, ny: int, device: int = 0, stream: int = 0):
+        self.nx, self.ny, self.n = int(nx), int(ny), int(nx) * int(ny)
+        self._h = C.c_void_p()
+        lib = _cabi.load()
+        _cabi.check(lib.gmrf_darcy_p1_create(device, C.c_void_p(stream), nx, ny, C.byref(self._h)))
+        nnz = C.c_int64(0)
+        _cabi.check(lib.gmrf_darcy_p1_pattern(self._h, C.byref(nnz), None, None, 0))
+        self.nnz = int(nnz.value)
+        rp, ci = np.empty(self.n + 1, dtype=np.int64), np.empty(self.nnz, dtype=np.int64)
+        _cabi.check(lib.gmrf_darcy_p1_pattern(self._h, None, _cabi.ptr(rp), _cabi.ptr(ci), 0))
+        self.pattern = sp.csr_matrix((np.ones(self.nnz), ci, rp), shape=(self.n, self.n))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _cabi.load().gmrf_darcy_p1_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def assemble(self, coeff_table, beta: float = 1.0):
+        """coeff_table: (ng, ng) array a[x index, y index] on the grid linspace(0, 1, ng)^2 (NumPy array or
+        torch CUDA tensor).  Returns (values in `pattern.data` order, load vector f), same kind as the input."""
+        if _is_torch(coeff_table):
+            import torch
+            tab = coeff_table.contiguous()
+            vals = torch.empty(self.nnz, dtype=torch.float64, device=tab.device)
+            f = torch.empty(self.n, dtype=torch.float64, device=tab.device)
+        else:
+            tab = np.ascontiguousarray(coeff_table, dtype=np.float64)
+            vals, f = np.empty(self.nnz), np.empty(self.n)
+        if tab.ndim != 2 or tab.shape[0] != tab.shape[1]:
+            raise ValueError("coeff_table must be square (ng x ng)")
+        _cabi.check(_cabi.load().gmrf_darcy_p1_assemble(self._h, _cabi.ptr(tab), tab.shape[0], float(beta), _cabi.ptr(vals),
+                                                        _cabi.ptr(f)))
+        return vals, f
+
+
 def gn_step(F: "TridiagonalCholeskyFactor", asm: PosteriorAssembler, q_values, Qx_prior, j_values, x, obs_diff,
             noise: float):
     """One Gauss-Newton step of scripts/solve_burger.jl:143-149 with everything resident on the

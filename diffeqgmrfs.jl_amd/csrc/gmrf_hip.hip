@@ -23,6 +23,7 @@
 
 #include "../../include/gmrf_hip.h"
 #include "assemble.hpp"
+#include "fem_assemble.hpp"
 #include "gemm_f64.hpp"
 #include "microbench.hpp"
 #include "misc_kernels.hpp"
@@ -2219,6 +2220,113 @@ gmrf_status gmrf_assemble_rhs(gmrf_assembler* as, const double* base, const doub
     HIPCHK(hipGetLastError());
     if (!dev) HIPCHK(hipMemcpyAsync(out, d_out, sizeof(double) * as->n, hipMemcpyDeviceToHost, as->stream));
     HIPCHK(hipStreamSynchronize(as->stream));
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- FEM block assembly (Darcy, P1)
+struct gmrf_darcy_p1 {
+    int device = -1;                    // -1: pattern only
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t nx = 0, ny = 0, n = 0, nnz = 0;
+    std::vector<int64_t> rowptr, colidx;            // 0-based
+    int64_t* d_rowptr = nullptr;
+    double *d_diag = nullptr, *d_mean = nullptr, *d_table = nullptr, *d_vals = nullptr, *d_f = nullptr;   // work + staging
+    int64_t table_cap = 0;
+};
+
+gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out) {
+    if (!out || nx < 2 || ny < 2 || nx > 32768 || ny > 32768) return bad_shape("bad Darcy mesh size");
+    auto* d = new gmrf_darcy_p1();
+    d->nx = nx; d->ny = ny; d->n = nx * ny;
+    d->rowptr.assign((size_t)d->n + 1, 0);
+    d->colidx.reserve((size_t)d->n * 7);
+    const int dxs[7] = {-1, 0, -1, 0, 1, 0, 1}, dys[7] = {-1, -1, 0, 0, 0, 1, 1};
+    for (int64_t iy = 0; iy < ny; ++iy)
+        for (int64_t ix = 0; ix < nx; ++ix) {
+            for (int s7 = 0; s7 < 7; ++s7) {
+                const int64_t jx = ix + dxs[s7], jy = iy + dys[s7];
+                if (jx < 0 || jy < 0 || jx >= nx || jy >= ny) continue;
+                d->colidx.push_back(jy * nx + jx);
+            }
+            d->rowptr[(size_t)(iy * nx + ix) + 1] = (int64_t)d->colidx.size();
+        }
+    d->nnz = (int64_t)d->colidx.size();
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+            (void)hipGetLastError();
+            delete d;
+            g_last_error = "no HIP device visible (libgmrf_hip needs an MI355X / gfx950 GPU)";
+            return GMRF_ERR_NO_DEVICE;
+        }
+        d->device = device;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) { if (stream) d->stream = (hipStream_t)stream; else { e = hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking); d->own_stream = (e == hipSuccess); } }
+        if (e == hipSuccess) e = hipMalloc(&d->d_rowptr, sizeof(int64_t) * (d->n + 1));
+        if (e == hipSuccess) e = hipMalloc(&d->d_diag, sizeof(double) * d->n);
+        if (e == hipSuccess) e = hipMalloc(&d->d_mean, sizeof(double));
+        if (e == hipSuccess) e = hipMemcpyAsync(d->d_rowptr, d->rowptr.data(), sizeof(int64_t) * (d->n + 1), hipMemcpyHostToDevice, d->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
+        if (e != hipSuccess) {
+            g_last_error = std::string("gmrf_darcy_p1_create: ") + hipGetErrorString(e);
+            (void)gmrf_darcy_p1_destroy(d);
+            return GMRF_ERR_HIP;
+        }
+    }
+    *out = d;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_darcy_p1_destroy(gmrf_darcy_p1* d) {
+    if (!d) return GMRF_OK;
+    if (d->device >= 0) {
+        (void)hipSetDevice(d->device);
+        if (d->stream) (void)hipStreamSynchronize(d->stream);
+        free_dev(d->d_rowptr); free_dev(d->d_diag); free_dev(d->d_mean); free_dev(d->d_table); free_dev(d->d_vals); free_dev(d->d_f);
+        if (d->own_stream) (void)hipStreamDestroy(d->stream);
+    }
+    delete d;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_darcy_p1_pattern(const gmrf_darcy_p1* d, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx, int32_t index_base) {
+    if (!d) return bad_shape("null handle");
+    if (nnz_out) *nnz_out = d->nnz;
+    if (rowptr) for (int64_t i = 0; i <= d->n; ++i) rowptr[i] = d->rowptr[(size_t)i] + index_base;
+    if (colidx) for (int64_t e = 0; e < d->nnz; ++e) colidx[e] = d->colidx[(size_t)e] + index_base;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, int64_t ng, double beta, double* vals_out,
+                                   double* f_out) {
+    if (!d || !coeff_table || !vals_out || !f_out || ng < 2 || ng > 46340) return bad_shape("bad Darcy assembly arguments");
+    if (d->device < 0) { g_last_error = "pattern-only Darcy assembler (created with device -1)"; return GMRF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(d->device));
+    const double* d_tab = coeff_table;
+    if (!is_device_ptr(coeff_table)) {
+        if (d->table_cap < ng * ng) {
+            free_dev(d->d_table); d->d_table = nullptr; d->table_cap = 0;
+            HIPCHK(hipMalloc(&d->d_table, sizeof(double) * ng * ng));
+            d->table_cap = ng * ng;
+        }
+        HIPCHK(hipMemcpyAsync(d->d_table, coeff_table, sizeof(double) * ng * ng, hipMemcpyHostToDevice, d->stream));
+        d_tab = d->d_table;
+    }
+    const bool v_dev = is_device_ptr(vals_out), f_dev = is_device_ptr(f_out);
+    if (!v_dev && !d->d_vals) HIPCHK(hipMalloc(&d->d_vals, sizeof(double) * d->nnz));
+    if (!f_dev && !d->d_f) HIPCHK(hipMalloc(&d->d_f, sizeof(double) * d->n));
+    DarcyP1Args a;
+    a.nx = (int)d->nx; a.ny = (int)d->ny; a.ng = (int)ng; a.table = d_tab; a.rowptr = d->d_rowptr; a.beta = beta;
+    a.vals = v_dev ? vals_out : d->d_vals; a.f = f_dev ? f_out : d->d_f; a.diag = d->d_diag;
+    const dim3 grid((unsigned)((d->n + 255) / 256));
+    hipLaunchKernelGGL(darcy_p1_rows, grid, dim3(256), 0, d->stream, a);
+    hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, d->stream, d->d_diag, d->n, d->d_mean);
+    hipLaunchKernelGGL(darcy_p1_constrain, grid, dim3(256), 0, d->stream, a, d->d_mean);
+    HIPCHK(hipGetLastError());
+    if (!v_dev) HIPCHK(hipMemcpyAsync(vals_out, d->d_vals, sizeof(double) * d->nnz, hipMemcpyDeviceToHost, d->stream));
+    if (!f_dev) HIPCHK(hipMemcpyAsync(f_out, d->d_f, sizeof(double) * d->n, hipMemcpyDeviceToHost, d->stream));
+    HIPCHK(hipStreamSynchronize(d->stream));
     return GMRF_OK;
 }
 

@@ -318,6 +318,25 @@ gmrf_status gmrf_assemble_precision(gmrf_assembler* as, const double* q_nzval, c
 gmrf_status gmrf_assemble_rhs(gmrf_assembler* as, const double* base, const double* j_vals,
                               const double* x, const double* obs_diff, double noise, double* out);
 
+/* ------------------------------------------------------------------ FEM block assembly (first piece)
+ * Darcy stiffness matrix  G[i][j] = int a grad(phi_i).grad(phi_j),  f[i] = beta int phi_i  with the
+ * homogeneous Dirichlet rows / columns applied -- assemble_darcy_diff_matrix,
+ * /root/reference/src/problems/darcy.jl:5-63 (cell loop :27-60, coefficient looked up at the quadrature
+ * point by nearest grid point, src/datasets/darcy.jl:30-34; `apply!` :61) -- on the structured P1 mesh
+ * of the BASELINE Darcy configs: nx x ny nodes on the unit square, x fastest, quads cut by the diagonal
+ * n00 - n11, one quadrature point per cell.  The values come out in CSR order of the 7-point
+ * pattern gmrf_darcy_p1_pattern returns, which is the `J` of gmrf_assemble_precision
+ * (Q_post = Q + Q_eps G'G): per problem only the ng x ng coefficient table crosses the bus.
+ * coeff_table[ix * ng + iy] = a at grid point (x = ix / (ng-1), y = iy / (ng-1)); host or device
+ * pointers; device = -1: pattern only. */
+typedef struct gmrf_darcy_p1 gmrf_darcy_p1;
+gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out);
+gmrf_status gmrf_darcy_p1_destroy(gmrf_darcy_p1* d);
+gmrf_status gmrf_darcy_p1_pattern(const gmrf_darcy_p1* d, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
+                                  int32_t index_base);
+gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, int64_t ng, double beta,
+                                   double* vals_out, double* f_out);
+
 /* ------------------------------------------------------------------ test hooks
  * Direct access to the dense device kernels for the parity tests (row-major operands on
  * the HOST; not part of the drop-in surface). */

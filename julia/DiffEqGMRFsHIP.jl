@@ -30,7 +30,7 @@ module DiffEqGMRFsHIP
 using SparseArrays, LinearAlgebra
 
 export TridiagonalCholeskyFactor, tridiagonal_cholesky, forward_solve, backward_solve, ldiv, PosteriorAssembler, GmrfCsr,
-       GmrfComm
+       GmrfComm, DarcyP1Assembler
 
 const libgmrf = get(ENV, "LIBGMRF_HIP", joinpath(@__DIR__, "..", "diffeqgmrfs.jl_amd", "csrc", "libgmrf_hip.so"))
 
@@ -373,6 +373,35 @@ function rhs!(out::Vector{Float64}, as::PosteriorAssembler, base, jt_nzval, x, o
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}),
         as.handle, base, jt_nzval, x, obs_diff, Float64(noise), out))
     return out
+end
+
+# ------------------------------------------------------------------------------------------ Darcy stiffness on the device
+# assemble_darcy_diff_matrix (src/problems/darcy.jl:5-63) on the structured P1 mesh: per problem only the
+# coefficient table crosses the bus; the values come out in the order `PosteriorAssembler` takes as J.
+mutable struct DarcyP1Assembler
+    handle::Ptr{Cvoid}
+    pattern::SparseMatrixCSC{Float64,Int}     # TRANSPOSE of the stiffness pattern (CSC of G' = CSR of G), values 1.0
+end
+
+function DarcyP1Assembler(nx::Integer, ny::Integer; device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gmrf_darcy_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), device, C_NULL, nx, ny, h))
+    nnz_out = Ref{Int64}(0)
+    check(ccall((:gmrf_darcy_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, C_NULL, C_NULL, 1))
+    rowptr = Vector{Int64}(undef, nx * ny + 1); colidx = Vector{Int64}(undef, nnz_out[])
+    check(ccall((:gmrf_darcy_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, rowptr, colidx, 1))
+    d = DarcyP1Assembler(h[], SparseMatrixCSC(nx * ny, nx * ny, rowptr, colidx, ones(nnz_out[])))
+    finalizer(x -> ccall((:gmrf_darcy_p1_destroy, libgmrf), Int32, (Ptr{Cvoid},), x.handle), d)
+    return d
+end
+
+"`coeff[ix, iy]` on the grid range(0, 1, ng)^2 (as `ds.darcy_vars[\"coeff\"][idx, :, :]`); returns (values of G in CSR order, f)."
+function assemble!(vals::Vector{Float64}, f::Vector{Float64}, d::DarcyP1Assembler, coeff::Matrix{Float64}; beta::Real = 1.0)
+    ng = size(coeff, 1)
+    tab = Matrix{Float64}(coeff')              # the library wants table[x index][y index] row-major = coeff' column-major
+    GC.@preserve tab vals f check(ccall((:gmrf_darcy_p1_assemble, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Float64}), d.handle, tab, ng, Float64(beta), vals, f))
+    return vals, f
 end
 
 # ------------------------------------------------------------------------------------------ multi-GPU

@@ -281,6 +281,64 @@ def condition_on_observations(Q, mu, A, q_eps: float, y, N_blocks: int):
     return Qp, F, ldiv(F, Q @ mu + q_eps * (A.T @ y))
 
 
+def get_xy_idcs(point_x, point_y, x_coords, y_coords):
+    """src/datasets/darcy.jl:30-34: nearest grid point per coordinate, `argmin(abs.(coords .- p))` (the first
+    minimum wins).  Vectorised over points."""
+    xi = np.argmin(np.abs(np.asarray(x_coords)[None, :] - np.asarray(point_x)[:, None]), axis=1)
+    yi = np.argmin(np.abs(np.asarray(y_coords)[None, :] - np.asarray(point_y)[:, None]), axis=1)
+    return xi, yi
+
+
+def assemble_darcy_diff_matrix(nx: int, ny: int, x_coords, y_coords, coeff_mat, beta: float = 1.0):
+    """`assemble_darcy_diff_matrix`, /root/reference/src/problems/darcy.jl:5-63, on the structured P1 mesh that
+    stands in for the reference's Gmsh P2 mesh: nx x ny nodes on the unit square, x fastest,
+    every quad cut by the diagonal n00 - n11 into the cells (n00, n10, n11) [all of them first] and
+    (n00, n11, n01); one quadrature point per cell (the centroid, weight |T|).  Per cell (:27-59):
+        coeff_val = coeff_mat[get_xy_idcs(x_q, x_coords, y_coords)...]          :39
+        fe[i]    += beta * phi_i(x_q) * dOmega                                  :47
+        Ge[i, j] += (grad phi_i . coeff_val grad phi_j) * dOmega                :50-52
+    then `assemble!` (:58) and `apply!(G, f, ch)` (:61) with homogeneous Dirichlet data on the boundary
+    nodes: constrained rows and columns zeroed, their diagonal set to meandiag(G) = sum |G_ii| / n, f zeroed
+    there (Ferrite semantics).  Returns (G as CSR with the full 7-point pattern, explicit zeros kept, f)."""
+    xs, ys = np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny)
+    qx, qy = np.meshgrid(np.arange(nx - 1), np.arange(ny - 1), indexing="xy")
+    n00 = (qy * nx + qx).ravel(); n10 = n00 + 1; n01 = n00 + nx; n11 = n01 + 1
+    cells = np.concatenate([np.stack([n00, n10, n11], axis=1), np.stack([n00, n11, n01], axis=1)], axis=0)
+    X, Y = xs[cells % nx], ys[cells // nx]                                  # cell_coords, (cells, 3)
+    # P1 shape functions on the cell: phi_i = (a_i + b_i x + c_i y) / (2 |T|)
+    b = np.stack([Y[:, 1] - Y[:, 2], Y[:, 2] - Y[:, 0], Y[:, 0] - Y[:, 1]], axis=1)
+    c = np.stack([X[:, 2] - X[:, 1], X[:, 0] - X[:, 2], X[:, 1] - X[:, 0]], axis=1)
+    area = 0.5 * np.abs(X[:, 0] * b[:, 0] + X[:, 1] * b[:, 1] + X[:, 2] * b[:, 2])
+    xq, yq = ((X[:, 0] + X[:, 1]) + X[:, 2]) / 3.0, ((Y[:, 0] + Y[:, 1]) + Y[:, 2]) / 3.0    # spatial_coordinate :35
+    xi, yi = get_xy_idcs(xq, yq, x_coords, y_coords)
+    coeff_val = np.asarray(coeff_mat)[xi, yi]                               # :39
+    n = nx * ny
+    G = sp.lil_matrix((n, n))
+    rows, cols, vals = [], [], []
+    f = np.zeros(n)
+    for i in range(3):                                                      # test functions :44
+        np.add.at(f, cells[:, i], beta * (1.0 / 3.0) * area)                # :47, phi_i(centroid) = 1/3
+        for j in range(3):                                                  # trial functions :49
+            rows.append(cells[:, i]); cols.append(cells[:, j])
+            vals.append((b[:, i] * b[:, j] + c[:, i] * c[:, j]) / (4.0 * area) * coeff_val)   # :50-52
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
+    G = sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()           # assemble! :58 (duplicates summed, zeros kept)
+    G.sort_indices()
+    # apply!(G, f, ch) :61
+    ixn, iyn = np.arange(n) % nx, np.arange(n) // nx
+    constrained = (ixn == 0) | (iyn == 0) | (ixn == nx - 1) | (iyn == ny - 1)
+    m = np.abs(G.diagonal()).sum() / n
+    G = G.tocoo()
+    data = G.data.copy()
+    hit = constrained[G.row] | constrained[G.col]
+    data[hit] = 0.0
+    data[hit & (G.row == G.col)] = m
+    G = sp.csr_matrix((data, (G.row, G.col)), shape=(n, n))
+    G.sort_indices()
+    f = np.where(constrained, 0.0, f)
+    return G, f
+
+
 def reconstruct(F: TridiagonalCholeskyFactor) -> np.ndarray:
     """Dense L L^T from the block factor (tests only, small n)."""
     N, bs = F.n_blocks, F.block_size

@@ -993,3 +993,51 @@ def test_spmm_node_major_lds_tiles(pkg):
     T = sp.diags([1.0, -2.5, 1.0], [-1, 0, 1], shape=(5000, 5000)).tocsr()
     Xt = rng.standard_normal((5000, 32))
     assert rel(pkg.CsrMatrix(T) @ Xt, T @ Xt) < 1e-14
+
+
+def test_darcy_stiffness_assembly_on_device(pkg):
+    """SURVEY 8f rank 4, first piece: assemble_darcy_diff_matrix (src/problems/darcy.jl:5-63) on the structured
+    P1 mesh, on the device, entry by entry against the oracle (values 1e-14 of max |G|: fixed summation
+    order over a node's cells); then the reference's per-problem chain with only the coefficient table
+    crossing the bus: table -> G (device) -> Q + Q_eps G'G (device) -> factor -> mean, against the oracle."""
+    import torch
+    gq = np.linspace(0.0, 1.0, 241)
+    GX, GY = np.meshgrid(gq, gq, indexing="ij")
+    for n, seed in ((32, 523802340), (64, 11), (256, 7)):
+        table = pkg.workloads.darcy_coefficient(seed)(GX.ravel(), GY.ravel()).reshape(241, 241)
+        Go, fo = O.assemble_darcy_diff_matrix(n, n, gq, gq, table, 2.0)
+        d = pkg.DarcyP1Assembler(n, n)
+        vals, f = d.assemble(table, beta=2.0)
+        assert np.array_equal(d.pattern.indices, Go.indices)
+        assert np.max(np.abs(vals - Go.data)) < 1e-14 * np.max(np.abs(Go.data))
+        assert np.max(np.abs(f - fo)) < 1e-15 * np.max(np.abs(fo))
+        vd, fd = d.assemble(torch.from_numpy(table).cuda(), beta=2.0)          # device-resident table and outputs
+        assert vd.is_cuda and np.array_equal(vd.cpu().numpy(), vals) and np.array_equal(fd.cpu().numpy(), f)
+    # rectangular mesh, another table size
+    tab2 = np.random.default_rng(3).uniform(1.0, 5.0, (50, 50))
+    g2 = np.linspace(0.0, 1.0, 50)
+    Go, fo = O.assemble_darcy_diff_matrix(40, 24, g2, g2, tab2, 1.0)
+    v2, f2 = pkg.DarcyP1Assembler(40, 24).assemble(tab2)
+    assert np.max(np.abs(v2 - Go.data)) < 1e-14 * np.max(np.abs(Go.data)) and np.max(np.abs(f2 - fo)) < 1e-15
+    # the problem loop of scripts/darcy/solve_darcy_gmrf-fem.jl:176-190 from the coefficient table on
+    n, N, q_eps = 32, 8, 1e8
+    Q0, _, _ = pkg.workloads.darcy_conditioning(n)
+    d = pkg.DarcyP1Assembler(n, n)
+    asm = pkg.PosteriorAssembler(Q0, d.pattern)
+    F = None
+    qd = torch.from_numpy(Q0.data).cuda()
+    w = pkg.workloads.make("darcy32")
+    for seed in (523802340, 99):
+        table = pkg.workloads.darcy_coefficient(seed)(GX.ravel(), GY.ravel()).reshape(241, 241)
+        a_vals, y = d.assemble(torch.from_numpy(table).cuda())
+        p_vals = asm.precision(qd, a_vals, q_eps)
+        if F is None:
+            P = asm.pattern.copy(); P.data = p_vals.cpu().numpy()
+            F = pkg.tridiagonal_cholesky(P, N)
+        else:
+            F.refactor(p_vals)
+        rhs = asm.rhs(None, a_vals, torch.zeros(n * n, dtype=torch.float64, device="cuda"), y, q_eps)
+        mu = pkg.ldiv(F, rhs)
+        Go, fo = O.assemble_darcy_diff_matrix(n, n, gq, gq, table, 1.0)
+        _, _, mu_o = O.condition_on_observations(Q0, None, Go, q_eps, fo, N)
+        assert mu.is_cuda and rel(mu.cpu().numpy(), mu_o) < solve_tol(w)

@@ -168,3 +168,29 @@ def test_julia_solver_blueprint_ccalls_match_the_shim():
     consts = {c.strip() for grp in re.findall(r"^const\s+([\w, ]+?)\s*=", shim, flags=re.M) for c in grp.split(",")}
     missing = sorted(u for u in used if u not in defined and u not in consts)
     assert not missing, missing
+
+
+def test_darcy_p1_pattern_and_oracle_assembly_without_gpu(pkg):
+    """SURVEY 8f rank 4, first piece: the 7-point CSR pattern of the structured P1 Darcy stiffness (library,
+    device = -1) equals the oracle's; the oracle's restatement of assemble_darcy_diff_matrix
+    (src/problems/darcy.jl:5-63) agrees with the independent vectorised generator behind the packaged
+    workloads; the numeric phase needs the GPU (no CPU fallback)."""
+    from oracle import bt_oracle as O
+    n = 32
+    coeff = pkg.workloads.darcy_coefficient(523802340)
+    gq = np.linspace(0.0, 1.0, 241)
+    GX, GY = np.meshgrid(gq, gq, indexing="ij")
+    table = coeff(GX.ravel(), GY.ravel()).reshape(241, 241)
+    G, f = O.assemble_darcy_diff_matrix(n, n, gq, gq, table, 1.0)
+    d = pkg.DarcyP1Assembler(n, n, device=-1)
+    assert d.nnz == G.nnz and np.array_equal(d.pattern.indptr, G.indptr) and np.array_equal(d.pattern.indices, G.indices)
+    _, obs, _ = pkg.workloads.darcy_conditioning(n, seeds=(523802340,))
+    A, y = obs[0]
+    assert abs(G - A).max() / abs(A).max() < 1e-14 and np.max(np.abs(f - y)) < 1e-16
+    # Ferrite's apply!: constrained rows / columns are unit-scale diagonal only, f vanishes there
+    bnd = np.flatnonzero((np.arange(n * n) % n == 0) | (np.arange(n * n) // n == 0))
+    Gd = G.toarray()
+    assert np.count_nonzero(Gd[bnd]) == bnd.size and np.all(f[bnd] == 0.0)
+    with pytest.raises(pkg.GmrfError) as e:
+        d.assemble(table)
+    assert e.value.status == pkg._cabi.ERR_NO_DEVICE
