@@ -130,7 +130,7 @@ def cpu_baseline(w, k_samples: int, sample_blocks: int = 8):
 class ProblemsJob:
     """T handles x batch B of independent posteriors on T streams / host threads (no collective)."""
 
-    def __init__(self, pkg, post, w, torch, local, config, batch, n_streams, samples, rank, keep_l):
+    def __init__(self, pkg, post, w, torch, local, config, batch, n_streams, samples, rank, keep_l, eager_flags=0):
         import numpy as np
         self.torch, self.samples, self.batch, self.n_streams = torch, samples, batch, n_streams
         total = batch * n_streams
@@ -151,6 +151,8 @@ class ProblemsJob:
             with torch.cuda.stream(st_t):
                 e_t = post.HipEngine(pkg, w, device_index=local, batch=batch, values=np.stack([vals[i] for i in idx]),
                                      rhs=np.stack([rhss[i] for i in idx]), keep_l=keep_l)
+                if eager_flags:
+                    e_t.F.set_eager(eager_flags)
                 j_t = post.ShardedPosterior(e_t, k_samples=samples, replicate_factor=True)
                 j_t.prepare()
             self.jobs.append((st_t, e_t, j_t))
@@ -245,6 +247,7 @@ def main():
                     help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-spmm", action="store_true", help="skip the K6 roofline leg (burgers4096x512 matrix)")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: skip the problems-mode and C4 legs")
+    ap.add_argument("--eager-flags", type=int, default=0, help="gmrf_bt_set_eager bits for every handle (experiments)")
     ap.add_argument("--force-shared", action="store_true",
                     help="rehearsal: run the shared-factor code (process group, communicator, broadcasts) with a world of one rank")
     args = ap.parse_args()
@@ -332,7 +335,8 @@ def main():
                     f"{B} mean(s) + {args.samples} samples per posterior")
         sharding = f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), samples sharded by Philox sample id"
     else:
-        pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
+        pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l,
+                         args.eager_flags)
         eng, job = pj.eng, pj.job
         pj.run(0, args.warmup)
         elapsed = timed(pj.run, sync, dist, torch, args.warmup, args.steps)

@@ -164,6 +164,7 @@ struct gmrf_handle {
     unsigned long long* dbg_stamps = nullptr;   // test hook: phase stamps of the fused panel step
     bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
     bool no_staircase = false;         // treat the coupling window as dense (comparison; takes effect at the next analysis)
+    bool left_looking = false;         // batches: left-looking in-panel steps (tile + potrf_panel_ll) instead of tile, panel, update
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -650,6 +651,26 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             // the workgroups of column j+1 write the whole panel L[j+1.., j]
             ProfScope ps(h, 1, f_tile + f_panel + f_upd);
             hipLaunchKernelGGL(potrf_step<false>, dim3(1 + utiles, 1), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+        } else if (!fused_in_panel && h->left_looking) {
+            // opt-in (set_eager bit 6): tile, then the LEFT-LOOKING panel (potrf_panel_ll): the panel's earlier columns
+            // are applied to column j when it is formed, the tiles right of it are left alone until the panel-end GEMM.
+            // Half the S traffic and two launches per step instead of three, but measured SLOWER on darcy256 / batch 32
+            // (30.4 ms per factor against 10.2 + 15.1 ms for panel + update: m workgroups per problem with up to four
+            // dependent 64-wide products each, against 3 m one-product workgroups) -- kept for comparison
+            {
+                ProfScope ps(h, 1, f_tile);
+                hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_TILE_LDS, h->stream, sa);
+            }
+            PanelLLArgs pa;
+            pa.S = S; pa.L = L; pa.X = X; pa.ld = ld; pa.pS = sa.pS; pa.pL = sa.pL; pa.pX = sa.pX;
+            pa.j = j; pa.j0 = cend - pw; pa.nt = nt;
+            pa.update_next_diag = (j + 1 < cend) ? 1 : 0;
+            const double jj = (double)(j - pa.j0);
+            // executed flops: per row tile 2 * 64^3 * jj (left-looking sum) + 2 * 64^3 * 20/32 (T X^T, triangular);
+            // the next diagonal tile: 10 of 16 sub-blocks x (jj + 1) columns
+            const double f_ll = 2.0 * 64.0 * 64.0 * 64.0 * (m * (jj + 0.625) + (pa.update_next_diag ? 0.625 * (jj + 1.0) : 0.0)) * nb;
+            ProfScope ps(h, 8, f_ll);
+            hipLaunchKernelGGL(potrf_panel_ll, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, pa);
         } else {
             // factor the B diagonal tiles once, then panel and update without the redundant tile work
             {
@@ -1051,6 +1072,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 8) != 0) != h->dense_g1) { destroy_graphs(h); h->dense_g1 = (eager & 8) != 0; }
     if (((eager & 16) != 0) != h->fork_graph) { destroy_graphs(h); h->fork_graph = (eager & 16) != 0; }
     h->no_staircase = (eager & 32) != 0;
+    if (((eager & 64) != 0) != h->left_looking) { destroy_graphs(h); h->left_looking = (eager & 64) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }

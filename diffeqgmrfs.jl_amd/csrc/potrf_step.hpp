@@ -554,6 +554,136 @@ __global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Left-looking panel step for batches (replaces potrf_panel + potrf_update): inside a panel of `pw` column
+// tiles starting at j0, the tiles right of column j are not touched while column j is being formed;
+// each row tile r > j of column j receives what the panel's earlier columns owe it when its turn comes:
+//     T      = S[r,j] - sum_{p = j0}^{j-1} L[r,p] L[j,p]^T      (K = 64 (j - j0); product from zero, ONE subtraction)
+//     L[r,j] = T X_jj^T
+// and the workgroup of row r = j + 1 also brings the next diagonal tile up to date,
+//     S[j+1,j+1] -= sum_{p = j0}^{j} L[j+1,p] L[j+1,p]^T        (unless j + 1 starts the next panel: the rank-256
+//                                                                 GEMM of the panel end does it then),
+// so that a 64-column step is two launches (tile, panel) instead of three and every tile of S inside the
+// panel is read once instead of being read and re-written by up to three rank-64 updates.
+// grid (m, B), m = nt - j - 1 row tiles; 4 waves, each a 16-row strip; operands straight from L2 (no LDS
+// staging), except T, which turns from the MFMA result layout into an operand through a wave-private
+// strip of one LDS tile (34 KB per workgroup: four fit a CU).
+struct PanelLLArgs {
+    double* S; double* L; const double* X;
+    int64_t ld, pS, pL, pX;
+    int j, j0, nt;
+    int update_next_diag;          // 1: the workgroup of row j + 1 updates S[j+1,j+1]
+};
+
+__global__ __launch_bounds__(256, 2) void potrf_panel_ll(PanelLLArgs pa) {
+    double* S = pa.S + (int64_t)blockIdx.y * pa.pS;
+    double* L = pa.L + (int64_t)blockIdx.y * pa.pL;
+    const double* X = pa.X + (int64_t)blockIdx.y * pa.pX;
+    __shared__ __attribute__((aligned(16))) double Ts[TILE_ELEMS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = pa.ld, oj = (int64_t)pa.j * 64;
+    const int r = pa.j + 1 + (int)blockIdx.x;
+    const int64_t R0 = (int64_t)r * 64 + 16 * wave;
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    // ---- T = S[r,j] - sum_p L[r,p] L[j,p]^T
+    v4d acc[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) acc[Jb] = zero;
+    for (int p = pa.j0; p < pa.j; ++p) {
+        const int64_t op = (int64_t)p * 64;
+        v2d a[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(L + (R0 + li) * ld + op + 8 * kg + 2 * lq);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const v2d b = *reinterpret_cast<const v2d*>(L + (oj + 16 * Jb + li) * ld + op + 8 * kg + 2 * lq);
+                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, acc[Jb], 0, 0, 0);
+                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, acc[Jb], 0, 0, 0);
+            }
+        }
+    }
+    double* tw = Ts + (16 * wave) * TLD;           // this wave's strip of the LDS tile
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            tw[(lq + 4 * q) * TLD + 16 * Jb + li] = S[(R0 + lq + 4 * q) * ld + oj + 16 * Jb + li] - acc[Jb][q];
+    // (LDS operations of one wave are served in order: the strip is read back by the wave that wrote it)
+    // ---- L[r,j] = T X_jj^T ; X lower triangular: column block Jb needs the k groups 0 .. 2 Jb + 1
+    v2d tf[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) tf[kg] = *reinterpret_cast<const v2d*>(tw + li * TLD + 8 * kg + 2 * lq);
+    v4d lo[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        lo[Jb] = zero;
+#pragma unroll
+        for (int kg = 0; kg < 2 * Jb + 2; ++kg) {
+            const v2d x = *reinterpret_cast<const v2d*>(X + (oj + 16 * Jb + li) * ld + oj + 8 * kg + 2 * lq);
+            lo[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kg].x, x.x, lo[Jb], 0, 0, 0);
+            lo[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kg].y, x.y, lo[Jb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L[(R0 + lq + 4 * q) * ld + oj + 16 * Jb + li] = lo[Jb][q];
+    }
+    if (!(pa.update_next_diag && blockIdx.x == 0)) return;
+    // ---- S[j+1,j+1] -= sum_{p = j0}^{j} L[j+1,p] L[j+1,p]^T  (lower 16 x 16 blocks; r == j + 1 here)
+    // the fresh column p = j comes from LDS (every wave's strip of L[j+1,j]), the earlier ones from L2
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tw[(lq + 4 * q) * TLD + 16 * Jb + li] = lo[Jb][q];
+    __syncthreads();
+    v4d d[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) d[Jb] = zero;
+    const int64_t C0 = (int64_t)r * 64;
+    for (int p = pa.j0; p < pa.j; ++p) {
+        const int64_t op = (int64_t)p * 64;
+        v2d a[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(L + (R0 + li) * ld + op + 8 * kg + 2 * lq);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb <= wave) {
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    const v2d b = *reinterpret_cast<const v2d*>(L + (C0 + 16 * Jb + li) * ld + op + 8 * kg + 2 * lq);
+                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, d[Jb], 0, 0, 0);
+                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, d[Jb], 0, 0, 0);
+                }
+            }
+        }
+    }
+    {
+        v2d a[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(tw + li * TLD + 8 * kg + 2 * lq);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb <= wave) {
+#pragma unroll
+                for (int kg = 0; kg < 8; ++kg) {
+                    const v2d b = *reinterpret_cast<const v2d*>(Ts + (16 * Jb + li) * TLD + 8 * kg + 2 * lq);
+                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, d[Jb], 0, 0, 0);
+                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, d[Jb], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        if (Jb <= wave) {
+            double* cg = S + R0 * ld + C0 + 16 * Jb;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cg[(int64_t)(lq + 4 * q) * ld + li] -= d[Jb][q];
+        }
+    }
+}
+
 constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
 
 // Stand-alone tile kernel (tests): S (ld 64) -> L, X.

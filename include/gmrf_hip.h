@@ -269,7 +269,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * panel step also for batch 1; bit 2: keep 64-multiples of right-hand sides on sweep_mm;
  * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse; bit 4: second
  * branch in the captured factor graph (inverse assembly beside the panel chain; experiment); bit 5:
- * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc). */
+ * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc); bit 6:
+ * batches factor a panel left-looking (tile + potrf_panel_ll launches; measured slower, kept for comparison). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 

@@ -1010,7 +1010,7 @@ def test_darcy_stiffness_assembly_on_device(pkg):
         vals, f = d.assemble(table, beta=2.0)
         assert np.array_equal(d.pattern.indices, Go.indices)
         assert np.max(np.abs(vals - Go.data)) < 1e-14 * np.max(np.abs(Go.data))
-        assert np.max(np.abs(f - fo)) < 1e-15 * np.max(np.abs(fo))
+        assert np.max(np.abs(f - fo)) < 1e-14 * np.max(np.abs(fo))      # six cell shares per node, summed in cell order
         vd, fd = d.assemble(torch.from_numpy(table).cuda(), beta=2.0)          # device-resident table and outputs
         assert vd.is_cuda and np.array_equal(vd.cpu().numpy(), vals) and np.array_equal(fd.cpu().numpy(), f)
     # rectangular mesh, another table size
@@ -1018,7 +1018,7 @@ def test_darcy_stiffness_assembly_on_device(pkg):
     g2 = np.linspace(0.0, 1.0, 50)
     Go, fo = O.assemble_darcy_diff_matrix(40, 24, g2, g2, tab2, 1.0)
     v2, f2 = pkg.DarcyP1Assembler(40, 24).assemble(tab2)
-    assert np.max(np.abs(v2 - Go.data)) < 1e-14 * np.max(np.abs(Go.data)) and np.max(np.abs(f2 - fo)) < 1e-15
+    assert np.max(np.abs(v2 - Go.data)) < 1e-14 * np.max(np.abs(Go.data)) and np.max(np.abs(f2 - fo)) < 1e-14 * np.max(np.abs(fo))
     # the problem loop of scripts/darcy/solve_darcy_gmrf-fem.jl:176-190 from the coefficient table on
     n, N, q_eps = 32, 8, 1e8
     Q0, _, _ = pkg.workloads.darcy_conditioning(n)
@@ -1041,3 +1041,37 @@ def test_darcy_stiffness_assembly_on_device(pkg):
         Go, fo = O.assemble_darcy_diff_matrix(n, n, gq, gq, table, 1.0)
         _, _, mu_o = O.condition_on_observations(Q0, None, Go, q_eps, fo, N)
         assert mu.is_cuda and rel(mu.cpu().numpy(), mu_o) < solve_tol(w)
+
+
+def test_left_looking_panels_of_batches(pkg):
+    """Opt-in (set_eager bit 6): batches factor each 256-column panel LEFT-looking (tile + potrf_panel_ll per
+    64-column step: the panel's earlier columns are applied to a column when it is formed, the next diagonal
+    tile is brought up to date by the workgroup below it).  Against the oracle, and against the default
+    right-looking form (tile, panel, update) to rounding, for blocks of 4 tiles (one panel), 8 tiles (two
+    panels) and padded blocks."""
+    for name, nb in (("darcy64", 4), ("burgers512x64", 2)):
+        w = pkg.workloads.make(name)
+        vals = np.stack([w.Q.data * (1.0 + 0.25 * p) for p in range(nb)])
+        rhs = np.stack([w.rhs] * nb)
+        Fo = O.tridiagonal_cholesky(w.Q, w.n_blocks)
+        res = {}
+        for flags in (0, 64):
+            F = pkg.TridiagonalCholeskyFactor(batch=nb)
+            F.set_eager(flags)
+            F.factor(w.Q, w.n_blocks, values=vals)
+            mu = F.solve_batch(rhs[:, None, :])[:, 0, :]
+            F.select_problem(0)
+            res[flags] = (mu, F.chos[w.n_blocks - 1].copy(), F.logdet())
+            assert np.max(np.abs(np.tril(res[flags][1]) - Fo.chos[-1])) / np.max(np.abs(Fo.chos[-1])) < TOL_FACTOR
+            assert rel(mu[0], O.ldiv(Fo, w.rhs)) < solve_tol(w)
+            assert rel(mu[nb - 1], O.ldiv(Fo, w.rhs) / (1.0 + 0.25 * (nb - 1))) < solve_tol(w)
+        assert np.max(np.abs(res[0][1] - res[64][1])) / np.max(np.abs(Fo.chos[-1])) < 1e-12
+        assert abs(res[0][2] - res[64][2]) < 1e-11 * abs(res[0][2])
+    # padded blocks (bs = 520 -> 1024: 16 tiles, four panels), three problems
+    w = pkg.workloads.random_block_tridiagonal(3, 520, seed=31, density=0.012)
+    Fb = pkg.TridiagonalCholeskyFactor(batch=3)
+    Fb.set_eager(64)
+    Fb.factor(w.Q, 3, values=np.stack([w.Q.data] * 3))
+    Fo = O.tridiagonal_cholesky(w.Q, 3)
+    Fb.select_problem(2)
+    assert np.max(np.abs(np.tril(Fb.chos[2]) - Fo.chos[2])) / np.max(np.abs(Fo.chos[2])) < TOL_FACTOR
