@@ -165,6 +165,8 @@ struct gmrf_handle {
     bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
     bool no_staircase = false;         // treat the coupling window as dense (comparison; takes effect at the next analysis)
     bool left_looking = false;         // batches: left-looking in-panel steps (tile + potrf_panel_ll) instead of tile, panel, update
+    bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
+    bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -630,6 +632,38 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     if (overlap && !h->aux) HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (overlap) { GCHK(fork_event(h, &ev_fork)); GCHK(fork_event(h, &ev_join)); }
+    if (fused && !h->no_lookahead && !h->doubling_x && !overlap && nt >= 2) {
+        // One problem, look-ahead chain (potrf_step, `lookahead`): tile 0 alone, then per step j ONE launch in which
+        // workgroup 0 forms L[j+1,j], updates tile (j+1,j+1) in LDS and factors it for the next launch while the other
+        // workgroups do panel + update of their tiles with the X_jj the previous launch left; the tiles of row j of
+        // the inverse ride along (xrow_strip), its last row gets the launch at the end.
+        StepArgs sa;
+        sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.nt = nt; sa.cend = nt;
+        sa.info = h->d_info; sa.blk = blk_id; sa.dbg = nullptr;
+        sa.pS = (int64_t)bsp * bsp; sa.pL = stride_pL(h); sa.pX = stride_pX(h); sa.blk_per_problem = (int)h->N;
+        const double t3 = 64.0 * 64.0 * 64.0;
+        {
+            sa.j = 0; sa.lookahead = 0; sa.xrow = -1;
+            ProfScope ps(h, 1, t3 / 3.0);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(1, 1), dim3(256), POTRF_TILE_LDS, h->stream, sa);
+        }
+        for (int j = 0; j + 1 < nt; ++j) {
+            const int m = nt - j - 1, ntile_wg = m * (m + 1) / 2;
+            sa.j = j; sa.lookahead = 1;
+            sa.xrow = (j >= 1) ? j : -1; sa.xrow_first = ntile_wg;
+            const int nx_wg = (j >= 1) ? 4 * j : 0;
+            const double f_x = (j >= 1) ? 2.0 * t3 * (0.5 * (double)j * (j + 1) + 0.625 * j) : 0.0;
+            ProfScope ps(h, 1, t3 / 3.0 + (double)m * t3 + 2.0 * t3 * ntile_wg + f_x);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(ntile_wg + nx_wg, 1), dim3(256), POTRF_STEP_LDS, h->stream, sa);
+        }
+        {
+            sa.j = nt - 1; sa.lookahead = 0; sa.xrow = nt - 1; sa.xrow_first = 0;
+            ProfScope ps(h, 1, 2.0 * t3 * (0.5 * (double)(nt - 1) * nt + 0.625 * (nt - 1)));
+            hipLaunchKernelGGL(potrf_step<false>, dim3(4 * (nt - 1), 1), dim3(256), 64 * 18 * sizeof(double), h->stream, sa);
+        }
+        HIPCHK(hipGetLastError());
+        return GMRF_OK;
+    }
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
@@ -644,9 +678,17 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const double f_tile = 64.0 * 64.0 * 64.0 / 3.0 * nb, f_panel = rem * 64.0 * 64.0 * nb;
         const double f_upd = 2.0 * 64.0 * 64.0 * 64.0 * utiles * nb;
         if (fused || m == 0) {
-            ProfScope ps(h, 1, f_tile + f_panel + f_upd);
-            hipLaunchKernelGGL(potrf_step<false>, dim3(1 + m * (m + 1) / 2, (unsigned)h->B), dim3(256),
+            // one problem, fused steps: the tiles of row j - 1 of the inverse ride in the launch of step j (4 workgroups
+            // per tile on CUs the step leaves idle; see xrow_strip), the last row gets a launch of its own below
+            const bool xrows = fused && !h->doubling_x && !overlap && j >= 2;
+            const int ntile_wg = 1 + m * (m + 1) / 2;
+            sa.xrow = xrows ? j - 1 : -1; sa.xrow_first = ntile_wg;
+            const int nx_wg = xrows ? 4 * (j - 1) : 0;
+            const double f_x = xrows ? 2.0 * 64.0 * 64.0 * 64.0 * (0.5 * (double)(j - 1) * j + 0.625 * (j - 1)) : 0.0;
+            ProfScope ps(h, 1, f_tile + f_panel + f_upd + f_x);
+            hipLaunchKernelGGL(potrf_step<false>, dim3(ntile_wg + nx_wg, (unsigned)h->B), dim3(256),
                                m == 0 ? POTRF_TILE_LDS : POTRF_STEP_LDS, h->stream, sa);
+            sa.xrow = -1;
         } else if (fused_in_panel && utiles > 0) {
             // the workgroups of column j+1 write the whole panel L[j+1.., j]
             ProfScope ps(h, 1, f_tile + f_panel + f_upd);
@@ -704,6 +746,20 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             h->gemm_stream = nullptr;
             GCHK(st);
         }
+    }
+    if (fused && !h->doubling_x && !overlap) {
+        // the inverse was assembled row by row inside the step launches; its last row is what is left
+        if (nt >= 2) {
+            StepArgs sa;
+            sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = nt - 1; sa.nt = nt;
+            sa.info = h->d_info; sa.blk = blk_id; sa.dbg = nullptr;
+            sa.pS = (int64_t)bsp * bsp; sa.pL = stride_pL(h); sa.pX = stride_pX(h); sa.blk_per_problem = (int)h->N;
+            sa.cend = nt; sa.xrow = nt - 1; sa.xrow_first = 0;
+            ProfScope ps(h, 1, 2.0 * 64.0 * 64.0 * 64.0 * (0.5 * (double)(nt - 1) * nt + 0.625 * (nt - 1)));
+            hipLaunchKernelGGL(potrf_step<false>, dim3(4 * (nt - 1), 1), dim3(256), 64 * 18 * sizeof(double), h->stream, sa);
+            HIPCHK(hipGetLastError());
+        }
+        return GMRF_OK;
     }
     // X = L^-1 by recursive doubling over the 64-wide diagonal inverses (the part not done beside
     // the panel chain above)
@@ -1073,6 +1129,8 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 16) != 0) != h->fork_graph) { destroy_graphs(h); h->fork_graph = (eager & 16) != 0; }
     h->no_staircase = (eager & 32) != 0;
     if (((eager & 64) != 0) != h->left_looking) { destroy_graphs(h); h->left_looking = (eager & 64) != 0; }
+    if (((eager & 128) != 0) != h->doubling_x) { destroy_graphs(h); h->doubling_x = (eager & 128) != 0; }
+    if (((eager & 256) != 0) != h->no_lookahead) { destroy_graphs(h); h->no_lookahead = (eager & 256) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -1921,7 +1979,7 @@ static gmrf_status spmm_plan(gmrf_csr* m) {
     std::vector<int32_t> tmp;
     // the tallest tile whose LDS image (distinct rows of X for 16 right-hand sides + the entries) lets three
     // workgroups share a CU; a matrix whose 16-row tiles do not fit keeps the plain kernel
-    const size_t lds_budget = 52 * 1024;
+    static const size_t lds_budget = [] { const char* e = getenv("GMRF_SPMM_LDS_KB"); return (size_t)(e ? atoi(e) : 52) * 1024; }();   // tuning aid
     m->plan_state = -1;
     for (int R : {64, 32, 16}) {
         const int64_t T = (m->n_rows + R - 1) / R;
@@ -1967,7 +2025,8 @@ static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const dou
                                     int64_t ldy, int k, const double* vals_override = nullptr) {
     gmrf_csr* m = const_cast<gmrf_csr*>(S);
     GCHK(spmm_plan(m));
-    const bool aligned = (k % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_X) % 16 == 0) && (((uintptr_t)d_Y) % 16 == 0);
+    const bool aligned = (k % 2 == 0) && (ldx % 2 == 0) && (ldy % 2 == 0) && (((uintptr_t)d_X) % 16 == 0) && (((uintptr_t)d_Y) % 16 == 0) &&
+                         (S->n_cols * ldx < ((int64_t)1 << 32));
     if (m->plan_state == 1 && aligned) {
         const int R = m->plan_rows, uc = m->plan_ucap, ec = m->plan_ecap;
         const dim3 grid((unsigned)((S->n_rows + R - 1) / R));

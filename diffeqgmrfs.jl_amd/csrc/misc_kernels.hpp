@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
 // staged; accumulation is fp64 either way.
 constexpr int SPMM_KC = 16;               // right-hand sides per chunk (one 128-byte line per row of X)
 constexpr int SPMM_XLD = 18;              // LDS row stride of the staged X rows (16-byte aligned, spreads banks)
-constexpr int SPMM_NG = 10;               // gather loads per thread and chunk: up to 320 distinct columns per tile
+constexpr int SPMM_NG = 10;               // most gather loads per thread and chunk: up to 320 distinct columns per tile
 
 inline size_t spmm_tile_lds_bytes(int R, int ucap, int ecap) {
     return (size_t)ucap * SPMM_XLD * 8 + (size_t)ecap * 8 + (size_t)ecap * 2 + (size_t)ucap * 4 + (size_t)(R + 1) * 4 + 16;
@@ -399,20 +399,47 @@ __global__ __launch_bounds__(SPMM_THREADS) void csr_spmm_tiles(const int64_t* __
             const int end = rp[min(row + 1, R)];
             v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
             const double* xk = xs + 4 * kq;
+#define GMRF_SPMM_FMA(V, XA, XB)                                                                                  \
+    a01.x = fma(V, XA.x, a01.x); a01.y = fma(V, XA.y, a01.y); a23.x = fma(V, XB.x, a23.x); a23.y = fma(V, XB.y, a23.y);
+            // four entries per turn: 4 index + 4 value + 8 sixteen-byte X reads in flight before the first product (the
+            // index -> X read chain is ~130 cycles of LDS latency; with three workgroups per CU nothing else hides it)
+            for (; e + 8 <= end; e += 8) {
+                int ii[8];
+                double vv[8];
+                v2d xa[8], xb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { ii[u] = ls[e + u]; vv[u] = vs[e + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    xa[u] = *reinterpret_cast<const v2d*>(xk + ii[u] * SPMM_XLD);
+                    xb[u] = *reinterpret_cast<const v2d*>(xk + ii[u] * SPMM_XLD + 2);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { GMRF_SPMM_FMA(vv[u], xa[u], xb[u]) }
+            }
+            for (; e + 4 <= end; e += 4) {
+                const int i0 = ls[e], i1 = ls[e + 1], i2 = ls[e + 2], i3 = ls[e + 3];
+                const double v0 = vs[e], v1 = vs[e + 1], v2 = vs[e + 2], v3 = vs[e + 3];
+                const v2d x0a = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD), x0b = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD + 2);
+                const v2d x1a = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD), x1b = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD + 2);
+                const v2d x2a = *reinterpret_cast<const v2d*>(xk + i2 * SPMM_XLD), x2b = *reinterpret_cast<const v2d*>(xk + i2 * SPMM_XLD + 2);
+                const v2d x3a = *reinterpret_cast<const v2d*>(xk + i3 * SPMM_XLD), x3b = *reinterpret_cast<const v2d*>(xk + i3 * SPMM_XLD + 2);
+                GMRF_SPMM_FMA(v0, x0a, x0b) GMRF_SPMM_FMA(v1, x1a, x1b) GMRF_SPMM_FMA(v2, x2a, x2b) GMRF_SPMM_FMA(v3, x3a, x3b)
+            }
             for (; e + 2 <= end; e += 2) {
                 const int i0 = ls[e], i1 = ls[e + 1];
                 const double v0 = vs[e], v1 = vs[e + 1];
                 const v2d x0a = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD), x0b = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD + 2);
                 const v2d x1a = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD), x1b = *reinterpret_cast<const v2d*>(xk + i1 * SPMM_XLD + 2);
-                a01.x = fma(v0, x0a.x, a01.x); a01.y = fma(v0, x0a.y, a01.y); a23.x = fma(v0, x0b.x, a23.x); a23.y = fma(v0, x0b.y, a23.y);
-                a01.x = fma(v1, x1a.x, a01.x); a01.y = fma(v1, x1a.y, a01.y); a23.x = fma(v1, x1b.x, a23.x); a23.y = fma(v1, x1b.y, a23.y);
+                GMRF_SPMM_FMA(v0, x0a, x0b) GMRF_SPMM_FMA(v1, x1a, x1b)
             }
             if (e < end) {
                 const int i0 = ls[e];
                 const double v0 = vs[e];
                 const v2d x0a = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD), x0b = *reinterpret_cast<const v2d*>(xk + i0 * SPMM_XLD + 2);
-                a01.x = fma(v0, x0a.x, a01.x); a01.y = fma(v0, x0a.y, a01.y); a23.x = fma(v0, x0b.x, a23.x); a23.y = fma(v0, x0b.y, a23.y);
+                GMRF_SPMM_FMA(v0, x0a, x0b)
             }
+#undef GMRF_SPMM_FMA
             if (row < nr) {
                 double* yp = Y + (r0 + row) * ldy + kc0 + 4 * kq;
                 if (kc0 + 4 * kq + 4 <= k && (ldy & 1) == 0) {

@@ -342,7 +342,62 @@ struct StepArgs {
     int blk_per_problem;  // reported id = blk + blockIdx.y * blk_per_problem
     int cend;             // potrf_update: column tiles j+1 .. cend-1 only (nt: the whole trailing block)
     unsigned long long* dbg;   // diagnostic stamps of workgroup 1 of step 0 (tests), else nullptr
+    // One problem: the inverse Linv is assembled ROW BY ROW beside the panel steps instead of by recursive
+    // doubling afterwards (8 dependent launches per block off the chain): workgroups xrow_first .. of the
+    // launch of step j compute the tiles X[xrow, c], c < xrow, of row xrow = j - 1, whose inputs (L[xrow, :],
+    // the rows of X above, X[xrow, xrow]) are final by then.  xrow < 0: none.
+    int xrow = -1;
+    int xrow_first = 0;        // first blockIdx.x of the X-row workgroups (4 per tile: 16-column strips)
+    // One problem, look-ahead form of the fused step: the diagonal tile j was factored by the PREVIOUS launch (its
+    // L_jj, X_jj are in global memory), nobody re-factors it; workgroup 0 owns tile (j+1, j+1): it forms L[j+1,j],
+    // updates its tile in LDS and factors it for the next launch, while the other workgroups do panel + update of
+    // theirs.  The chain per step is  update (j+1,j+1) -> factor  instead of  factor -> update everything.
+    int lookahead = 0;
 };
+
+// X[r, c][:, strip] = -X_rr * sum_{p = c}^{r-1} L[r, p] X[p, c][:, strip]   (block forward substitution: only the
+// diagonal inverses multiply, like inside the tile).  One workgroup per 64 x 16 output strip: wave w forms rows
+// 16 w .. of the sum (operands straight from L2), the four strips meet in LDS for the product with X_rr.
+__device__ __forceinline__ void xrow_strip(const StepArgs& sa, int q, double* sm) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld;
+    const int r = sa.xrow, c = q >> 2, cs = q & 3;
+    const int64_t orow = (int64_t)r * 64, ocol = (int64_t)c * 64 + 16 * cs;
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ arow = sa.L + (orow + 16 * wave + li) * ld;
+    for (int p = c; p < r; ++p) {
+        const int64_t op = (int64_t)p * 64;
+        v2d a[8];
+        double b0[8], b1[8];
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            a[kg] = *reinterpret_cast<const v2d*>(arow + op + 8 * kg + 2 * lq);
+            b0[kg] = sa.X[(op + 8 * kg + 2 * lq) * ld + ocol + li];
+            b1[kg] = sa.X[(op + 8 * kg + 2 * lq + 1) * ld + ocol + li];
+        }
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b0[kg], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b1[kg], acc, 0, 0, 0);
+        }
+    }
+    constexpr int XL = 18;                                   // LDS image T[64][16] with row stride 18
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) sm[(16 * wave + lq + 4 * qq) * XL + li] = acc[qq];
+    __syncthreads();
+    // rows 16 w .. of  -X_rr T ; X_rr lower triangular: k groups 0 .. 2 w + 1
+    v4d res = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* __restrict__ xrr = sa.X + (orow + 16 * wave + li) * ld + orow;
+    for (int kg = 0; kg < 2 * wave + 2; ++kg) {
+        const v2d xv = *reinterpret_cast<const v2d*>(xrr + 8 * kg + 2 * lq);
+        res = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.x, sm[(8 * kg + 2 * lq) * XL + li], res, 0, 0, 0);
+        res = __builtin_amdgcn_mfma_f64_16x16x4f64(xv.y, sm[(8 * kg + 2 * lq + 1) * XL + li], res, 0, 0, 0);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) sa.X[(orow + 16 * wave + lq + 4 * qq) * ld + ocol + li] = -res[qq];
+}
+
 
 // Fused panel step: grid.x = 1 + m (m + 1) / 2, m = nt - j - 1  (cend < nt: 1 + the tiles of columns
 // j+1 .. cend-1 only; the rest of the trailing block is updated per panel by the GEMM kernel).  Workgroup 0 factors and inverts
@@ -357,6 +412,10 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     sa.X += (int64_t)blockIdx.y * sa.pX;
     sa.blk += (int)blockIdx.y * sa.blk_per_problem;
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if (sa.xrow >= 0 && (int)blockIdx.x >= sa.xrow_first) {          // X-row role (one problem, fused steps)
+        xrow_strip(sa, (int)blockIdx.x - sa.xrow_first, smem);
+        return;
+    }
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
     // the tile-only launch (grid.x = 1) allocates up to here only (POTRF_TILE_LDS): with 75 KB instead
@@ -374,7 +433,13 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
 
     int r = 0, c = 0;
     const int w = (int)blockIdx.x;
-    if (w > 0) {
+    const bool la = sa.lookahead != 0;
+    if (la) {                                    // every workgroup owns a tile of the trailing block; 0 -> (j+1, j+1)
+        int t = w, rr = 0;
+        while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+        r = sa.j + 1 + rr;
+        c = sa.j + 1 + (t - rr * (rr + 1) / 2);
+    } else if (w > 0) {
         if (sa.cend >= sa.nt) {                  // the whole trailing block, row by row
             int t = w - 1, rr = 0;
             while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
@@ -387,32 +452,40 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
             r = c + t;
         }
     }
-    tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
     // the C tile this wave will update (rows 16*wave.., MFMA C/D layout), fetched now, used last
     double* Sg = sa.S + (int64_t)r * 64 * ld + (int64_t)c * 64;
     v4d cpre[4];
-    if (w > 0) {
+    if (w > 0 || la) {
 #pragma unroll
         for (int Jb = 0; Jb < 4; ++Jb)
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 cpre[Jb][q] = Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li];
     }
-    SideLoad side;
-    side.gA = (w > 0) ? sa.S + (int64_t)r * 64 * ld + oj : nullptr; side.sA = As;
-    side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
-    side.ld = ld; side.stamps = nullptr;
-    __syncthreads();
-    const bool stamp = sa.dbg && sa.j == 0 && w == 1 && tid == 0 && blockIdx.y == 0;
-    if (stamp) sa.dbg[0] = __builtin_amdgcn_s_memtime();
     bool bad = false;
-    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
-    if (stamp) sa.dbg[1] = __builtin_amdgcn_s_memtime();
-    if (w == 0) {
-        if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
-        tile_s2g(Ts, sa.L + oj * ld + oj, ld, tid);
-        tile_s2g(Xs, sa.X + oj * ld + oj, ld, tid);
-        return;
+    const bool stamp = !la && sa.dbg && sa.j == 0 && w == 1 && tid == 0 && blockIdx.y == 0;
+    if (la) {
+        // X_jj of the previous launch and this workgroup's panel tiles: three independent tile loads
+        tile_g2s(sa.X + oj * ld + oj, ld, Xs, tid);
+        tile_g2s(sa.S + (int64_t)r * 64 * ld + oj, ld, As, tid);
+        if (c != r) tile_g2s(sa.S + (int64_t)c * 64 * ld + oj, ld, Bs, tid);
+        __syncthreads();
+    } else {
+        tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
+        SideLoad side;
+        side.gA = (w > 0) ? sa.S + (int64_t)r * 64 * ld + oj : nullptr; side.sA = As;
+        side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
+        side.ld = ld; side.stamps = nullptr;
+        __syncthreads();
+        if (stamp) sa.dbg[0] = __builtin_amdgcn_s_memtime();
+        tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+        if (stamp) sa.dbg[1] = __builtin_amdgcn_s_memtime();
+        if (w == 0) {
+            if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
+            tile_s2g(Ts, sa.L + oj * ld + oj, ld, tid);
+            tile_s2g(Xs, sa.X + oj * ld + oj, ld, tid);
+            return;
+        }
     }
     // ---- panel rows: Lr = As Xs^T, Lc = Bs Xs^T.  k runs outermost in groups of 8: a lane fetches
     // two consecutive k of its operand row with ONE ds_read_b128 (every LDS instruction issued
@@ -473,6 +546,27 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
         }
     }
     if (stamp) sa.dbg[4] = __builtin_amdgcn_s_memtime();
+    if (la && w == 0) {
+        // look-ahead: the updated tile (j+1, j+1) stays in LDS and is factored here, for the next launch
+        __syncthreads();                                   // (Ts is free: nothing of this launch lives there)
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb < jb_end) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    Ts[(16 * wave + lq + 4 * q) * TLD + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
+            }
+        }
+        __syncthreads();
+        SideLoad none;
+        none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+        tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+        if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
+        const int64_t o1 = oj + 64;
+        tile_s2g(Ts, sa.L + o1 * ld + o1, ld, tid);
+        tile_s2g(Xs, sa.X + o1 * ld + o1, ld, tid);
+        return;
+    }
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
         if (Jb < jb_end) {

@@ -270,7 +270,9 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse; bit 4: second
  * branch in the captured factor graph (inverse assembly beside the panel chain; experiment); bit 5:
  * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc); bit 6:
- * batches factor a panel left-looking (tile + potrf_panel_ll launches; measured slower, kept for comparison). */
+ * batches factor a panel left-looking (tile + potrf_panel_ll launches; measured slower, kept for comparison); bit 7:
+ * one problem assembles Linv by recursive doubling after the panel steps instead of row by row inside them; bit 8:
+ * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain. */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 

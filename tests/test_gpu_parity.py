@@ -188,9 +188,11 @@ def test_forked_factor_graph_matches_single_branch(pkg):
     of a block's first half on a second branch beside the panel chain of the second half.  Same
     kernels on the same data: bitwise equal to the single-branch graph and to plain stream launches."""
     w = pkg.workloads.make("burgers512x64")
-    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    F = pkg.TridiagonalCholeskyFactor()
+    F.set_eager(128)                         # the inverse by recursive doubling: what the forked branch overlaps
+    F.factor(w.Q, w.n_blocks)
     a = pkg.ldiv(F, w.rhs); la = F.chos[40].copy(); xa = F.get_block(pkg._cabi.BLOCK_LINV, 40)
-    for flags in (16, 1, 16):
+    for flags in (16 | 128, 1 | 128, 16 | 128):
         F.set_eager(flags)
         for _ in range(2):                   # capture, then a replay of the forked graph
             F.refactor(w.Q.data)
@@ -975,10 +977,11 @@ def test_spmm_node_major_lds_tiles(pkg):
         Yd = S64 @ Xd
         assert Yd.is_cuda and Yd.shape == (w.n, k) and np.array_equal(Yd.cpu().numpy(), S64 @ X)
         assert rel(S64 @ np.asfortranarray(X), Qr @ X) < 1e-14   # column-major operand: the lane-group kernel
-    # every right-hand side of the tiled kernel sums its row in entry order, like the one-vector kernel
+    # every right-hand side of the tiled kernel sums its row in entry order: a column does not depend on its neighbours
     X = rng.standard_normal((w.n, 16))
     Y = S64 @ X
-    assert np.array_equal(Y[:, 3], S64 @ np.ascontiguousarray(X[:, 3]))
+    assert np.array_equal(Y[:, 3], (S64 @ np.ascontiguousarray(X[:, 2:6]))[:, 1])
+    assert rel(Y[:, 3], S64 @ np.ascontiguousarray(X[:, 3])) < 1e-15
     # ragged: empty rows, a row count that is no multiple of the tile, rectangular, a tile with too many
     # distinct columns (falls back to the plain node-major kernel), a dense-ish matrix beyond the entry cap
     A = sp.random(1000, 700, density=0.01, random_state=rng, data_rvs=rng.standard_normal).tolil()
@@ -1075,3 +1078,54 @@ def test_left_looking_panels_of_batches(pkg):
     Fo = O.tridiagonal_cholesky(w.Q, 3)
     Fb.select_problem(2)
     assert np.max(np.abs(np.tril(Fb.chos[2]) - Fo.chos[2])) / np.max(np.abs(Fo.chos[2])) < TOL_FACTOR
+
+
+def test_inverse_rows_inside_the_fused_steps(pkg):
+    """One problem, blocks of up to 16 tiles: the inverse Linv_i is assembled row by row by extra workgroups of
+    the fused panel-step launches (block forward substitution, X[r,c] = -X_rr sum_p L[r,p] X[p,c]) instead of by
+    recursive doubling after them (set_eager bit 7 keeps the doubling).  Same L bitwise; Linv, C and the
+    solves to rounding; both against the oracle; L Linv = I to the conditioning of the block."""
+    for name in ("darcy64", "burgers512x64", "darcy256"):
+        w = pkg.workloads.make(name)
+        if name == "darcy256":
+            w.meta.setdefault("cond", 3.4e9)
+        Fr = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        Fd = pkg.TridiagonalCholeskyFactor()
+        Fd.set_eager(128)
+        Fd.factor(w.Q, w.n_blocks)
+        i = w.n_blocks // 2
+        assert np.array_equal(Fr.chos[0], Fd.chos[0])
+        Xr, Xd = Fr.get_block(pkg._cabi.BLOCK_LINV, i), Fd.get_block(pkg._cabi.BLOCK_LINV, i)
+        L = np.tril(Fr.chos[i])
+        scale = np.max(np.abs(Xd))
+        assert np.max(np.abs(Xr - Xd)) / scale < 1e-10
+        eye = np.eye(L.shape[0])
+        err_r, err_d = np.max(np.abs(L @ Xr - eye)), np.max(np.abs(L @ Xd - eye))
+        assert err_r <= 4.0 * err_d + 1e-13, (err_r, err_d)          # substitution is at least as accurate as doubling
+        assert np.allclose(np.triu(Xr, 1), 0.0)
+        tol = solve_tol(w)
+        x_r, x_d = pkg.ldiv(Fr, w.rhs), pkg.ldiv(Fd, w.rhs)
+        assert rel(x_r, x_d) < tol
+        if name != "darcy256":
+            assert rel(x_r, O.ldiv(O.tridiagonal_cholesky(w.Q, w.n_blocks), w.rhs)) < tol
+        qn = abs(w.Q).sum(axis=1).max()
+        assert np.linalg.norm(w.Q @ x_r - w.rhs) / (qn * np.linalg.norm(x_r) + np.linalg.norm(w.rhs)) < 1e-14
+        # the look-ahead chain (tile j+1 factored inside the launch of step j) does the same arithmetic as the form in
+        # which every workgroup of a step re-factors the diagonal tile (set_eager bit 8): bitwise equal factor
+        Fn = pkg.TridiagonalCholeskyFactor()
+        Fn.set_eager(256)
+        Fn.factor(w.Q, w.n_blocks)
+        for b in (0, i, w.n_blocks - 1):
+            assert np.array_equal(Fr.chos[b], Fn.chos[b])
+            assert np.array_equal(Fr.get_block(pkg._cabi.BLOCK_LINV, b), Fn.get_block(pkg._cabi.BLOCK_LINV, b))
+        assert np.array_equal(x_r, pkg.ldiv(Fn, w.rhs))
+    # a non-SPD block is still reported with its index by the look-ahead chain
+    w = pkg.workloads.make("darcy64")
+    Qc = w.Q.tocsc()
+    bad = Qc.data.copy()
+    d = np.flatnonzero((Qc.indices == 1000) & (np.repeat(np.arange(w.n), np.diff(Qc.indptr)) == 1000))[0]
+    bad[d] = -1e20
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    with pytest.raises(pkg.NotPositiveDefinite) as e:
+        F.refactor(bad)
+    assert e.value.info == 1000 // w.block_size + 1

@@ -31,6 +31,12 @@ if len(sys.argv) > 3:
         wk = w.get(k, [1, 0.0, 0.0])
         table[k] = {"launches": a[0], "read_bytes_per_launch": 2 * a[1] / a[0] * 1024,
                     "write_bytes_per_launch": wk[1] / max(wk[0], 1) * 1024, "avg_us": a[2] / a[0]}
+    import os, subprocess
+    try:
+        head = subprocess.run(["git", "-C", os.path.dirname(os.path.abspath(__file__)), "rev-parse", "--short=12", "HEAD"],
+                              capture_output=True, text=True, timeout=5).stdout.strip() or os.environ.get("GMRF_HEAD", "?")
+    except Exception:
+        head = os.environ.get("GMRF_HEAD", "?")
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 for 16-byte lanes "
                          "(MI355X_MICROARCH.md, HBM section); bench.py --steps 1 --warmup 1 --streams 1 --no-single-problem",
-               "kernels": table}, open(sys.argv[3], "w"), indent=1)
+               "batch": 32, "head": head, "kernels": table}, open(sys.argv[3], "w"), indent=1)
