@@ -2031,9 +2031,18 @@ static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const dou
         const int R = m->plan_rows, uc = m->plan_ucap, ec = m->plan_ecap;
         const dim3 grid((unsigned)((S->n_rows + R - 1) / R));
         const size_t lds = spmm_tile_lds_bytes(R, uc, ec);
-        if (vals_override) hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, vals_override, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
-        else if (S->d_vals32) hipLaunchKernelGGL(csr_spmm_tiles<float>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, S->d_vals32, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
-        else hipLaunchKernelGGL(csr_spmm_tiles<double>, grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, S->d_vals, S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);
+        // 7 gather loads per thread and chunk serve up to 224 distinct columns per tile, 10 up to 320
+#define GMRF_SPMM_TILES(VT, VP)                                                                                          \
+        do {                                                                                                             \
+            if (uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
+                                              S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);  \
+            else hipLaunchKernelGGL((csr_spmm_tiles<VT, SPMM_NG>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP,    \
+                                    S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);            \
+        } while (0)
+        if (vals_override) GMRF_SPMM_TILES(double, vals_override);
+        else if (S->d_vals32) GMRF_SPMM_TILES(float, S->d_vals32);
+        else GMRF_SPMM_TILES(double, S->d_vals);
+#undef GMRF_SPMM_TILES
     } else {
         const dim3 grid((unsigned)((S->n_rows + 15) / 16));
         if (vals_override) hipLaunchKernelGGL(csr_spmm_rows<double>, grid, dim3(256), 0, st, S->d_rowptr, S->d_colidx, vals_override, S->n_rows, d_X, ldx, d_Y, ldy, k);

@@ -325,8 +325,8 @@ constexpr int SPMM_THREADS = 256;
 // come from L2): a lane owns FOUR right-hand sides of one row, so the index and value of an entry are
 // read once per 4 products and the X values as 16-byte pieces -- 12 LDS cycles per 256 products instead
 // of 6 per 64 with one right-hand side per lane.
-template <typename VT>
-__global__ __launch_bounds__(SPMM_THREADS) void csr_spmm_tiles(const int64_t* __restrict__ rowptr,
+template <typename VT, int NG>
+__global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles(const int64_t* __restrict__ rowptr,
                                                                const uint16_t* __restrict__ lidx,
                                                                const VT* __restrict__ vals,
                                                                const int64_t* __restrict__ tile_uptr,
@@ -368,26 +368,28 @@ __global__ __launch_bounds__(SPMM_THREADS) void csr_spmm_tiles(const int64_t* __
     __syncthreads();
     const int seg = t & 7, ub = t >> 3;                      // gather: 8 threads x 16 B per row piece, 32 rows per pass
     const int kq = t & 3, rsub = t >> 2;                     // multiply: 4 lanes x 4 right-hand sides per row, 64 rows per pass
-    // this thread's pieces of the distinct rows of X: row offsets once, the loads per chunk
-    int64_t goff[SPMM_NG];
+    // this thread's pieces of the distinct rows of X: row offsets once (units of 16 bytes, 32 bits: the host checks
+    // n_cols * ldx < 2^32 for this path), the loads per chunk
+    uint32_t goff[NG];
+    const v2d* __restrict__ X2 = reinterpret_cast<const v2d*>(X);
 #pragma unroll
-    for (int i = 0; i < SPMM_NG; ++i) {
+    for (int i = 0; i < NG; ++i) {
         const int u = ub + 32 * i;
-        goff[i] = (u < U) ? (int64_t)uc[u] * ldx + 2 * seg : (int64_t)-1;
+        goff[i] = (u < U) ? (uint32_t)(((int64_t)uc[u] * ldx) / 2 + seg) : 0xffffffffu;
     }
-    v2d g[SPMM_NG];
+    v2d g[NG];
     auto gather = [&](int kc0) {
         const bool seg_ok = kc0 + 2 * seg < k;               // k is even on this path (host checks)
 #pragma unroll
-        for (int i = 0; i < SPMM_NG; ++i) {
+        for (int i = 0; i < NG; ++i) {
             g[i] = (v2d){0.0, 0.0};
-            if (goff[i] >= 0 && seg_ok) g[i] = *reinterpret_cast<const v2d*>(X + goff[i] + kc0);
+            if (goff[i] != 0xffffffffu && seg_ok) g[i] = X2[(size_t)goff[i] + (size_t)(kc0 / 2)];
         }
     };
     gather(0);
     for (int kc0 = 0; kc0 < k; kc0 += SPMM_KC) {
 #pragma unroll
-        for (int i = 0; i < SPMM_NG; ++i) {
+        for (int i = 0; i < NG; ++i) {
             const int u = ub + 32 * i;
             if (u < U) *reinterpret_cast<v2d*>(xs + u * SPMM_XLD + 2 * seg) = g[i];
         }
@@ -403,6 +405,10 @@ __global__ __launch_bounds__(SPMM_THREADS) void csr_spmm_tiles(const int64_t* __
     a01.x = fma(V, XA.x, a01.x); a01.y = fma(V, XA.y, a01.y); a23.x = fma(V, XB.x, a23.x); a23.y = fma(V, XB.y, a23.y);
             // four entries per turn: 4 index + 4 value + 8 sixteen-byte X reads in flight before the first product (the
             // index -> X read chain is ~130 cycles of LDS latency; with three workgroups per CU nothing else hides it)
+            // 8 / 4 / 2 / 1 entries per turn: all of a turn's index -> X read chains (~130 cycles of LDS latency each) are in
+            // flight before its first product; with three workgroups per CU nothing else hides that latency
+            // (2 per turn: 833 us, 4: 729 us, 8: 697 us on the burgers4096x512 matrix at k = 64; a predicated
+            // 8-entry turn for the tail: 740 us)
             for (; e + 8 <= end; e += 8) {
                 int ii[8];
                 double vv[8];
