@@ -167,6 +167,7 @@ struct gmrf_handle {
     bool left_looking = false;         // batches: left-looking in-panel steps (tile + potrf_panel_ll) instead of tile, panel, update
     bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
+    bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -723,7 +724,14 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                 ProfScope ps(h, 8, f_panel);
                 hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
             }
-            if (utiles > 0) {
+            if (utiles > 0 && h->update_via_gemm) {
+                // experiment (set_eager bit 9): the in-panel rank-64 update on the LDS-staged GEMM kernel instead of the
+                // L2-fed potrf_update: tiles (r, c), j < c < cend, r >= c, of  S -= L[:, j] L[:, j]^T
+                const double* Lj = L + (int64_t)(j + 1) * 64 * ld + (int64_t)j * 64;
+                double* Sj = S + (int64_t)(j + 1) * 64 * ld + (int64_t)(j + 1) * 64;
+                GCHK(gemm(h, false, false, 64 * m, 64 * (cend - j - 1), 64, 0, 1, -1.0, Lj, ld, Lj, ld, 1.0, Sj, ld, sa.pL, sa.pL, sa.pS,
+                          1, 0, 0, 0, nullptr, 0, 0, 9, f_upd));
+            } else if (utiles > 0) {
                 ProfScope ps(h, 9, f_upd);
                 hipLaunchKernelGGL(potrf_update, dim3(utiles, (unsigned)h->B), dim3(256), 0, h->stream, sa);
             }
@@ -1131,6 +1139,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 64) != 0) != h->left_looking) { destroy_graphs(h); h->left_looking = (eager & 64) != 0; }
     if (((eager & 128) != 0) != h->doubling_x) { destroy_graphs(h); h->doubling_x = (eager & 128) != 0; }
     if (((eager & 256) != 0) != h->no_lookahead) { destroy_graphs(h); h->no_lookahead = (eager & 256) != 0; }
+    if (((eager & 512) != 0) != h->update_via_gemm) { destroy_graphs(h); h->update_via_gemm = (eager & 512) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
