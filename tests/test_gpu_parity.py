@@ -887,7 +887,9 @@ def test_without_the_l_blocks(pkg):
     assert e.value.status == pkg._cabi.ERR_NO_FACTOR
     with pytest.raises(pkg.GmrfError):
         F0.export_factor()
-    assert F0.stats()["factor_bytes"] < 0.6 * F1.stats()["factor_bytes"]
+    bs = w.n // w.n_blocks                                # exactly the N triangular blocks are gone
+    assert F1.stats()["factor_bytes"] - F0.stats()["factor_bytes"] == 8 * bs * bs * w.n_blocks
+    assert F0.stats()["factor_bytes"] < 0.65 * F1.stats()["factor_bytes"]
     # a batch, re-factored with new values
     vals = np.stack([w.Q.data, 2.0 * w.Q.data])
     Fb = pkg.TridiagonalCholeskyFactor(batch=2)
