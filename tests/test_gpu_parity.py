@@ -943,7 +943,7 @@ def test_factor_moves_between_handles_with_its_layout(pkg):
     Fa = pkg.tridiagonal_cholesky(wa.Q, wa.n_blocks)               # analysed pattern a ...
     Fb = pkg.tridiagonal_cholesky(wb.Q, wb.n_blocks)
     xb = pkg.ldiv(Fb, wb.rhs)
-    assert list(Fa.get_layout()[:2]) != list(Fb.get_layout()[:2])
+    assert not np.array_equal(Fa.get_layout(), Fb.get_layout())    # (same window at this size, other staircase)
     # ... then receives factor b: layout, buffers, commit
     Fa.adopt_layout(wb.n, wb.n_blocks, Fb.get_layout())
     for kind in (pkg._cabi.BLOCK_LINV, pkg._cabi.BLOCK_C):
