@@ -870,9 +870,14 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     return GMRF_OK;
 }
 
+// Stream captures of different handles (host threads) are taken one at a time: capture + instantiate is a
+// once-per-shape set-up step, and concurrent captures are the one place where handles would meet inside the runtime.
+static std::mutex g_capture_mu;
+
 static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
     if (h->eager || h->profiling) return factor_blocks_range(h, i0, i1);
     if (!h->factor_graph || h->factor_graph_i0 != i0 || h->factor_graph_i1 != i1) {
+        std::lock_guard<std::mutex> capture_lock(g_capture_mu);
         if (h->factor_graph) { (void)hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
@@ -1011,6 +1016,7 @@ static gmrf_status run_sweeps(gmrf_handle* h, int mode, int kp) {
     const int64_t key = (int64_t)mode * 4096 + kp;
     auto it = h->sweep_graphs.find(key);
     if (it == h->sweep_graphs.end()) {
+        std::lock_guard<std::mutex> capture_lock(g_capture_mu);
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
