@@ -247,6 +247,7 @@ def main():
                     help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-spmm", action="store_true", help="skip the K6 roofline leg (burgers4096x512 matrix)")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: skip the problems-mode and C4 legs")
+    ap.add_argument("--side-leg-limit", type=float, default=360.0, help="N > 1: seconds after which the side legs are abandoned")
     ap.add_argument("--eager-flags", type=int, default=0, help="gmrf_bt_set_eager bits for every handle (experiments)")
     ap.add_argument("--force-shared", action="store_true",
                     help="rehearsal: run the shared-factor code (process group, communicator, broadcasts) with a world of one rank")
@@ -359,7 +360,20 @@ def main():
         out.update(extra)
 
     # ------------------------------------------------------------------ N > 1: the other legs, same run
+    watchdog = None
     if shared and not args.no_side_legs:
+        # The side legs never cost the headline: if they overrun (a rank stuck in a collective), every rank leaves
+        # after --side-leg-limit seconds and rank 0 prints the line it already has.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["side_legs"] = {"error": f"side legs exceeded {args.side_leg_limit} s and were abandoned"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(args.side_leg_limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         # (a) the same job on ONE rank (no broadcast): what sharing the factor is compared with
         side = {}
         if rank == 0:
@@ -409,6 +423,7 @@ def main():
                                      "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
             out["side_legs"] = side
         pj.close()
+        watchdog.cancel()
 
     # ------------------------------------------------------------------ N = 1: per-kernel roofline + parity + CPU baseline
     if rank == 0 and world == 1 and not shared:
