@@ -177,8 +177,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     if (g.ke_n) ke = min(ke, g.ke_n[bn]);
 
     extern __shared__ __attribute__((aligned(16))) double gsm[];
+    const bool single = (g.tri & 2048) != 0;         // experiment: one LDS stage (half the LDS, twice the workgroups per CU)
     double* As0 = gsm;                               // [2][64 * LD]
-    double* Bs0 = gsm + 2 * GEMM_BM * LD;            // [2][64 * LD]
+    double* Bs0 = gsm + (single ? 1 : 2) * GEMM_BM * LD;            // [2][64 * LD]
 
     const int t = threadIdx.x;
     const int lane = t & 63, w = t >> 6;
@@ -203,7 +204,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
+        const int cur = single ? 0 : (kt & 1);
+        const int nxt = single ? 0 : (cur ^ 1);
         const bool more = (kt + 1 < nkt);
         if (more && !(g.tri & 512)) {
             const int k0 = kb + (kt + 1) * BK;
@@ -229,9 +231,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
             __builtin_amdgcn_sched_barrier(0);
             f = fn;
         }
+        if (single) __syncthreads();
         if (more && !(g.tri & 512)) {
-            gemm_store_tile<A_T, BK>(As0 + (cur ^ 1) * GEMM_BM * LD, t, ra);
-            gemm_store_tile<B_N, BK>(Bs0 + (cur ^ 1) * GEMM_BN * LD, t, rb);
+            gemm_store_tile<A_T, BK>(As0 + nxt * GEMM_BM * LD, t, ra);
+            gemm_store_tile<B_N, BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
         }
         if (!(g.tri & 1024)) __syncthreads();
     }
@@ -673,6 +676,12 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
         return hipGetLastError();
     }
     static const bool force_bk16 = getenv("GMRF_GEMM_BK16") != nullptr;     // tuning aid
+    // One LDS stage instead of two (two barriers per K step, half the LDS): four workgroups per CU instead of
+    // two.  Launches of more than ~1.5 rounds of tiles gain (the fixed part of a tile -- first operand loads,
+    // epilogue -- hides behind three neighbours instead of one: 1024^2 x 32 outputs, K = 64 / 128 / 256 / 1024:
+    // 26 -> 32, 38 -> 44, 47.6 -> 49.5, 53.7 -> 55.5 TF/s); single-round launches lose 2-8 % to the second barrier.
+    static const int single_env = [] { const char* e = getenv("GMRF_GEMM_SINGLE_STAGE"); return e ? atoi(e) : -1; }();   // tuning aid
+    const bool single_stage = single_env >= 0 ? single_env != 0 : grid.x > 768;
     const bool wide = (g.K % 32 == 0) && !force_bk16;
     if (gemm_uses_ll(g, batch)) {
         const int64_t lx = g.N / GEMM_LL, ly = g.M / GEMM_LL;
@@ -687,8 +696,10 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
     }
 #define GMRF_GEMM_LAUNCH(AT, BN)                                                                 \
     do {                                                                                         \
-        if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>(), st, gs); \
-        else hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 16>), grid, block, gemm_lds_bytes<16>(), st, gs);     \
+        if (single_stage) gs.tri |= 2048;                                                        \
+        const size_t ldsdiv = single_stage ? 2 : 1;                                              \
+        if (wide) hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 32>), grid, block, gemm_lds_bytes<32>() / ldsdiv, st, gs); \
+        else hipLaunchKernelGGL((gemm_f64_mfma<AT, BN, 16>), grid, block, gemm_lds_bytes<16>() / ldsdiv, st, gs);     \
     } while (0)
     if (!a_t && !b_n) GMRF_GEMM_LAUNCH(false, false);
     else if (!a_t && b_n) GMRF_GEMM_LAUNCH(false, true);
