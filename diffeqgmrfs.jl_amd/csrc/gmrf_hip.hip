@@ -94,7 +94,7 @@ struct gmrf_csr {
     int32_t* d_ucols = nullptr;        // distinct columns of every tile, ascending
     uint16_t* d_lidx = nullptr;        // per entry: index of its column in the tile's list
     int64_t n_ucols = 0;
-    int plan_rows = 0, plan_ucap = 0, plan_ecap = 0;   // rows per tile, LDS capacities (distinct columns, entries)
+    int plan_rows = 0, plan_ucap = 0, plan_ecap = 0, plan_ecap_pad = 0;   // rows per tile, LDS capacities (distinct columns, entries)
 };
 
 // ------------------------------------------------------------------------------------ handle
@@ -2001,7 +2001,7 @@ static gmrf_status spmm_plan(gmrf_csr* m) {
         uptr.assign((size_t)T + 1, 0);
         ucols.clear();
         ucols.reserve((size_t)(m->nnz / 3 + 16));
-        int64_t umax = 0, emax = 0;
+        int64_t umax = 0, emax = 0, pmax = 0;
         bool ok = true;
         for (int64_t tix = 0; tix < T && ok; ++tix) {
             const int64_t r0 = tix * R, r1 = std::min(m->n_rows, r0 + R);
@@ -2010,6 +2010,9 @@ static gmrf_status spmm_plan(gmrf_csr* m) {
             std::sort(tmp.begin(), tmp.end());
             tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
             umax = std::max<int64_t>(umax, (int64_t)tmp.size()); emax = std::max(emax, b - a);
+            int64_t padded = 0;                                  // rows padded to multiples of 8 entries (csr_spmm_tiles_pad)
+            for (int64_t r = r0; r < r1; ++r) padded += (rp[r + 1] - rp[r] + 7) / 8 * 8;
+            pmax = std::max(pmax, padded);
             if ((int64_t)tmp.size() > 32 * SPMM_NG || b - a > 8192) { ok = false; break; }
             for (int64_t e = a; e < b; ++e)
                 lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), ci[(size_t)e]) - tmp.begin());
@@ -2018,8 +2021,10 @@ static gmrf_status spmm_plan(gmrf_csr* m) {
         }
         if (!ok) continue;
         const int ucap = (int)std::max<int64_t>(32, (umax + 31) / 32 * 32), ecap = (int)std::max<int64_t>(256, (emax + 255) / 256 * 256);
+        const int ecap_pad = (int)std::max<int64_t>(256, (pmax + 255) / 256 * 256);
         if (spmm_tile_lds_bytes(R, ucap, ecap) > lds_budget) continue;
         m->plan_rows = R; m->plan_ucap = ucap; m->plan_ecap = ecap;
+        m->plan_ecap_pad = (spmm_tile_pad_lds_bytes(R, ucap, ecap_pad) <= lds_budget + 1024) ? ecap_pad : 0;
         m->n_ucols = (int64_t)ucols.size();
         HIPCHK(hipMalloc(&m->d_tile_uptr, sizeof(int64_t) * (T + 1)));
         HIPCHK(hipMalloc(&m->d_ucols, sizeof(int32_t) * std::max<size_t>(ucols.size(), 1)));
@@ -2045,11 +2050,18 @@ static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const dou
     if (m->plan_state == 1 && aligned) {
         const int R = m->plan_rows, uc = m->plan_ucap, ec = m->plan_ecap;
         const dim3 grid((unsigned)((S->n_rows + R - 1) / R));
-        const size_t lds = spmm_tile_lds_bytes(R, uc, ec);
+        static const bool no_pad = [] { const char* e = getenv("GMRF_SPMM_PAD"); return e && atoi(e) == 0; }();   // tuning aid
+        const bool pad = m->plan_ecap_pad > 0 && !no_pad;
+        const int ecl = pad ? m->plan_ecap_pad : ec;
+        const size_t lds = pad ? spmm_tile_pad_lds_bytes(R, uc, ecl) : spmm_tile_lds_bytes(R, uc, ec);
         // 7 gather loads per thread and chunk serve up to 224 distinct columns per tile, 10 up to 320
 #define GMRF_SPMM_TILES(VT, VP)                                                                                          \
         do {                                                                                                             \
-            if (uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
+            if (pad && uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles_pad<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
+                                              S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ecl);  \
+            else if (pad) hipLaunchKernelGGL((csr_spmm_tiles_pad<VT, SPMM_NG>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP,    \
+                                    S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ecl);            \
+            else if (uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
                                               S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);  \
             else hipLaunchKernelGGL((csr_spmm_tiles<VT, SPMM_NG>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP,    \
                                     S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);            \

@@ -462,6 +462,155 @@ __global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles(const int64_t*
     }
 }
 
+// The same kernel with the entries of a row PADDED to a multiple of 8 in LDS (value 0, the row's first local
+// index): every row starts at a multiple of 8 entries, so the 8 indices of a turn are one ALIGNED 16-byte
+// read and the values four -- the unpadded kernel's merged index read sits at a 2-byte boundary
+// (SQ_LDS_UNALIGNED_STALL = a third of its LDS-active cycles, tools/pmc_spmm_lds.sh) -- and the tail
+// turns (4 / 2 / 1 entries) disappear.  A product with a padding entry adds 0 * x = 0 (exact for finite x).
+// Entries are staged row by row (4 lanes per row), the padded row starts come from a wave scan.
+// The staged rows of X are 128 bytes with NO padding, swizzled instead: a row holds eight 16-byte slots, lane
+// (row, kq) of the multiply reads slot kq (right-hand sides 4kq, 4kq+1) and slot 4 + kq (4kq+2, 4kq+3), and slot s of
+// local row u lives at position s ^ (4 * bit1(u)).  The 16 lanes a ds_read_b128 serves together are 4 rows x 4 kq:
+// rows with consecutive local indices (the common case: neighbouring rows of a stencil matrix) then cover all 64
+// banks exactly once -- parity of u picks the 128-byte half of the bank array, bit 1 the 64-byte quarter.  With the
+// padded stride of 18 doubles the unpadded kernel's reads of rows u and u + 2 overlap in 3 of 4 slots
+// (SQ_LDS_BANK_CONFLICT = 21 % of its LDS-active cycles); stride 20: 767 us, 18: 621 us, swizzle: 585 us.
+template <typename VT, int NG>
+__global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles_pad(const int64_t* __restrict__ rowptr,
+                                                                   const uint16_t* __restrict__ lidx,
+                                                                   const VT* __restrict__ vals,
+                                                                   const int64_t* __restrict__ tile_uptr,
+                                                                   const int32_t* __restrict__ ucols, int64_t n_rows,
+                                                                   const double* __restrict__ X, int64_t ldx,
+                                                                   double* __restrict__ Y, int64_t ldy, int k,
+                                                                   int R, int ucap, int ecap) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs = smem;                                       // [ucap][16], swizzled (below)
+    double* vs = xs + (size_t)ucap * SPMM_KC;               // [ecap]   (padded rows)
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + ecap);   // [ecap]
+    int* uc = reinterpret_cast<int*>(ls + ecap);             // [ucap]   (ecap is a multiple of 8)
+    int* rp = uc + ucap;                                     // [R + 1]  CSR offsets relative to the tile
+    int* pp = rp + R + 1;                                    // [R + 1]  padded offsets
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * R;
+    const int nr = (int)min((int64_t)R, n_rows - r0);
+    const int64_t e0 = rowptr[r0];
+    if (t < 64) {                                            // R <= 64: one wave scans the padded row lengths
+        const int a = (t < R) ? (int)(rowptr[r0 + min(t, nr)] - e0) : 0;
+        const int b = (t < R) ? (int)(rowptr[r0 + min(t + 1, nr)] - e0) : 0;
+        int x = (b - a + 7) & ~7;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (t >= d) x += y;
+        }
+        if (t < R) { rp[t] = a; pp[t + 1] = x; if (t == R - 1) rp[R] = b; }
+        if (t == 0) pp[0] = 0;
+    }
+    const int64_t u0 = tile_uptr[blockIdx.x];
+    const int U = (int)(tile_uptr[blockIdx.x + 1] - u0);
+    for (int u = t; u < U; u += SPMM_THREADS) uc[u] = ucols[u0 + u];
+    __syncthreads();
+    const int kq = t & 3, rsub = t >> 2;                     // 4 lanes per row: staging of entries and multiply
+    for (int p = 0; p < R; p += 64) {
+        const int row = p + rsub;
+        if (row < R) {
+            const int a = rp[row], len = rp[row + 1] - a, pa = pp[row], plen = pp[row + 1] - pa;
+            uint16_t li[4];
+            double v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                    // the first 16 entries of the row: independent loads
+                const int j = kq + 4 * i;
+                const bool ok = j < len;
+                li[i] = ok ? lidx[e0 + a + j] : (uint16_t)0xffff;
+                v[i] = ok ? (double)vals[e0 + a + j] : 0.0;
+            }
+            const uint16_t first = (len > 0) ? lidx[e0 + a] : (uint16_t)0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int j = kq + 4 * i;
+                if (j < plen) { ls[pa + j] = (j < len) ? li[i] : first; vs[pa + j] = v[i]; }
+            }
+            for (int j = 16 + kq; j < plen; j += 4) {
+                const bool ok = j < len;
+                ls[pa + j] = ok ? lidx[e0 + a + j] : first;
+                vs[pa + j] = ok ? (double)vals[e0 + a + j] : 0.0;
+            }
+        }
+    }
+    const int seg = t & 7, ub = t >> 3;                      // gather: 8 threads x 16 B per row piece, 32 rows per pass
+    uint32_t goff[NG];
+    const v2d* __restrict__ X2 = reinterpret_cast<const v2d*>(X);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int u = ub + 32 * i;
+        goff[i] = (u < U) ? (uint32_t)(((int64_t)uc[u] * ldx) / 2 + seg) : 0xffffffffu;
+    }
+    v2d g[NG];
+    auto gather = [&](int kc0) {
+        const bool seg_ok = kc0 + 2 * seg < k;               // k is even on this path (host checks)
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            g[i] = (v2d){0.0, 0.0};
+            if (goff[i] != 0xffffffffu && seg_ok) g[i] = X2[(size_t)goff[i] + (size_t)(kc0 / 2)];
+        }
+    };
+    gather(0);
+    for (int kc0 = 0; kc0 < k; kc0 += SPMM_KC) {
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int u = ub + 32 * i;
+            if (u < U) {
+                const int slot = (((seg & 1) << 2) | (seg >> 1)) ^ ((u & 2) << 1);
+                *reinterpret_cast<v2d*>(xs + u * SPMM_KC + 2 * slot) = g[i];
+            }
+        }
+        __syncthreads();                                     // (first chunk: also the staged entries)
+        if (kc0 + SPMM_KC < k) gather(kc0 + SPMM_KC);        // in flight while this chunk is multiplied
+        for (int p = 0; p < R; p += 64) {
+            const int row = p + rsub;
+            const int e_begin = pp[min(row, R)], e_end = pp[min(row + 1, R)];
+            v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
+            for (int e = e_begin; e < e_end; e += 8) {
+                const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
+                const v2d v01 = *reinterpret_cast<const v2d*>(vs + e), v23 = *reinterpret_cast<const v2d*>(vs + e + 2);
+                const v2d v45 = *reinterpret_cast<const v2d*>(vs + e + 4), v67 = *reinterpret_cast<const v2d*>(vs + e + 6);
+                const int ii[8] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16),
+                                   (int)(q.z & 0xffffu), (int)(q.z >> 16), (int)(q.w & 0xffffu), (int)(q.w >> 16)};
+                const double vv[8] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
+                v2d xa[8], xb[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int o = ((ii[u] << 4) | (kq << 1)) ^ ((ii[u] & 2) << 2);     // in doubles: row * 16 + 2 * slot(kq, 0)
+                    xa[u] = *reinterpret_cast<const v2d*>(xs + o);
+                    xb[u] = *reinterpret_cast<const v2d*>(xs + (o ^ 8));
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    a01.x = fma(vv[u], xa[u].x, a01.x); a01.y = fma(vv[u], xa[u].y, a01.y);
+                    a23.x = fma(vv[u], xb[u].x, a23.x); a23.y = fma(vv[u], xb[u].y, a23.y);
+                }
+            }
+            if (row < nr) {
+                double* yp = Y + (r0 + row) * ldy + kc0 + 4 * kq;
+                if (kc0 + 4 * kq + 4 <= k && (ldy & 1) == 0) {
+                    *reinterpret_cast<v2d*>(yp) = a01; *reinterpret_cast<v2d*>(yp + 2) = a23;
+                } else {
+                    if (kc0 + 4 * kq < k) yp[0] = a01.x;
+                    if (kc0 + 4 * kq + 1 < k) yp[1] = a01.y;
+                    if (kc0 + 4 * kq + 2 < k) yp[2] = a23.x;
+                    if (kc0 + 4 * kq + 3 < k) yp[3] = a23.y;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+inline size_t spmm_tile_pad_lds_bytes(int R, int ucap, int ecap_pad) {
+    return (size_t)ucap * SPMM_KC * 8 + (size_t)ecap_pad * 8 + (size_t)ecap_pad * 2 + (size_t)ucap * 4 + (size_t)(2 * R + 2) * 4 + 16;
+}
+
 // Node-major right-hand sides without a tile plan (a tile with too many entries or distinct columns,
 // odd k / ldx): 16 lanes along the right-hand sides, 4 rows per wave, operands straight from global
 // memory; same summation order.
