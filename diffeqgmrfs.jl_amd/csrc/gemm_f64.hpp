@@ -79,6 +79,16 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ P, int
     }
 }
 
+// [k][row]-stored operand kept as it lies in memory: LDS image [BK][64], straight 16-byte copies (a half wave
+// writes one 512-byte k row: no bank conflicts; the transposing gemm_store_tile<true> puts lanes 4 apart on the
+// same banks -- SQ_LDS_BANK_CONFLICT was 0.64 of the LDS-active cycles of gemm_f64_mfma<false, true>).
+template <int BK>
+__device__ __forceinline__ void gemm_store_tile_natural(double* sm, int t, const v2d (&rg)[BK / 8]) {
+    const int kk = t >> 5, r = (t & 31) * 2;
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) *reinterpret_cast<v2d*>(sm + (kk + 8 * i) * 64 + r) = rg[i];
+}
+
 template <bool ROWS_CONTIG, int BK>
 __device__ __forceinline__ void gemm_store_tile(double* sm, int t, const v2d (&rg)[BK / 8]) {
     constexpr int LD = BK + 4;
@@ -141,15 +151,24 @@ __device__ __forceinline__ void gemm_tile_order(const GemmArgs& g, int& bm, int&
 // cycles) per wave to land before it is needed.
 struct GemmFrag { v2d a0, a1, b0, b1; };
 
-template <int LD>
+// B_NAT: the B image is [k][64] (gemm_store_tile_natural).  A lane then reads the two neighbouring columns
+// wn + 2 li, wn + 2 li + 1 of rows k and k + 1: b0 = row k, b1 = row k + 1, .x feeds the MFMA tile of the even
+// columns of the wave's 32-column range, .y the odd ones (the two output tiles interleave; same k slots per
+// MFMA as the [n][k] image, hence bitwise the same sums).  A 16-lane group reads 256 contiguous bytes.
+template <int LD, bool B_NAT>
 __device__ __forceinline__ GemmFrag gemm_read_frag(const double* as, const double* bs, int wm, int wn, int li,
                                                    int lq, int kg) {
     GemmFrag f;
     const int k = kg * 8 + 2 * lq;
     f.a0 = *reinterpret_cast<const v2d*>(as + (wm + li) * LD + k);
     f.a1 = *reinterpret_cast<const v2d*>(as + (wm + 16 + li) * LD + k);
-    f.b0 = *reinterpret_cast<const v2d*>(bs + (wn + li) * LD + k);
-    f.b1 = *reinterpret_cast<const v2d*>(bs + (wn + 16 + li) * LD + k);
+    if (B_NAT) {
+        f.b0 = *reinterpret_cast<const v2d*>(bs + k * 64 + wn + 2 * li);
+        f.b1 = *reinterpret_cast<const v2d*>(bs + (k + 1) * 64 + wn + 2 * li);
+    } else {
+        f.b0 = *reinterpret_cast<const v2d*>(bs + (wn + li) * LD + k);
+        f.b1 = *reinterpret_cast<const v2d*>(bs + (wn + 16 + li) * LD + k);
+    }
     return f;
 }
 
@@ -200,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         gemm_load_tile<A_T, BK>(A, g.lda, m0, kb, t, ra);
         gemm_load_tile<B_N, BK>(B, g.ldb, n0, kb, t, rb);
         gemm_store_tile<A_T, BK>(As0, t, ra);
-        gemm_store_tile<B_N, BK>(Bs0, t, rb);
+        if (B_N) gemm_store_tile_natural<BK>(Bs0, t, rb);
+        else gemm_store_tile<false, BK>(Bs0, t, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nkt; ++kt) {
@@ -214,27 +234,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         }
         const double* as = As0 + cur * GEMM_BM * LD;
         const double* bs = Bs0 + cur * GEMM_BN * LD;
-        GemmFrag f = gemm_read_frag<LD>(as, bs, wm, wn, li, lq, 0);
+        GemmFrag f = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, 0);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
             GemmFrag fn = f;
-            if (kg + 1 < BK / 8 && !(g.tri & 256)) fn = gemm_read_frag<LD>(as, bs, wm, wn, li, lq, kg + 1);
+            if (kg + 1 < BK / 8 && !(g.tri & 256)) fn = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, kg + 1);
             __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, f.b0.x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, f.b1.x, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, f.b0.x, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, f.b1.x, acc[1][1], 0, 0, 0);
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, f.b0.y, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, f.b1.y, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, f.b0.y, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, f.b1.y, acc[1][1], 0, 0, 0);
+            // operands of output tile j at k slot p: [n][k] image: column tile j = b_j, slot = .x / .y;
+            // [k][n] image (B_N): row k + p = b_p, even / odd columns = .x / .y
+            const double b00 = f.b0.x, b01 = B_N ? f.b0.y : f.b1.x, b10 = B_N ? f.b1.x : f.b0.y, b11 = f.b1.y;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, b00, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.x, b01, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, b00, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.x, b01, acc[1][1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, b10, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a0.y, b11, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, b10, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, b11, acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             f = fn;
         }
         if (single) __syncthreads();
         if (more && !(g.tri & 512)) {
             gemm_store_tile<A_T, BK>(As0 + nxt * GEMM_BM * LD, t, ra);
-            gemm_store_tile<B_N, BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
+            if (B_N) gemm_store_tile_natural<BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
+            else gemm_store_tile<false, BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
         }
         if (!(g.tri & 1024)) __syncthreads();
     }
@@ -245,6 +269,30 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     }
     // f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.
     const double alpha = g.alpha, beta = g.beta;
+    if (B_N) {
+        // the two tiles of a row group interleave: a lane owns the columns wn + 2 li, wn + 2 li + 1
+        const bool vec = ((g.ldc | ldd) & 1) == 0 && ((((uintptr_t)C) | ((uintptr_t)Dm)) & 15) == 0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm + i * 16 + lq + 4 * r;
+                const int col = n0 + wn + 2 * li;
+                double* c = C + (int64_t)row * g.ldc + col;
+                v2d v = (v2d){alpha * acc[i][0][r], alpha * acc[i][1][r]};
+                if (vec) {
+                    if (beta != 0.0) {
+                        const v2d d = *reinterpret_cast<const v2d*>(Dm + (int64_t)row * ldd + col);
+                        v.x += beta * d.x; v.y += beta * d.y;
+                    }
+                    *reinterpret_cast<v2d*>(c) = v;
+                } else {
+                    if (beta != 0.0) { v.x += beta * Dm[(int64_t)row * ldd + col]; v.y += beta * Dm[(int64_t)row * ldd + col + 1]; }
+                    c[0] = v.x; c[1] = v.y;
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll

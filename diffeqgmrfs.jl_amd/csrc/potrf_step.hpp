@@ -157,8 +157,15 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
             a[jj + 1] = fma(-l, lc1, a[jj + 1]);
         }
         __builtin_amdgcn_sched_barrier(0);
+        // aligned 16-byte pieces only (the scratch is 16-byte aligned, c0 a multiple of 16): left to itself the
+        // compiler merges the reads from cc = jj + 2 on into ds_read_b128 at 8-byte boundaries for odd jj
+        // (SQ_LDS_UNALIGNED_STALL was 0.42 of this kernel's LDS-active cycles)
 #pragma unroll
-        for (int cc = jj + 2; cc < 16; ++cc) up[cc] = lcol[jj * 64 + c0 + cc];
+        for (int cc = (jj + 2) & ~1; cc < 16; cc += 2) {
+            const v2d q = *reinterpret_cast<const v2d*>(lcol + jj * 64 + c0 + cc);
+            if (cc >= jj + 2) up[cc] = q.x;
+            up[cc + 1] = q.y;
+        }
         lprev = l;
         __builtin_amdgcn_sched_barrier(0);
 #undef GMRF_DELAYED_SLOT
