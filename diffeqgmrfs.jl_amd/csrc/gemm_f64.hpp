@@ -79,6 +79,38 @@ __device__ __forceinline__ void gemm_load_tile(const double* __restrict__ P, int
     }
 }
 
+// The same loads as gemm_load_tile, split into a per-thread 32-bit byte offset computed ONCE per output tile
+// (rows and the k position inside a K step) and a wave-uniform base that advances per K step: the loads take the
+// scalar-base + 32-bit-offset form and the K loop carries no 64-bit address arithmetic (it was 22 VALU
+// instructions per K step beside 32 MFMAs).  Offsets stay below 2^32 for blocks up to 16384 x 16384.
+template <bool ROWS_CONTIG, int BK>
+__device__ __forceinline__ void gemm_tile_offsets(int64_t ld, int row0, int t, uint32_t (&off)[BK / 8]) {
+    if (!ROWS_CONTIG) {
+        constexpr int TPR = BK / 2, RPP = 256 / TPR;
+        const int r = t / TPR, kk = (t % TPR) * 2;
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) off[i] = (uint32_t)(((int64_t)(row0 + r + i * RPP) * ld + kk) * 8);
+    } else {
+        const int kk = t >> 5, r = (t & 31) * 2;
+#pragma unroll
+        for (int i = 0; i < BK / 8; ++i) off[i] = (uint32_t)(((int64_t)(kk + i * 8) * ld + row0 + r) * 8);
+    }
+}
+template <bool ROWS_CONTIG>
+__device__ __forceinline__ const char* gemm_tile_base(const double* P, int64_t ld, int k0) {
+    return reinterpret_cast<const char*>(ROWS_CONTIG ? P + (int64_t)k0 * ld : P + k0);
+}
+template <int BK>
+__device__ __forceinline__ void gemm_load_tile_off(const char* base, uint32_t (&off)[BK / 8], v2d (&rg)[BK / 8]) {
+#pragma unroll
+    for (int i = 0; i < BK / 8; ++i) {
+        // opaque to the optimiser at this point: otherwise the zero-extension of the offset is hoisted out of the K
+        // loop as a 64-bit VGPR pair and instruction selection (per basic block) no longer sees base + zext(offset)
+        asm volatile("" : "+v"(off[i]));
+        rg[i] = *reinterpret_cast<const v2d*>(base + off[i]);
+    }
+}
+
 // [k][row]-stored operand kept as it lies in memory: LDS image [BK][64], straight 16-byte copies (a half wave
 // writes one 512-byte k row: no bank conflicts; the transposing gemm_store_tile<true> puts lanes 4 apart on the
 // same banks -- SQ_LDS_BANK_CONFLICT was 0.64 of the LDS-active cycles of gemm_f64_mfma<false, true>).
@@ -215,9 +247,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
     unsigned long long c0 = 0, r0 = 0;
     if (g.stamps) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     v2d ra[BK / 8], rb[BK / 8];
+    uint32_t offa[BK / 8], offb[BK / 8];
+    gemm_tile_offsets<A_T, BK>(g.lda, m0, t, offa);
+    gemm_tile_offsets<B_N, BK>(g.ldb, n0, t, offb);
     if (nkt > 0) {
-        gemm_load_tile<A_T, BK>(A, g.lda, m0, kb, t, ra);
-        gemm_load_tile<B_N, BK>(B, g.ldb, n0, kb, t, rb);
+        gemm_load_tile_off<BK>(gemm_tile_base<A_T>(A, g.lda, kb), offa, ra);
+        gemm_load_tile_off<BK>(gemm_tile_base<B_N>(B, g.ldb, kb), offb, rb);
         gemm_store_tile<A_T, BK>(As0, t, ra);
         if (B_N) gemm_store_tile_natural<BK>(Bs0, t, rb);
         else gemm_store_tile<false, BK>(Bs0, t, rb);
@@ -227,18 +262,20 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
         const int cur = single ? 0 : (kt & 1);
         const int nxt = single ? 0 : (cur ^ 1);
         const bool more = (kt + 1 < nkt);
-        if (more && !(g.tri & 512)) {
+        if (more) {
             const int k0 = kb + (kt + 1) * BK;
-            gemm_load_tile<A_T, BK>(A, g.lda, m0, k0, t, ra);
-            gemm_load_tile<B_N, BK>(B, g.ldb, n0, k0, t, rb);
+            gemm_load_tile_off<BK>(gemm_tile_base<A_T>(A, g.lda, k0), offa, ra);
+            gemm_load_tile_off<BK>(gemm_tile_base<B_N>(B, g.ldb, k0), offb, rb);
         }
         const double* as = As0 + cur * GEMM_BM * LD;
         const double* bs = Bs0 + cur * GEMM_BN * LD;
-        GemmFrag f = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, 0);
+        // two fragment sets, alternating (indices are compile-time after unrolling: no register copies)
+        GemmFrag fr[2];
+        fr[0] = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, 0);
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            GemmFrag fn = f;
-            if (kg + 1 < BK / 8 && !(g.tri & 256)) fn = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, kg + 1);
+            if (kg + 1 < BK / 8) fr[(kg + 1) & 1] = gemm_read_frag<LD, B_N>(as, bs, wm, wn, li, lq, kg + 1);
+            const GemmFrag& f = fr[kg & 1];
             __builtin_amdgcn_sched_barrier(0);
             // operands of output tile j at k slot p: [n][k] image: column tile j = b_j, slot = .x / .y;
             // [k][n] image (B_N): row k + p = b_p, even / odd columns = .x / .y
@@ -252,15 +289,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_mfma(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, b10, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a1.y, b11, acc[1][1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            f = fn;
         }
         if (single) __syncthreads();
-        if (more && !(g.tri & 512)) {
+        if (more) {
             gemm_store_tile<A_T, BK>(As0 + nxt * GEMM_BM * LD, t, ra);
             if (B_N) gemm_store_tile_natural<BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
             else gemm_store_tile<false, BK>(Bs0 + nxt * GEMM_BN * LD, t, rb);
         }
-        if (!(g.tri & 1024)) __syncthreads();
+        __syncthreads();
     }
 
     if (g.stamps && blockIdx.x == 0 && t == 0) {
