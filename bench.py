@@ -209,10 +209,15 @@ def spmm_roofline(pkg, torch):
         S = pkg.CsrMatrix(w.Q, values_f32=f32, stream=st.cuda_stream)
         for k in (1, 64):
             X = torch.randn(w.n, dtype=torch.float64, device="cuda") if k == 1 else torch.randn(w.n, k, dtype=torch.float64, device="cuda")
-            for _ in range(3):
-                S @ X
+            # warm up to steady clocks: the matrix was just built on the host (GPU idle for seconds), and the first
+            # ~30 ms of launches after an idle period run 15-20 % slower (tools/spmm_clock_probe.py)
+            t_w = time.perf_counter()
+            while time.perf_counter() - t_w < 0.1:
+                for _ in range(10):
+                    S @ X
+                torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 10
+            reps = 30
             e0.record(st)
             for _ in range(reps):
                 S @ X
