@@ -135,7 +135,8 @@ class ProblemsJob:
         self.torch, self.samples, self.batch, self.n_streams = torch, samples, batch, n_streams
         total = batch * n_streams
         vals, rhss = [w.Q.data], [w.rhs]
-        for p in range(1, min(total, 8)):            # coefficient fields on the same mesh: same pattern, different values
+        n_distinct = 1 if os.environ.get("GMRF_BENCH_SAME_VALUES") == "1" else 8      # (diagnostic: one coefficient field for all)
+        for p in range(1, min(total, n_distinct)):   # coefficient fields on the same mesh: same pattern, different values
             same = False
             if config.startswith("darcy"):
                 wp = pkg.workloads.darcy(int(config[5:]), seed=523802340 + 1000 * rank + p)
@@ -145,8 +146,13 @@ class ProblemsJob:
             else:
                 vals.append(w.Q.data * (1.0 + 0.01 * p)); rhss.append(w.rhs)
         self.jobs = []
+        # one stream per handle, each on a hardware queue of its own (two streams that share a queue serialise: 27.3 k
+        # instead of 32.2 k solves/s with 4 handles -- gmrf_streams_create probes which streams overlap)
+        self.stream_set = pkg.StreamSet(n_streams, device=local) if n_streams > 1 else None
+        self.streams_on_own_queue = self.stream_set.n_distinct if self.stream_set else 1
         for t in range(n_streams):
-            st_t = torch.cuda.current_stream() if n_streams == 1 else torch.cuda.Stream()
+            st_t = (torch.cuda.current_stream() if n_streams == 1
+                    else torch.cuda.ExternalStream(self.stream_set.pointers[t], device=torch.device("cuda", local)))
             idx = [(t * batch + p) % len(vals) for p in range(batch)]
             with torch.cuda.stream(st_t):
                 e_t = post.HipEngine(pkg, w, device_index=local, batch=batch, values=np.stack([vals[i] for i in idx]),
@@ -182,6 +188,10 @@ class ProblemsJob:
         for _, e, _ in self.jobs:
             e.F.close()
         self.jobs = []
+        if self.stream_set is not None:
+            self.torch.cuda.synchronize()
+            self.stream_set.close()
+            self.stream_set = None
         self.torch.cuda.empty_cache()
 
 
@@ -350,6 +360,7 @@ def main():
         workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; {pj.n_streams * pj.batch} independent "
                     f"posterior(s) per GPU and step ({pj.n_streams} stream(s) x batch {pj.batch}), each factor + mean + {args.samples} samples")
         sharding = "independent problems per rank, no data-path collective"
+        extra["streams_on_own_hardware_queue"] = pj.streams_on_own_queue
 
     if rank == 0:
         out = {

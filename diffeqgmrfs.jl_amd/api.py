@@ -729,6 +729,33 @@ def logdet(L: TridiagonalCholeskyFactor) -> float:
     return L.logdet()
 
 
+class StreamSet:
+    """n HIP streams on hardware queues of their own (gmrf_streams_create): one per handle that is driven side by side
+    with others.  `.pointers` are hipStream_t values (pass as `stream=` to TridiagonalCholeskyFactor / CsrMatrix, or wrap
+    with torch.cuda.ExternalStream); `.n_distinct` of them were measured to overlap pairwise."""
+
+    def __init__(self, n: int, device: int = 0):
+        import ctypes as C
+        lib = _cabi.load()
+        arr = (C.c_void_p * n)()
+        nd = C.c_int32(0)
+        _cabi.check(lib.gmrf_streams_create(device, n, arr, C.byref(nd)))
+        self.device, self._arr, self._n = device, arr, n
+        self.pointers = [int(arr[i] or 0) for i in range(n)]
+        self.n_distinct = int(nd.value)
+
+    def close(self):
+        if self._arr is not None:
+            _cabi.load().gmrf_streams_destroy(self.device, self._n, self._arr)
+            self._arr, self.pointers = None, []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """RCCL communicator of this process (one per GPU) through the C ABI -- what a Julia host uses to
     share a factor over xGMI (include/gmrf_hip.h, "multi-GPU").  `unique_id()` on rank 0, ship the

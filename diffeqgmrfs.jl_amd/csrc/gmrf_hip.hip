@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -938,6 +939,70 @@ static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* 
     h->stats.factor_ms = ms;
     if (h->profiling) prof_collect(h);
     return s;
+}
+
+// ------------------------------------------------------------------------------------ streams on distinct hardware queues
+// spins for `ticks` of the constant 100 MHz clock (always terminates: the clock advances)
+__global__ void gmrf_spin_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {}
+}
+
+static double spin_pair_ms(hipStream_t a, hipStream_t b, unsigned long long ticks) {
+    (void)hipDeviceSynchronize();
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(gmrf_spin_kernel, dim3(1), dim3(64), 0, a, ticks);
+    if (b) hipLaunchKernelGGL(gmrf_spin_kernel, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipStreamSynchronize(a);
+    if (b) (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+gmrf_status gmrf_streams_create(int32_t device, int32_t n, void** streams, int32_t* n_distinct) {
+    if (n <= 0 || n > 32 || !streams) return bad_shape("gmrf_streams_create: 1 <= n <= 32 streams");
+    HIPCHK(hipSetDevice(device));
+    const int ncand = std::min(3 * n + 4, 48);
+    std::vector<hipStream_t> cand((size_t)ncand, nullptr);
+    for (int i = 0; i < ncand; ++i) {
+        if (hipStreamCreateWithFlags(&cand[(size_t)i], hipStreamNonBlocking) != hipSuccess) {
+            for (int j = 0; j < i; ++j) (void)hipStreamDestroy(cand[(size_t)j]);
+            g_last_error = "hipStreamCreateWithFlags failed"; return GMRF_ERR_HIP;
+        }
+        // first use binds the stream to its hardware queue
+        hipLaunchKernelGGL(gmrf_spin_kernel, dim3(1), dim3(64), 0, cand[(size_t)i], 1ull);
+    }
+    HIPCHK(hipDeviceSynchronize());
+    const unsigned long long ticks = 100000ull;                       // 1 ms at 100 MHz
+    double one = 1e30;
+    for (int r = 0; r < 3; ++r) one = std::min(one, spin_pair_ms(cand[0], nullptr, ticks));
+    std::vector<int> chosen;
+    for (int i = 0; i < ncand && (int)chosen.size() < n; ++i) {
+        bool ok = true;
+        for (int c : chosen) {
+            // serialised pairs take 2 x one, overlapped ones ~1 x one (best of two tries against host jitter)
+            const double t = std::min(spin_pair_ms(cand[(size_t)c], cand[(size_t)i], ticks), spin_pair_ms(cand[(size_t)c], cand[(size_t)i], ticks));
+            if (t > 1.5 * one) { ok = false; break; }
+        }
+        if (ok) chosen.push_back(i);
+    }
+    const int nd = (int)chosen.size();
+    std::vector<char> used((size_t)ncand, 0);
+    for (int c : chosen) used[(size_t)c] = 1;
+    for (int i = 0; i < ncand && (int)chosen.size() < n; ++i)         // not enough distinct queues: fill up with the others
+        if (!used[(size_t)i]) { chosen.push_back(i); used[(size_t)i] = 1; }
+    for (int k = 0; k < n; ++k) streams[k] = (void*)cand[(size_t)chosen[(size_t)k]];
+    for (int i = 0; i < ncand; ++i)
+        if (!used[(size_t)i]) (void)hipStreamDestroy(cand[(size_t)i]);
+    if (n_distinct) *n_distinct = nd;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_streams_destroy(int32_t device, int32_t n, void** streams) {
+    if (n < 0 || (n > 0 && !streams)) return bad_shape("gmrf_streams_destroy");
+    HIPCHK(hipSetDevice(device));
+    for (int k = 0; k < n; ++k)
+        if (streams[k]) { (void)hipStreamSynchronize((hipStream_t)streams[k]); (void)hipStreamDestroy((hipStream_t)streams[k]); streams[k] = nullptr; }
+    return GMRF_OK;
 }
 
 // ------------------------------------------------------------------------------------ sweeps

@@ -245,6 +245,18 @@ gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t roo
                                        int64_t i1, int32_t with_l);
 gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c);
 
+/* Streams for several handles driven side by side (one host thread and one stream per handle: the latency-bound
+ * launches of one factorisation leave CUs to the others -- bench.py runs 4 handles x 32 problems).  The HIP runtime
+ * multiplexes streams onto a few hardware queues (4 by default) and two streams that land on the same queue
+ * SERIALISE: measured on MI355X, 4 handles on 4 streams of which two share a queue deliver 27.3 k solves/s, on four
+ * distinct queues 32.2 k (tools/stream_pairs.py).  gmrf_streams_create makes candidate streams
+ * (hipStreamNonBlocking), runs a 1 ms spin kernel on pairs of them to find out which overlap, keeps n mutually
+ * overlapping ones (as far as there are: *n_distinct tells how many of the returned streams are on queues of their
+ * own) and destroys the rest.  streams: n hipStream_t, to be passed to gmrf_bt_create / released with
+ * gmrf_streams_destroy.  (No reference counterpart: the reference is single-threaded CPU code.) */
+gmrf_status gmrf_streams_create(int32_t device, int32_t n, void** streams, int32_t* n_distinct);
+gmrf_status gmrf_streams_destroy(int32_t device, int32_t n, void** streams);
+
 /* Pipelined factorisation (factor block ranges so a broadcast of finished blocks can
  * overlap): begin uploads the matrix, step_async enqueues blocks [i0, i1) and returns,
  * end synchronises and reports SPD failures. */

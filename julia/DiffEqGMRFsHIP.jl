@@ -61,10 +61,10 @@ mutable struct TridiagonalCholeskyFactor{T}
     N::Int
     n_blocks::Int
     batch::Int
-    function TridiagonalCholeskyFactor{T}(device::Integer = 0; batch::Integer = 1) where {T}
+    function TridiagonalCholeskyFactor{T}(device::Integer = 0; batch::Integer = 1, stream::Ptr{Cvoid} = C_NULL) where {T}
         T === Float64 || error("libgmrf_hip is fp64 only")
         h = Ref{Ptr{Cvoid}}(C_NULL)
-        check(ccall((:gmrf_bt_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, C_NULL, h))
+        check(ccall((:gmrf_bt_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), device, stream, h))
         obj = new{T}(h[], 0, 0, 1)
         finalizer(o -> ccall((:gmrf_bt_destroy, libgmrf), Int32, (Ptr{Cvoid},), o.handle), obj)
         batch == 1 || set_batch!(obj, batch)
@@ -474,6 +474,22 @@ bcast_blocks_async!(F::TridiagonalCholeskyFactor, c::GmrfComm, i0::Integer, i1::
     check(ccall((:gmrf_bt_bcast_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, Int32), F.handle, c.handle, root, i0, i1, with_l ? 1 : 0))
 comm_wait!(F::TridiagonalCholeskyFactor, c::GmrfComm) =
     check(ccall((:gmrf_comm_wait, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), F.handle, c.handle))
+
+"""
+    create_streams(n; device = 0) -> (streams::Vector{Ptr{Cvoid}}, n_distinct)
+
+`n` HIP streams on hardware queues of their own (probed by the library: streams that share a queue serialise), one per
+handle that a task drives side by side with others: `TridiagonalCholeskyFactor{Float64}(device; stream = streams[t])`.
+Release with `destroy_streams!`.
+"""
+function create_streams(n::Integer; device::Integer = 0)
+    streams = Vector{Ptr{Cvoid}}(undef, n)
+    nd = Ref{Int32}(0)
+    check(ccall((:gmrf_streams_create, libgmrf), Int32, (Int32, Int32, Ptr{Ptr{Cvoid}}, Ptr{Int32}), device, n, streams, nd))
+    return streams, Int(nd[])
+end
+destroy_streams!(streams::Vector{Ptr{Cvoid}}; device::Integer = 0) =
+    check(ccall((:gmrf_streams_destroy, libgmrf), Int32, (Int32, Int32, Ptr{Ptr{Cvoid}}), device, length(streams), streams))
 
 """
     shared_factor!(F, c, A, N_blocks; group = 8)

@@ -167,3 +167,20 @@ def test_multi_rank_rehearsal_on_one_gpu(rehearsal):
     assert res.get("two_ranks_rc") == 0, res.get("two_ranks.log")
     assert res.get("single_rc") == 0, res.get("single.log")
     assert res["ok"], res["checks"]
+
+
+@pytest.mark.gpu
+def test_streams_on_distinct_hardware_queues(pkg):
+    """gmrf_streams_create: n usable streams, of which n_distinct were measured to overlap pairwise; a handle on
+    such a stream gives the results of a handle on the default stream."""
+    ss = pkg.StreamSet(4)
+    assert len(ss.pointers) == 4 and all(p != 0 for p in ss.pointers) and len(set(ss.pointers)) == 4
+    assert 1 <= ss.n_distinct <= 4
+    w = pkg.workloads.random_block_tridiagonal(4, 128, seed=3)
+    x0 = pkg.ldiv(pkg.tridiagonal_cholesky(w.Q, 4), w.rhs)
+    for p in ss.pointers:
+        F = pkg.TridiagonalCholeskyFactor(stream=p).factor(w.Q, 4)
+        assert np.array_equal(pkg.ldiv(F, w.rhs), x0)
+        F.close()
+    ss.close()
+    assert ss.pointers == []
