@@ -628,7 +628,8 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // one-launch step (43 ms against 48 ms on darcy256); beyond that the fused step's redundant
     // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
     const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
-    const int pw = (!fused && nt >= 8) ? 4 : nt;           // panel width in tiles
+    static const int pw_env = [] { const char* e = getenv("GMRF_PANEL_TILES"); return e ? atoi(e) : 4; }();   // tuning aid
+    const int pw = (!fused && nt >= 8) ? ((pw_env == 2 || pw_env == 8) ? pw_env : 4) : nt;           // panel width in tiles
     // a lone problem with larger blocks: two-level, with the fused kernel restricted to the panel's
     // own columns as the in-panel step (one launch instead of three where the panel has columns left)
     const bool fused_in_panel = (h->B == 1 && !h->split_step && nt > 16);
