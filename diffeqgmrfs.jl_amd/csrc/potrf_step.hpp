@@ -177,23 +177,53 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
     if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
 }
 
-// One wave: X_kk = L_kk^-1 for the 16x16 diagonal block at c0 (lane c < 16 owns column c).
-// Column-oriented substitution: once x[k] is final every later row gets its update at once, so
-// the dependent chain is 16 (mul, fma) pairs instead of 120 accumulations.
+// value of quad lane J (lanes 4g .. 4g+3 form a quad) in every lane of the quad: two DPP moves, no LDS
+template <int J>
+__device__ __forceinline__ double quad_bcast(double v) {
+    constexpr int ctrl = J | (J << 2) | (J << 4) | (J << 6);          // quad_perm:[J,J,J,J]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave: X_kk = L_kk^-1 for the 16x16 diagonal block at c0.  Column-oriented substitution -- once x[k] is final
+// every later row gets its update at once -- over all 64 lanes: lane 4 c + q owns rows q, q+4, q+8, q+12 of column c,
+// so a step is one multiply in the owner lane, a quad broadcast of x[k] (DPP) and at most four fma, with every
+// entry of L and every 1/l_kk in registers before the chain starts: ~60 cycles per step.  (16 lanes with one
+// column each, L re-read from LDS inside the chain: 2 900 cycles per call, measured -- and the call for the last
+// diagonal block sits on the tile's critical path.)
 __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, double* Xs, int c0, int lane) {
-    if (lane >= 16) return;
-    const int c = lane;
-    double x[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x[r] = (r == c) ? 1.0 : 0.0;
+    const int c = lane >> 2, q = lane & 3;
+    double lv[4][16];                      // lv[i][k] = L[4 i + q][k] for 4 i + q > k, else 0 (the block's upper part holds don't-cares)
+    double rv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        x[k] = (k >= c) ? x[k] * rinvs[c0 + k] : 0.0;
+        rv[k] = rinvs[c0 + k];
 #pragma unroll
-        for (int r = k + 1; r < 16; ++r) x[r] = fma(-Ts[(c0 + r) * TLD + c0 + k], x[k], x[r]);
+        for (int i = k / 4; i < 4; ++i) {
+            const int r = 4 * i + q;
+            const double v = Ts[(c0 + r) * TLD + c0 + k];
+            lv[i][k] = (r > k) ? v : 0.0;
+        }
     }
+    double x[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) Xs[(c0 + r) * TLD + c0 + c] = x[r];
+    for (int i = 0; i < 4; ++i) x[i] = (4 * i + q == c) ? 1.0 : 0.0;
+#define GMRF_INV16_STEP(K)                                                                        \
+    {                                                                                              \
+        constexpr int ik = (K) / 4, qk = (K) % 4;                                                  \
+        const double xs = x[ik] * rv[K];                                                           \
+        if (q == qk) x[ik] = xs;                      /* rows above the column's diagonal stay 0 */ \
+        const double xk = quad_bcast<qk>(x[ik]);                                                   \
+        _Pragma("unroll") for (int i = ik; i < 4; ++i) x[i] = fma(-lv[i][K], xk, x[i]);           \
+    }
+    GMRF_INV16_STEP(0) GMRF_INV16_STEP(1) GMRF_INV16_STEP(2) GMRF_INV16_STEP(3)
+    GMRF_INV16_STEP(4) GMRF_INV16_STEP(5) GMRF_INV16_STEP(6) GMRF_INV16_STEP(7)
+    GMRF_INV16_STEP(8) GMRF_INV16_STEP(9) GMRF_INV16_STEP(10) GMRF_INV16_STEP(11)
+    GMRF_INV16_STEP(12) GMRF_INV16_STEP(13) GMRF_INV16_STEP(14) GMRF_INV16_STEP(15)
+#undef GMRF_INV16_STEP
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
 }
 
 // Trailing sub-tile (I, J) of the tile: T[I][J] -= P_I P_J^T with the panel at columns c0..c0+15.
@@ -248,6 +278,30 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         Xs[off] = 0.0;
     }
     __syncthreads();
+    // --- inverse of the tile by block forward substitution over the four 16-row blocks:
+    //        X[I][J] = -X[I][I] * sum_{K=J..I-1} L[I][K] X[K][J],      I = 1, 2, 3,  J < I.
+    // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
+    // eps * cond(16x16 block); the cheaper recursive doubling X21 = -X22 (L21 X11) multiplies two
+    // computed inverses and was measured 20-100x less accurate for cond(tile) >= 1e5.
+    // Schedule: block rows 1 and 2 need nothing of the last panel, so waves 1 and 2 form their sums WHILE wave 0
+    // factors it and wave 3 inverts the third diagonal block (a 16x16 substitution is 2 900 cycles: it must not sit
+    // between two panels).  Wave 1 owns block column 0, wave 2 block (2,1): everything a sum reads was written by
+    // the same wave or before a barrier; their scratch is the part of Xs that block row 3 fills at the very end --
+    // Wk belongs to the panel factorisation until then.  After the last panel: X[2][J] = -X22 * sum (one product),
+    // then the sums of block row 3 beside the last diagonal inverse (wave 3), then one product per wave.
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    auto sum_ij = [&](int I, int J) {                    // sum_{K=J..I-1} L[I][K] X[K][J]
+        v4d t = zero;
+        for (int K = J; K < I; ++K)
+            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+        return t;
+    };
+    auto finish_ij = [&](int I, int J, const double* scratch, int lds) {      // X[I][J] = -X[I][I] * scratch
+        const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, scratch, lds, zero, true, li, lq);
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
+    };
+    double* s30 = Xs + 48 * TLD;                          // scratch: blocks (3,0) and (3,1) of Xs (row stride TLD)
+    double* s31 = Xs + 48 * TLD + 16;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         const int c0 = 16 * kb;
@@ -269,6 +323,16 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
                 if (wave == 1) subtile_update(Ts, 3, 3, pc0, li, lq);
             }
             if (wave == 3) inv16(Ts, rinvs, Xs, pc0, lane);
+            if (kb == 3) {
+                // block row 1 and the sums of block row 2 (diagonal inverses 0 and 1 are final)
+                if (wave == 1) {
+                    store_d16(s30, TLD, sum_ij(1, 0), li, lq);
+                    finish_ij(1, 0, s30, TLD);
+                    store_d16(s30, TLD, sum_ij(2, 0), li, lq);
+                } else if (wave == 2) {
+                    store_d16(s31, TLD, sum_ij(2, 1), li, lq);
+                }
+            }
         }
         __syncthreads();
         TILE_STAMP(3 + 3 * kb);
@@ -280,40 +344,32 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         __syncthreads();
     }
     TILE_STAMP(13);
-    // rows above a panel's diagonal received don't-care values: zero the strict upper triangles
-    // of the four diagonal 16x16 blocks (waves 1, 2; waves 0 and 3 start the inverse assembly)
-    if (wave == 1 || wave == 2) {
-        for (int i = tid - 64; i < 4 * 256; i += 128) {
-            const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
-            if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
-        }
-    }
-    // --- inverse of the tile by block forward substitution over the four 16-row blocks:
-    //        X[I][J] = -X[I][I] * sum_{K=J..I-1} L[I][K] X[K][J],      I = 1, 2, 3,  J < I.
-    // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
-    // eps * cond(16x16 block); the cheaper recursive doubling X21 = -X22 (L21 X11) multiplies two
-    // computed inverses and was measured 20-100x less accurate for cond(tile) >= 1e5.
-    // Wave J owns block column J: everything block (I, J) reads was written by the same wave
-    // (X[K][J], its scratch) or before the last barrier (L, the diagonal inverses 0..2), so block
-    // rows 1 and 2 need no workgroup barrier -- LDS operations of one wave are served in order.
-    // Wave 3 meanwhile inverts the last diagonal block; one barrier, then block row 3.
-    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
     double* Wm = Wk + wave * 16 * 18;
-    auto block_ij = [&](int I, int J) {
-        v4d t = zero;
-        for (int K = J; K < I; ++K)
-            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
-        store_d16(Wm, 18, t, li, lq);
-        const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Wm, 18, zero, true, li, lq);
-        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
-    };
+    // after the last panel, no barrier until the last diagonal inverse is there: wave 3 inverts it; wave 1 finishes
+    // X[2][0] and sums column 0 of block row 3 (it wrote X[1][0], X[2][0] itself), wave 2 the same for column 1,
+    // wave 0 zeroes the strict upper triangles of the diagonal blocks (don't-care values above a panel's diagonal)
+    // and sums column 2 (needs X[2][2] only).  Then one product with X[3][3] per wave.
+    int J3 = -1;
     if (wave == 3) {
         inv16(Ts, rinvs, Xs, 48, lane);
     } else {
-        for (int I = wave + 1; I < 3; ++I) block_ij(I, wave);
+        if (wave == 0) {
+            for (int i = lane; i < 4 * 256; i += 64) {
+                const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
+                if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
+            }
+            J3 = 2;
+        } else if (wave == 1) {
+            finish_ij(2, 0, s30, TLD);
+            J3 = 0;
+        } else {
+            finish_ij(2, 1, s31, TLD);
+            J3 = 1;
+        }
+        store_d16(Wm, 18, sum_ij(3, J3), li, lq);
     }
     __syncthreads();
-    if (wave < 3) block_ij(3, wave);
+    if (wave < 3) finish_ij(3, J3, Wm, 18);
     __syncthreads();
     TILE_STAMP(14);
 }
