@@ -742,7 +742,8 @@ inline bool gemm_uses_ll(const GemmArgs& g, int batch) {
     if (gemm_ll_policy() == 2 || g.K % 32 || (g.tri & ~15) || g.stamps) return false;
     const int64_t sx = g.N / GEMM_BN, sy = g.M / GEMM_BM;
     const int64_t tiles = ((g.lower_only && g.M == g.N) ? sx * (sx + 1) / 2 : sx * sy) * batch;
-    return tiles <= 128;
+    static const int64_t ll_max = [] { const char* e = getenv("GMRF_GEMM_LL_MAX_TILES"); return (int64_t)(e ? atoi(e) : 128); }();   // tuning aid
+    return tiles <= ll_max;
 }
 
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
