@@ -16,7 +16,8 @@ ONE factor shared by all ranks -- rank 0 factors a batch of posteriors block-ran
 every finished range of Linv / C blocks is broadcast over RCCL (the library's own communicator,
 gmrf_comm_*; torch.distributed if that cannot be set up) while the next range is being factored --
 and the samples sharded: every rank takes the means and draws ITS OWN 64 samples per posterior.
-value = B_shared * (1 + 64 N) * steps / time.  Beside it, in the same run: the independent-problems
+value = B_shared * (1 + 64 N) * steps / time (B_shared = 32 posteriors per step: the root factors them as one
+batch, 2.6 ms per posterior, and 0.83 GB per posterior cross xGMI).  Beside it, in the same run: the independent-problems
 mode of the N = 1 line (no data-path collective) and BASELINE config C4 (elliptic 512^2, 256 samples
 sharded over the ranks).
 
@@ -253,7 +254,7 @@ def main():
                     help="independent batched handles per GPU, each on its own HIP stream and host thread")
     ap.add_argument("--mode", choices=["auto", "problems", "shared-factor"], default="auto",
                     help="auto: problems on one GPU, shared-factor on several")
-    ap.add_argument("--shared-batch", type=int, default=8, help="posteriors per step whose factor is shared (N > 1)")
+    ap.add_argument("--shared-batch", type=int, default=32, help="posteriors per step whose factor is shared (N > 1)")
     ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
     ap.add_argument("--keep-l", action="store_true", help="retain the L blocks (F.chos); default: only Linv and C are stored")
     ap.add_argument("--transport", choices=["auto", "cabi", "torch"], default="auto")
