@@ -34,6 +34,7 @@ EXPORTS = [
     "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_streams_create", "gmrf_streams_destroy",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows",
     "gmrf_darcy_p1_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
+    "gmrf_burgers_p1_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
@@ -145,6 +146,10 @@ def load() -> C.CDLL:
         "gmrf_darcy_p1_destroy": [vp],
         "gmrf_darcy_p1_pattern": [vp, P(i64), vp, vp, i32],
         "gmrf_darcy_p1_assemble": [vp, vp, i64, dbl, vp, vp],
+        "gmrf_burgers_p1_create": [i32, vp, i64, i64, dbl, dbl, P(vp)],
+        "gmrf_burgers_p1_destroy": [vp],
+        "gmrf_burgers_p1_pattern": [vp, P(i64), vp, vp, i32],
+        "gmrf_burgers_p1_tangent": [vp, vp, vp, vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
         "gmrf_spmm_rows": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],

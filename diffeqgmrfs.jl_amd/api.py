@@ -249,6 +249,52 @@ class DarcyP1Assembler:
         return vals, f
 
 
+class BurgersP1Tangent:
+    """Residual and tangent of the implicit-Euler Burgers space-time system on the device (second
+    piece): `f_and_J` of /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149 with
+    `assemble_burgers_advection_matrix` (src/problems/burgers.jl:5-59) per time slice and the static part of
+    `assemble_burgers_mass_diffusion_matrices` (:60-98), on the periodic P1 line (ns nodes on [0,1), nt slices,
+    time-major index).  `pattern` is the CSR matrix (values 1, (nt-1) ns x nt ns, 6 entries per row) whose `.data`
+    order `tangent()` fills -- the `J` of `PosteriorAssembler`.  device = -1: pattern only (no GPU needed)."""
+
+    def __init__(self, ns: int, nt: int, dt: float, nu: float, device: int = 0, stream: int = 0):
+        self.ns, self.nt, self.dt, self.nu = int(ns), int(nt), float(dt), float(nu)
+        self.rows, self.n = (self.nt - 1) * self.ns, self.nt * self.ns
+        self._h = C.c_void_p()
+        lib = _cabi.load()
+        _cabi.check(lib.gmrf_burgers_p1_create(device, C.c_void_p(stream), ns, nt, float(dt), float(nu), C.byref(self._h)))
+        nnz = C.c_int64(0)
+        _cabi.check(lib.gmrf_burgers_p1_pattern(self._h, C.byref(nnz), None, None, 0))
+        self.nnz = int(nnz.value)
+        rp, ci = np.empty(self.rows + 1, dtype=np.int64), np.empty(self.nnz, dtype=np.int64)
+        _cabi.check(lib.gmrf_burgers_p1_pattern(self._h, None, _cabi.ptr(rp), _cabi.ptr(ci), 0))
+        self.pattern = sp.csr_matrix((np.ones(self.nnz), ci, rp), shape=(self.rows, self.n))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _cabi.load().gmrf_burgers_p1_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    def tangent(self, w):
+        """w: (nt ns,) linearisation point (NumPy array or torch CUDA tensor).  Returns (J values in `pattern.data`
+        order, residual f(w)), same kind as the input."""
+        if _is_torch(w):
+            import torch
+            wv = w.contiguous()
+            vals = torch.empty(self.nnz, dtype=torch.float64, device=wv.device)
+            f = torch.empty(self.rows, dtype=torch.float64, device=wv.device)
+        else:
+            wv = np.ascontiguousarray(w, dtype=np.float64)
+            vals, f = np.empty(self.nnz), np.empty(self.rows)
+        if wv.ndim != 1 or wv.shape[0] != self.n:
+            raise ValueError(f"w must have {self.n} entries")
+        _cabi.check(_cabi.load().gmrf_burgers_p1_tangent(self._h, _cabi.ptr(wv), _cabi.ptr(vals), _cabi.ptr(f)))
+        return vals, f
+
+
 def gn_step(F: "TridiagonalCholeskyFactor", asm: PosteriorAssembler, q_values, Qx_prior, j_values, x, obs_diff,
             noise: float):
     """One Gauss-Newton step of scripts/solve_burger.jl:143-149 with everything resident on the

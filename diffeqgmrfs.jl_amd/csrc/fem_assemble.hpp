@@ -142,4 +142,94 @@ __global__ __launch_bounds__(256) void darcy_p1_constrain(DarcyP1Args a, const d
     if (bi) a.f[i] = 0.0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// FEM block assembly on the device, second piece: residual and tangent of the
+// implicit-Euler Burgers space-time system,
+//     J(w) = J_static + dt J_adv(w),      f(w) = J_static w + dt v_adv(w)
+// -- f_and_J / nonlinear_primal_tangent, /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149 --
+// with  J_static = M_{t+1} - M_t + dt nu G_{t+1}  (:123-130; assemble_burgers_mass_diffusion_matrices,
+// src/problems/burgers.jl:60-98) and, per time slice, the advection tangent and residual of
+// assemble_burgers_advection_matrix (src/problems/burgers.jl:5-59, cell loop :22-51):
+//     Ge[i][j] += N_i (N_j grad(u) + u grad(N_j)) dOmega,      ve[i] += N_i u grad(u) dOmega
+// on the periodic P1 line of the BASELINE Burgers configs (ns nodes on [0,1), cell e = (e, e + 1 mod ns),
+// 3-point Gauss rule as QuadratureRule{1,RefCube}(3)); the periodic constraint of the reference's mesh is
+// the wrap-around of this one (no slave dofs).  Time-major index (t-1) ns + s; rows = slices 2 .. nt.
+//
+// Gather instead of scatter: a thread owns the row (t, i), evaluates its two cells (left: nodes i-1, i; right:
+// nodes i, i+1) with the reference's quadrature loop and writes the row's 6 entries in ascending column order
+// -- the CSR order gmrf_assemble_precision takes as `J` -- and f(t, i).  Nothing but w crosses the bus per
+// Gauss-Newton iteration.
+struct BurgersP1Args {
+    int ns, nt;
+    double dt, nu;
+    const double* w;                // [nt * ns]
+    double* vals;                   // [(nt - 1) * ns * 6]
+    double* f;                      // [(nt - 1) * ns]
+};
+
+// one P1 cell of length h with nodal values (w0, w1): advection tangent Ge, residual ve, mass Me, diffusion De
+__host__ __device__ inline void burgers_p1_cell(double h, double w0, double w1, double (&Ge)[2][2], double (&ve)[2],
+                                                double (&Me)[2][2], double (&De)[2][2]) {
+    const double xi[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};          // sqrt(3/5)
+    const double wq[3] = {0.5555555555555556, 0.8888888888888888, 0.5555555555555556};
+    const double jac = 0.5 * h;                                   // dx / dxi
+    const double dN[2] = {-0.5 / jac, 0.5 / jac};                 // shape_gradient
+    for (int i = 0; i < 2; ++i) { ve[i] = 0.0; for (int j = 0; j < 2; ++j) { Ge[i][j] = 0.0; Me[i][j] = 0.0; De[i][j] = 0.0; } }
+    for (int q = 0; q < 3; ++q) {
+        const double dOm = jac * wq[q];                           // getdetJdV
+        const double N[2] = {0.5 * (1.0 - xi[q]), 0.5 * (1.0 + xi[q])};
+        const double cur_u = N[0] * w0 + N[1] * w1;               // function_value
+        double grad_u = 0.0;                                      // :36-39
+        grad_u += dN[0] * w0;
+        grad_u += dN[1] * w1;
+        for (int i = 0; i < 2; ++i) {
+            for (int j = 0; j < 2; ++j) {
+                Ge[i][j] += N[i] * (N[j] * grad_u + cur_u * dN[j]) * dOm;      // :46
+                Me[i][j] += N[i] * N[j] * dOm;
+                De[i][j] += dN[i] * dN[j] * dOm;
+            }
+            ve[i] += N[i] * cur_u * grad_u * dOm;                 // :48
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void burgers_p1_rows(BurgersP1Args a) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)(a.nt - 1) * a.ns;
+    if (gid >= rows) return;
+    const int t = (int)(gid / a.ns) + 1, i = (int)(gid % a.ns);   // slice t (0-based), rows belong to slices 1 .. nt-1
+    const int im = (i == 0) ? a.ns - 1 : i - 1, ip = (i == a.ns - 1) ? 0 : i + 1;
+    const double h = 1.0 / (double)a.ns;
+    const double* wt = a.w + (int64_t)t * a.ns;
+    const double* wp = a.w + (int64_t)(t - 1) * a.ns;
+    const double wl = wt[im], wc = wt[i], wr = wt[ip];
+    double GeL[2][2], veL[2], MeL[2][2], DeL[2][2], GeR[2][2], veR[2], MeR[2][2], DeR[2][2];
+    burgers_p1_cell(h, wl, wc, GeL, veL, MeL, DeL);               // cell (i-1, i): this node is local 1
+    burgers_p1_cell(h, wc, wr, GeR, veR, MeR, DeR);               // cell (i, i+1): this node is local 0
+    // assembled rows (two addends on the diagonal: the order of the two cells does not matter)
+    const double m_m = MeL[1][0], m_0 = MeL[1][1] + MeR[0][0], m_p = MeR[0][1];
+    const double d_m = DeL[1][0], d_0 = DeL[1][1] + DeR[0][0], d_p = DeR[0][1];
+    const double g_m = GeL[1][0], g_0 = GeL[1][1] + GeR[0][0], g_p = GeR[0][1];
+    const double v_i = veL[1] + veR[0];
+    const double dtnu = a.dt * a.nu;
+    // J_static = M_{t+1} - M_t + dt nu G_{t+1}
+    const double sp_m = -m_m, sp_0 = -m_0, sp_p = -m_p;                              // block t-1
+    const double st_m = m_m + dtnu * d_m, st_0 = m_0 + dtnu * d_0, st_p = m_p + dtnu * d_p;   // block t
+    // ascending column order inside a block: the wrap-around columns of the first / last node move
+    int o_m = 0, o_0 = 1, o_p = 2;
+    if (i == 0) { o_0 = 0; o_p = 1; o_m = 2; }
+    else if (i == a.ns - 1) { o_p = 0; o_m = 1; o_0 = 2; }
+    double* v = a.vals + gid * 6;
+    v[o_m] = sp_m; v[o_0] = sp_0; v[o_p] = sp_p;
+    v[3 + o_m] = st_m + a.dt * g_m; v[3 + o_0] = st_0 + a.dt * g_0; v[3 + o_p] = st_p + a.dt * g_p;
+    // f = J_static * w + dt * v_adv : the product sums a row in ascending column order
+    double sv[6], xv[6];
+    sv[o_m] = sp_m; sv[o_0] = sp_0; sv[o_p] = sp_p; sv[3 + o_m] = st_m; sv[3 + o_0] = st_0; sv[3 + o_p] = st_p;
+    xv[o_m] = wp[im]; xv[o_0] = wp[i]; xv[o_p] = wp[ip]; xv[3 + o_m] = wl; xv[3 + o_0] = wc; xv[3 + o_p] = wr;
+    double acc = 0.0;
+    for (int e = 0; e < 6; ++e) acc += sv[e] * xv[e];
+    a.f[gid] = acc + a.dt * v_i;
+}
+
 }  // namespace gmrf

@@ -2521,6 +2521,96 @@ gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, 
     return GMRF_OK;
 }
 
+// --------------------------------------------------------------------------------- Burgers tangent (8f rank 4)
+struct gmrf_burgers_p1 {
+    int device = -1;                    // -1: pattern only
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t ns = 0, nt = 0, rows = 0, nnz = 0;
+    double dt = 0.0, nu = 0.0;
+    double *d_w = nullptr, *d_vals = nullptr, *d_f = nullptr;       // staging for host callers
+};
+
+gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu,
+                                   gmrf_burgers_p1** out) {
+    if (!out || ns < 3 || nt < 2 || ns > (1 << 24) || nt > (1 << 20) || !(dt > 0.0) || !(nu >= 0.0))
+        return bad_shape("bad Burgers mesh (ns >= 3 nodes, nt >= 2 slices, dt > 0, nu >= 0)");
+    auto* b = new gmrf_burgers_p1();
+    b->ns = ns; b->nt = nt; b->rows = (nt - 1) * ns; b->nnz = b->rows * 6; b->dt = dt; b->nu = nu;
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+            (void)hipGetLastError();
+            delete b;
+            g_last_error = "no HIP device visible (libgmrf_hip needs an MI355X / gfx950 GPU)";
+            return GMRF_ERR_NO_DEVICE;
+        }
+        b->device = device;
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) { if (stream) b->stream = (hipStream_t)stream; else { e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking); b->own_stream = (e == hipSuccess); } }
+        if (e != hipSuccess) { g_last_error = std::string("gmrf_burgers_p1_create: ") + hipGetErrorString(e); delete b; return GMRF_ERR_HIP; }
+    }
+    *out = b;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_burgers_p1_destroy(gmrf_burgers_p1* b) {
+    if (!b) return GMRF_OK;
+    if (b->device >= 0) {
+        (void)hipSetDevice(b->device);
+        if (b->stream) (void)hipStreamSynchronize(b->stream);
+        free_dev(b->d_w); free_dev(b->d_vals); free_dev(b->d_f);
+        if (b->own_stream) (void)hipStreamDestroy(b->stream);
+    }
+    delete b;
+    return GMRF_OK;
+}
+
+// CSR pattern of J: row (t, i), t = 1 .. nt-1 (0-based slices), holds the columns {i-1, i, i+1} (periodic) of slices
+// t-1 and t, ascending
+gmrf_status gmrf_burgers_p1_pattern(const gmrf_burgers_p1* b, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
+                                    int32_t index_base) {
+    if (!b) return bad_shape("null handle");
+    if (nnz_out) *nnz_out = b->nnz;
+    if (rowptr) for (int64_t r = 0; r <= b->rows; ++r) rowptr[r] = 6 * r + index_base;
+    if (colidx)
+        for (int64_t r = 0; r < b->rows; ++r) {
+            const int64_t t = r / b->ns + 1, i = r % b->ns;
+            int64_t c[3] = {(i + b->ns - 1) % b->ns, i, (i + 1) % b->ns};
+            std::sort(c, c + 3);
+            for (int k = 0; k < 3; ++k) {
+                colidx[6 * r + k] = (t - 1) * b->ns + c[k] + index_base;
+                colidx[6 * r + 3 + k] = t * b->ns + c[k] + index_base;
+            }
+        }
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_burgers_p1_tangent(gmrf_burgers_p1* b, const double* w, double* vals_out, double* f_out) {
+    if (!b || !w || !vals_out || !f_out) return bad_shape("bad Burgers tangent arguments");
+    if (b->device < 0) { g_last_error = "pattern-only Burgers assembler (created with device -1)"; return GMRF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(b->device));
+    const int64_t n = b->ns * b->nt;
+    const double* d_w = w;
+    if (!is_device_ptr(w)) {
+        if (!b->d_w) HIPCHK(hipMalloc(&b->d_w, sizeof(double) * n));
+        HIPCHK(hipMemcpyAsync(b->d_w, w, sizeof(double) * n, hipMemcpyHostToDevice, b->stream));
+        d_w = b->d_w;
+    }
+    const bool v_dev = is_device_ptr(vals_out), f_dev = is_device_ptr(f_out);
+    if (!v_dev && !b->d_vals) HIPCHK(hipMalloc(&b->d_vals, sizeof(double) * b->nnz));
+    if (!f_dev && !b->d_f) HIPCHK(hipMalloc(&b->d_f, sizeof(double) * b->rows));
+    BurgersP1Args a;
+    a.ns = (int)b->ns; a.nt = (int)b->nt; a.dt = b->dt; a.nu = b->nu; a.w = d_w;
+    a.vals = v_dev ? vals_out : b->d_vals; a.f = f_dev ? f_out : b->d_f;
+    hipLaunchKernelGGL(burgers_p1_rows, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, b->stream, a);
+    HIPCHK(hipGetLastError());
+    if (!v_dev) HIPCHK(hipMemcpyAsync(vals_out, b->d_vals, sizeof(double) * b->nnz, hipMemcpyDeviceToHost, b->stream));
+    if (!f_dev) HIPCHK(hipMemcpyAsync(f_out, b->d_f, sizeof(double) * b->rows, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return GMRF_OK;
+}
+
 // --------------------------------------------------------------------------------- variances
 static gmrf_status need_single(gmrf_handle* h) {
     if (h->B != 1) return bad_shape("marginal variances are computed per handle with batch 1");

@@ -352,6 +352,25 @@ gmrf_status gmrf_darcy_p1_pattern(const gmrf_darcy_p1* d, int64_t* nnz_out, int6
 gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, int64_t ng, double beta,
                                    double* vals_out, double* f_out);
 
+/* Residual and tangent of the implicit-Euler Burgers space-time system (FEM block assembly, second piece):
+ *     J(w) = J_static + dt J_adv(w),     f(w) = J_static w + dt v_adv(w)
+ * -- f_and_J / nonlinear_primal_tangent, /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149, with
+ * J_static = M_{t+1} - M_t + dt nu G_{t+1} (:123-130; assemble_burgers_mass_diffusion_matrices,
+ * src/problems/burgers.jl:60-98) and assemble_burgers_advection_matrix (src/problems/burgers.jl:5-59, cell loop
+ * :22-51) per time slice -- on the periodic P1 line of the BASELINE Burgers configs: ns nodes on [0,1), nt time
+ * slices, time-major index (t-1) ns + s, 3-point Gauss rule.  J has (nt-1) ns rows (slices 2 .. nt), nt ns columns
+ * and 6 entries per row; the values come out in the CSR order of gmrf_burgers_p1_pattern, which is the `J` that
+ * gmrf_assemble_precision / gmrf_assemble_rhs take: a Gauss-Newton iteration (scripts/solve_burger.jl:143-149)
+ * moves only w across the bus, or nothing at all with device pointers.  w, vals_out ((nt-1) ns 6), f_out
+ * ((nt-1) ns): host or device pointers.  device -1: pattern only. */
+typedef struct gmrf_burgers_p1 gmrf_burgers_p1;
+gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu,
+                                   gmrf_burgers_p1** out);
+gmrf_status gmrf_burgers_p1_destroy(gmrf_burgers_p1* b);
+gmrf_status gmrf_burgers_p1_pattern(const gmrf_burgers_p1* b, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
+                                    int32_t index_base);
+gmrf_status gmrf_burgers_p1_tangent(gmrf_burgers_p1* b, const double* w, double* vals_out, double* f_out);
+
 /* ------------------------------------------------------------------ test hooks
  * Direct access to the dense device kernels for the parity tests (row-major operands on
  * the HOST; not part of the drop-in surface). */

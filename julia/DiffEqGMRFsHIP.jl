@@ -30,7 +30,7 @@ module DiffEqGMRFsHIP
 using SparseArrays, LinearAlgebra
 
 export TridiagonalCholeskyFactor, tridiagonal_cholesky, forward_solve, backward_solve, ldiv, PosteriorAssembler, GmrfCsr,
-       GmrfComm, DarcyP1Assembler
+       GmrfComm, DarcyP1Assembler, BurgersP1Tangent
 
 const libgmrf = get(ENV, "LIBGMRF_HIP", joinpath(@__DIR__, "..", "diffeqgmrfs.jl_amd", "csrc", "libgmrf_hip.so"))
 
@@ -401,6 +401,34 @@ function assemble!(vals::Vector{Float64}, f::Vector{Float64}, d::DarcyP1Assemble
     tab = Matrix{Float64}(coeff')              # the library wants table[x index][y index] row-major = coeff' column-major
     GC.@preserve tab vals f check(ccall((:gmrf_darcy_p1_assemble, libgmrf), Int32,
         (Ptr{Cvoid}, Ptr{Float64}, Int64, Float64, Ptr{Float64}, Ptr{Float64}), d.handle, tab, ng, Float64(beta), vals, f))
+    return vals, f
+end
+
+# Burgers residual and tangent (f_and_J, scripts/burgers/solve_burgers_gmrf-fem.jl:118-149) on the periodic P1 line
+mutable struct BurgersP1Tangent
+    handle::Ptr{Cvoid}
+    pattern::SparseMatrixCSC{Float64,Int}     # TRANSPOSE of J's pattern (CSC of J' = CSR of J), values 1.0
+    rows::Int
+end
+
+function BurgersP1Tangent(ns::Integer, nt::Integer, dt::Real, nu::Real; device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gmrf_burgers_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ref{Ptr{Cvoid}}),
+                device, C_NULL, ns, nt, Float64(dt), Float64(nu), h))
+    nnz_out = Ref{Int64}(0)
+    check(ccall((:gmrf_burgers_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, C_NULL, C_NULL, 1))
+    rows = (nt - 1) * ns
+    rowptr = Vector{Int64}(undef, rows + 1); colidx = Vector{Int64}(undef, nnz_out[])
+    check(ccall((:gmrf_burgers_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, rowptr, colidx, 1))
+    b = BurgersP1Tangent(h[], SparseMatrixCSC(nt * ns, rows, rowptr, colidx, ones(nnz_out[])), rows)
+    finalizer(x -> ccall((:gmrf_burgers_p1_destroy, libgmrf), Int32, (Ptr{Cvoid},), x.handle), b)
+    return b
+end
+
+"`(J values in CSR order, f) = f_and_J(w)`: the values are what `precision!` / `rhs!` of a `PosteriorAssembler` built on `b.pattern` take as J."
+function tangent!(vals::Vector{Float64}, f::Vector{Float64}, b::BurgersP1Tangent, w::Vector{Float64})
+    GC.@preserve w vals f check(ccall((:gmrf_burgers_p1_tangent, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), b.handle, w, vals, f))
     return vals, f
 end
 

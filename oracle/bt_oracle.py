@@ -363,3 +363,89 @@ def max_err(pred, soln):
 def rel_err(pred, soln):
     """src/metrics.jl:11-13."""
     return float(np.linalg.norm(pred - soln) / np.linalg.norm(soln))
+
+
+# --------------------------------------------------------------------------- Burgers tangent (SURVEY 8f rank 4)
+def _p1_line_cellvalues(h: float):
+    """CellValues of one cell of the uniform P1 line, QuadratureRule{1,RefCube}(3): per quadrature point the
+    weight detJ dV, the shape values and the physical shape gradients (constant for P1)."""
+    xi = (-np.sqrt(3.0 / 5.0), 0.0, np.sqrt(3.0 / 5.0))
+    wq = (5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0)
+    jac = 0.5 * h
+    dN = (-0.5 / jac, 0.5 / jac)
+    return [(jac * wq[q], (0.5 * (1.0 - xi[q]), 0.5 * (1.0 + xi[q])), dN) for q in range(3)]
+
+
+def assemble_burgers_advection_matrix(ns: int, cur_weights):
+    """Parity oracle of /root/reference/src/problems/burgers.jl:5-59 (`assemble_burgers_advection_matrix`) on the
+    periodic P1 line with ns nodes on [0,1): cell e has the dofs (e, e + 1 mod ns) -- the periodic constraint of
+    the reference's mesh condensed into the wrap-around, so there are no prescribed dofs left to zero (:53-57).
+    Returns (G as CSR, v).  Line-by-line: the cell loop :22-51, quadrature loop :30-50."""
+    cv = _p1_line_cellvalues(1.0 / ns)
+    G = sp.lil_matrix((ns, ns))
+    v = np.zeros(ns)
+    for e in range(ns):                                        # CellIterator(dh)
+        dofs = (e, (e + 1) % ns)
+        Ge = np.zeros((2, 2)); ve = np.zeros(2)
+        w = (cur_weights[dofs[0]], cur_weights[dofs[1]])       # :28
+        for dOm, N, dN in cv:                                  # :30
+            cur_u = N[0] * w[0] + N[1] * w[1]                  # :34 function_value
+            grad_u = 0.0                                       # :36-39
+            for k in range(2):
+                grad_u += dN[k] * w[k]
+            for i in range(2):                                 # :40
+                for j in range(2):                             # :43
+                    Ge[i, j] += N[i] * (N[j] * grad_u + cur_u * dN[j]) * dOm        # :46
+                ve[i] += N[i] * cur_u * grad_u * dOm           # :48
+        for i in range(2):                                     # :51 assemble!
+            for j in range(2):
+                G[dofs[i], dofs[j]] += Ge[i, j]
+            v[dofs[i]] += ve[i]
+    return G.tocsr(), v
+
+
+def assemble_burgers_mass_diffusion_matrices(ns: int):
+    """/root/reference/src/problems/burgers.jl:60-98 on the same mesh (consistent mass, lumping = false):
+    Me[i][j] = sum_q N_i N_j dOmega, Ge[i][j] = sum_q grad N_i grad N_j dOmega per cell (:80-83), assembled."""
+    cv = _p1_line_cellvalues(1.0 / ns)
+    M = sp.lil_matrix((ns, ns)); G = sp.lil_matrix((ns, ns))
+    for e in range(ns):
+        dofs = (e, (e + 1) % ns)
+        Me = np.zeros((2, 2)); Ge = np.zeros((2, 2))
+        for dOm, N, dN in cv:
+            for i in range(2):
+                for j in range(2):
+                    Me[i, j] += N[i] * N[j] * dOm
+                    Ge[i, j] += dN[i] * dN[j] * dOm
+        for i in range(2):
+            for j in range(2):
+                M[dofs[i], dofs[j]] += Me[i, j]
+                G[dofs[i], dofs[j]] += Ge[i, j]
+    return M.tocsr(), G.tocsr()
+
+
+def burgers_f_and_J(ns: int, nt: int, dt: float, nu: float, w):
+    """`f_and_J(w)` of /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149:
+    J_static = M_{t+1} - M_t + dt nu G_{t+1} (:123-130), per slice t = 2 .. nt the advection tangent and residual
+    (:132-144), f = J_static w + dt f_adv, J = J_static + dt J_adv (:146-149).  Returns (f, J as CSR with sorted
+    indices, (nt - 1) ns x nt ns)."""
+    M, G = assemble_burgers_mass_diffusion_matrices(ns)
+    Z = sp.csr_matrix((ns, ns))
+
+    def s2st(A, t):                                            # spatial_to_spatiotemporal(A, t, nt), t 1-based
+        return sp.hstack([A if k == t - 1 else Z for k in range(nt)], format="csr")
+
+    Mt = sp.vstack([s2st(M, t) for t in range(1, nt)], format="csr")
+    Mt1 = sp.vstack([s2st(M, t) for t in range(2, nt + 1)], format="csr")
+    Gt1 = sp.vstack([s2st(G, t) for t in range(2, nt + 1)], format="csr")
+    J_static = (Mt1 - Mt + (dt * nu) * Gt1).tocsr()
+    Js, vs = [], []
+    w = np.asarray(w, dtype=np.float64)
+    for t in range(2, nt + 1):
+        Gt, vt = assemble_burgers_advection_matrix(ns, w[(t - 1) * ns:t * ns])
+        Js.append(s2st(Gt, t)); vs.append(vt)
+    J_adv = sp.vstack(Js, format="csr"); f_adv = np.concatenate(vs)
+    f = J_static @ w + dt * f_adv
+    J = (J_static + dt * J_adv).tocsr()
+    J.sort_indices()
+    return f, J

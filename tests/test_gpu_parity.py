@@ -1139,3 +1139,49 @@ def test_inverse_rows_inside_the_fused_steps(pkg):
     with pytest.raises(pkg.NotPositiveDefinite) as e:
         F.refactor(bad)
     assert e.value.info == 1000 // w.block_size + 1
+
+
+def test_burgers_tangent_on_device_and_resident_gauss_newton(pkg):
+    """SURVEY 8f rank 4, second piece: f_and_J of scripts/burgers/solve_burgers_gmrf-fem.jl:118-149 (advection tangent
+    src/problems/burgers.jl:5-59 per time slice + the static mass / diffusion part) on the device, entry by entry
+    against the oracle (1e-14 of max |J|: two cells per row, fixed order); then Gauss-Newton iterations
+    (scripts/solve_burger.jl:143-149) in which NOTHING crosses the bus: w -> (J values, f) -> Q + noise J'J and the
+    right-hand side -> re-factor -> solve, all on device tensors, against the oracle's iteration."""
+    import torch
+    rng = np.random.default_rng(8)
+    for ns, nt in ((16, 5), (512, 64), (4096, 6)):
+        dt, nu = 1.0 / (nt - 1), 0.01 / np.pi
+        w = rng.standard_normal(ns * nt)
+        fo, Jo = O.burgers_f_and_J(ns, nt, dt, nu, w)
+        b = pkg.BurgersP1Tangent(ns, nt, dt, nu)
+        vals, f = b.tangent(w)
+        assert np.array_equal(b.pattern.indices, Jo.indices)
+        assert np.max(np.abs(vals - Jo.data)) < 1e-14 * np.max(np.abs(Jo.data))
+        assert np.max(np.abs(f - fo)) < 1e-13 * max(np.max(np.abs(fo)), 1.0)
+        vd, fd = b.tangent(torch.from_numpy(w).cuda())
+        assert vd.is_cuda and np.array_equal(vd.cpu().numpy(), vals) and np.array_equal(fd.cpu().numpy(), f)
+    # device-resident Gauss-Newton on the Burgers prior of the packaged workload (prior + initial condition in Q)
+    ns, nt = 64, 8
+    gn = pkg.workloads.burgers_gauss_newton(ns, nt)
+    dt, nu, noise, N = 1.0 / (nt - 1), 0.01 / np.pi, gn["noise"], gn["n_blocks"]
+    b = pkg.BurgersP1Tangent(ns, nt, dt, nu)
+    asm = pkg.PosteriorAssembler(gn["Q"], b.pattern)
+    qd = torch.from_numpy(gn["Q"].data).cuda(); qx = torch.from_numpy(gn["Qx_prior"]).cuda()
+    x_dev = torch.from_numpy(gn["x_prior"].copy()).cuda()
+    xs = np.arange(ns) / ns
+    x_dev[:ns] = torch.from_numpy(np.sin(2 * np.pi * xs)).cuda()          # a non-trivial starting point
+    xo = x_dev.cpu().numpy().copy()
+    F = None
+    for it in range(3):
+        jv, fv = b.tangent(x_dev)                                           # device in, device out
+        if F is None:
+            P = asm.pattern.copy(); P.data = asm.precision(qd, jv, noise).cpu().numpy()
+            F = pkg.tridiagonal_cholesky(P, N)
+        x_dev = pkg.gn_step(F, asm, qd, qx, jv, x_dev, -fv, noise)
+        fo, Jo = O.burgers_f_and_J(ns, nt, dt, nu, xo)
+        xo = O.gn_step(gn["Q"], Jo, gn["Qx_prior"], xo, -fo, noise, N)
+        assert x_dev.is_cuda and rel(x_dev.cpu().numpy(), xo) < 1e-9
+    # the iteration reduces the residual it linearises
+    f_end, _ = O.burgers_f_and_J(ns, nt, dt, nu, xo)
+    f_start, _ = O.burgers_f_and_J(ns, nt, dt, nu, np.r_[np.sin(2 * np.pi * xs), gn["x_prior"][ns:]])
+    assert np.linalg.norm(f_end) < 0.1 * np.linalg.norm(f_start)

@@ -194,3 +194,39 @@ def test_darcy_p1_pattern_and_oracle_assembly_without_gpu(pkg):
     with pytest.raises(pkg.GmrfError) as e:
         d.assemble(table)
     assert e.value.status == pkg._cabi.ERR_NO_DEVICE
+
+
+def test_burgers_p1_pattern_and_oracle_tangent_without_gpu(pkg):
+    """SURVEY 8f rank 4, second piece: the CSR pattern of the Burgers space-time tangent J (library, device = -1)
+    equals the pattern of the oracle's f_and_J (scripts/burgers/solve_burgers_gmrf-fem.jl:118-149); the oracle's
+    restatement of assemble_burgers_advection_matrix (src/problems/burgers.jl:5-59) is pinned by what the function
+    computes: its matrix is the derivative of its residual vector (finite differences), the residual of a constant
+    state vanishes, mass / diffusion have their closed forms; the numeric phase needs the GPU (no CPU fallback)."""
+    from oracle import bt_oracle as O
+    ns, nt, dt, nu = 16, 5, 0.05, 0.01 / np.pi
+    rng = np.random.default_rng(4)
+    w = rng.standard_normal(ns * nt)
+    f, J = O.burgers_f_and_J(ns, nt, dt, nu, w)
+    b = pkg.BurgersP1Tangent(ns, nt, dt, nu, device=-1)
+    assert b.pattern.shape == J.shape and b.nnz == J.nnz == 6 * (nt - 1) * ns
+    assert np.array_equal(b.pattern.indptr, J.indptr) and np.array_equal(b.pattern.indices, J.indices)
+    # the oracle itself
+    h = 1.0 / ns
+    M, G = O.assemble_burgers_mass_diffusion_matrices(ns)
+    assert abs(M[3, 3] - 4 * h / 6) < 1e-16 and abs(M[3, 4] - h / 6) < 1e-16 and abs(M[0, ns - 1] - h / 6) < 1e-16
+    assert abs(G[3, 3] - 2 / h) < 1e-12 and abs(G[3, 2] + 1 / h) < 1e-12 and abs(G[ns - 1, 0] + 1 / h) < 1e-12
+    u = w[:ns]
+    Gt, vt = O.assemble_burgers_advection_matrix(ns, u)
+    num = np.zeros((ns, ns))
+    for j in range(ns):
+        e = np.zeros(ns); e[j] = 1e-6
+        num[:, j] = (O.assemble_burgers_advection_matrix(ns, u + e)[1] - O.assemble_burgers_advection_matrix(ns, u - e)[1]) / 2e-6
+    assert np.max(np.abs(Gt.toarray() - num)) < 1e-8
+    assert np.max(np.abs(O.assemble_burgers_advection_matrix(ns, np.full(ns, 0.7))[1])) < 1e-15     # u u_x = 0
+    assert abs(vt.sum()) < 1e-13                               # int u u_x over the periodic line
+    # a steady state of the scheme: constant in space and time -> f = 0 (M (u_t+1 - u_t) + dt (nu G u + adv) = 0)
+    f0, _ = O.burgers_f_and_J(ns, nt, dt, nu, np.full(ns * nt, -0.3))
+    assert np.max(np.abs(f0)) < 1e-15
+    with pytest.raises(pkg.GmrfError) as e:
+        b.tangent(w)
+    assert e.value.status == pkg._cabi.ERR_NO_DEVICE
