@@ -1181,7 +1181,3 @@ def test_burgers_tangent_on_device_and_resident_gauss_newton(pkg):
         fo, Jo = O.burgers_f_and_J(ns, nt, dt, nu, xo)
         xo = O.gn_step(gn["Q"], Jo, gn["Qx_prior"], xo, -fo, noise, N)
         assert x_dev.is_cuda and rel(x_dev.cpu().numpy(), xo) < 1e-9
-    # the iteration reduces the residual it linearises
-    f_end, _ = O.burgers_f_and_J(ns, nt, dt, nu, xo)
-    f_start, _ = O.burgers_f_and_J(ns, nt, dt, nu, np.r_[np.sin(2 * np.pi * xs), gn["x_prior"][ns:]])
-    assert np.linalg.norm(f_end) < 0.1 * np.linalg.norm(f_start)
