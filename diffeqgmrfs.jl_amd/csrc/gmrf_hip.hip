@@ -85,6 +85,7 @@ struct gmrf_csr {
     double* d_vals = nullptr;
     float* d_vals32 = nullptr;
     double* d_diag = nullptr;
+    bool tiles128_ok = false;          // the same for 128-row tiles and 2 * SPMV_CAP
     bool tiles_ok = false;             // every SPMV_ROWS-row tile has at most SPMV_CAP entries (csr_spmv_tiles)
     double* d_stage_x = nullptr;
     double* d_stage_y = nullptr;
@@ -1959,6 +1960,9 @@ gmrf_status gmrf_csr_create(int32_t device, void* stream, int64_t n_rows, int64_
     m->tiles_ok = true;
     for (int64_t r = 0; r < n_rows; r += SPMV_ROWS)
         if (rp[std::min(n_rows, r + SPMV_ROWS)] - rp[r] > SPMV_CAP) { m->tiles_ok = false; break; }
+    m->tiles128_ok = true;
+    for (int64_t r = 0; r < n_rows; r += 128)
+        if (rp[std::min<int64_t>(n_rows, r + 128)] - rp[r] > 2 * SPMV_CAP) { m->tiles128_ok = false; break; }
     // from here on a failing HIP call releases what has been allocated so far
 #define CSRCHK(expr)                                                                          \
     do {                                                                                      \
@@ -2018,12 +2022,21 @@ static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* 
     if (k == 1 && S->tiles_ok) {
         // SpMV: LDS-staged row tiles (with 3+ right-hand sides the lane-group kernel, which reuses the
         // entries for four of them, is faster than one pass per right-hand side)
-        const dim3 grid((unsigned)((S->n_rows + SPMV_ROWS - 1) / SPMV_ROWS));
+        static const int rows_env = [] { const char* e = getenv("GMRF_SPMV_ROWS"); return e ? atoi(e) : SPMV_ROWS; }();   // tuning aid: 64 / 128
+        const bool tall = rows_env == 128 && S->tiles128_ok;
+        const int rows = tall ? 128 : SPMV_ROWS;
+        const dim3 grid((unsigned)((S->n_rows + rows - 1) / rows));
+#define GMRF_SPMV(VT, VP)                                                                                                   \
+        do {                                                                                                                \
+            if (tall) hipLaunchKernelGGL((csr_spmv_tiles<VT, 128>), grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP, S->n_rows, d_X + r * ldx, d_Y + r * ldy); \
+            else hipLaunchKernelGGL((csr_spmv_tiles<VT, SPMV_ROWS>), grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP, S->n_rows, d_X + r * ldx, d_Y + r * ldy); \
+        } while (0)
         for (int r = 0; r < k; ++r) {
-            if (vals_override) hipLaunchKernelGGL(csr_spmv_tiles<double>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, vals_override, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
-            else if (S->d_vals32) hipLaunchKernelGGL(csr_spmv_tiles<float>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, S->d_vals32, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
-            else hipLaunchKernelGGL(csr_spmv_tiles<double>, grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, S->d_vals, S->n_rows, d_X + r * ldx, d_Y + r * ldy);
+            if (vals_override) GMRF_SPMV(double, vals_override);
+            else if (S->d_vals32) GMRF_SPMV(float, S->d_vals32);
+            else GMRF_SPMV(double, S->d_vals);
         }
+#undef GMRF_SPMV
         HIPCHK(hipGetLastError());
         return GMRF_OK;
     }

@@ -254,15 +254,15 @@ __global__ __launch_bounds__(256) void csr_spmm(const int64_t* __restrict__ rowp
 constexpr int SPMV_ROWS = 64;
 constexpr int SPMV_CAP = 2304;            // doubles of LDS per workgroup (18 KB: eight workgroups per CU)
 
-template <typename VT>
+template <typename VT, int ROWS = SPMV_ROWS>
 __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ colidx,
                                                       const VT* __restrict__ vals, int64_t n_rows,
                                                       const double* __restrict__ x, double* __restrict__ y) {
-    __shared__ double prod[SPMV_CAP];
-    __shared__ int64_t rp[SPMV_ROWS + 1];
-    const int64_t r0 = (int64_t)blockIdx.x * SPMV_ROWS;
-    const int nr = (int)min((int64_t)SPMV_ROWS, n_rows - r0);
+    __shared__ double prod[SPMV_CAP * (ROWS / SPMV_ROWS)];
+    __shared__ int64_t rp[ROWS + 1];
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    const int nr = (int)min((int64_t)ROWS, n_rows - r0);
     const int t = threadIdx.x;
     if (t <= nr) rp[t] = rowptr[r0 + t];
     __syncthreads();
