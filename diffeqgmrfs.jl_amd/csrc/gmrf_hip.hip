@@ -135,7 +135,10 @@ struct gmrf_handle {
     double c_streamed = 0.0;           // doubles of one C_i inside the staircase (what a k = 1 sweep reads)
     double g2_tile_k = 0.0;            // sum over lower tiles of the K extent of S = -C C^T (flop accounting)
     bool c_dirty = false;              // C must be re-zeroed (new pattern)
-    int* d_lo_rowptr = nullptr;        // [N][bsp + 1] row-wise view of the lower blocks' entry lists
+    int* d_lo_rowptr = nullptr;
+    // tile plan of the sparse C = B X^T (spmm_bxt_tiles): per lower block and 64-row tile the distinct columns, per entry its index into them
+    int* d_bxt_uptr = nullptr; int* d_bxt_ucols = nullptr; uint16_t* d_bxt_lidx = nullptr;
+    int bxt_ecap = 0; int bxt_nrt = 0; bool bxt_plan_ok = false;        // [N][bsp + 1] row-wise view of the lower blocks' entry lists
     int64_t lo_row_max = 0;            // most entries in one row of a lower block
     bool sparse_b = false;             // lower blocks are sparse enough for C = B X^T by spmm_bxt
     bool dense_g1 = false;             // force the dense GEMM for C = B X^T (comparison)
@@ -508,6 +511,48 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
         // the sparse way, anything denser keeps the GEMM.
         h->lo_row_max = max_row;
         h->sparse_b = keys.size() < ((size_t)1 << 31) && max_row <= 32 && h->bsp >= 64;
+        // tile plan for spmm_bxt_tiles (rows of the lower blocks are sorted by (row, column): a 64-row tile is a
+        // contiguous range of entries)
+        free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
+        h->d_bxt_uptr = nullptr; h->d_bxt_ucols = nullptr; h->d_bxt_lidx = nullptr; h->bxt_plan_ok = false;
+        if (h->sparse_b && N > 1) {
+            const int nrt = (int)(h->rmax / 64);
+            std::vector<int> uptr((size_t)(N * (nrt + 1)), 0), ucols;
+            std::vector<uint16_t> lidx(std::max<size_t>(keys.size(), 1), 0);
+            std::vector<int> tmp;
+            bool ok = true;
+            int64_t pmax = 0;
+            for (int64_t i = 1; i < N && ok; ++i) {
+                const int* rp = rowptr.data() + i * (bsp + 1);
+                for (int rt = 0; rt < nrt && ok; ++rt) {
+                    const int ea = rp[rt * 64], eb = rp[rt * 64 + 64];
+                    tmp.clear();
+                    for (int e = ea; e < eb; ++e) tmp.push_back((int)(keys[(size_t)e] & 0xffffffffu));
+                    std::sort(tmp.begin(), tmp.end());
+                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                    if ((int)tmp.size() > BXT_UCAP) { ok = false; break; }
+                    for (int e = ea; e < eb; ++e)
+                        lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), (int)(keys[(size_t)e] & 0xffffffffu)) - tmp.begin());
+                    uptr[(size_t)(i * (nrt + 1) + rt)] = (int)ucols.size();
+                    ucols.insert(ucols.end(), tmp.begin(), tmp.end());
+                    int64_t padded = 0;
+                    for (int r = rt * 64; r < rt * 64 + 64; ++r) padded += (rp[r + 1] - rp[r] + 7) / 8 * 8;
+                    pmax = std::max(pmax, padded);
+                }
+                uptr[(size_t)(i * (nrt + 1) + nrt)] = (int)ucols.size();
+            }
+            const int ecap = (int)std::max<int64_t>(64, (pmax + 63) / 64 * 64);
+            if (ok && bxt_tile_lds_bytes(ecap) <= 53 * 1024) {
+                HIPCHK(hipMalloc(&h->d_bxt_uptr, uptr.size() * sizeof(int)));
+                HIPCHK(hipMalloc(&h->d_bxt_ucols, std::max<size_t>(ucols.size(), 1) * sizeof(int)));
+                HIPCHK(hipMalloc(&h->d_bxt_lidx, lidx.size() * sizeof(uint16_t)));
+                HIPCHK(hipMemcpyAsync(h->d_bxt_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                if (!ucols.empty()) HIPCHK(hipMemcpyAsync(h->d_bxt_ucols, ucols.data(), ucols.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+                HIPCHK(hipMemcpyAsync(h->d_bxt_lidx, lidx.data(), lidx.size() * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
+                HIPCHK(hipStreamSynchronize(h->stream));
+                h->bxt_ecap = ecap; h->bxt_nrt = nrt; h->bxt_plan_ok = true;
+            }
+        }
     }
     h->analyzed = true;
     h->factored = false;
@@ -844,7 +889,20 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                 const dim3 grid((unsigned)((W / ba.cw) * rch * (int)nb));
                 // streamed bytes: C inside the staircase (written) + the rows of Linv from the first gathered column on (read)
                 ProfScope ps(h, 10, 8.0 * (h->c_streamed + 0.5 * (double)W * W) * (double)h->B);
-                if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
+                static const bool no_tiles = [] { const char* e = getenv("GMRF_BXT_TILES"); return e && atoi(e) == 0; }();   // tuning aid
+                if (h->bxt_plan_ok && !no_tiles && h->bxt_nrt == rm / 64) {
+                    BxtTileArgs ta;
+                    ta.rowptr = ba.rowptr; ta.lidx = h->d_bxt_lidx; ta.vals = h->d_vals; ta.n_entries = h->n_entries;
+                    ta.uptr = h->d_bxt_uptr + i * (h->bxt_nrt + 1); ta.ucols = h->d_bxt_ucols;
+                    ta.X = Xp; ta.C = C; ta.ld = ld; ta.ldc = ldc; ta.pX = pX; ta.pC = pC; ta.kst = h->d_kst;
+                    ta.cm = cm; ta.rm = rm; ta.bsp = bsp; ta.ecap = h->bxt_ecap;
+                    const int chunks = W / 16, nrt = rm / 64;
+                    ta.nch = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)chunks * nrt * nb / 512));
+                    const int ncg = (chunks + ta.nch - 1) / ta.nch;
+                    hipLaunchKernelGGL(spmm_bxt_tiles, dim3((unsigned)(ncg * nrt * (int)nb)), dim3(256), bxt_tile_lds_bytes(h->bxt_ecap),
+                                       h->stream, ta);
+                }
+                else if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
                 else if (h->lo_row_max <= 16) hipLaunchKernelGGL(spmm_bxt<16>, grid, dim3(256), 0, h->stream, ba);
                 else hipLaunchKernelGGL(spmm_bxt<32>, grid, dim3(256), 0, h->stream, ba);
                 HIPCHK(hipGetLastError());
@@ -1166,6 +1224,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     free_dev(h->d_lo_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
+    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);

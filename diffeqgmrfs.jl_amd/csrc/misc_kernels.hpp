@@ -197,6 +197,143 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
     }
 }
 
+// The same product with the operands of a 64-row tile staged in LDS (the plan comes from the symbolic phase: per
+// lower block and 64-row tile the sorted DISTINCT columns of its entries, and per entry its 16-bit index into that
+// list -- a stencil tile of 64 rows touches ~200 of the 1024 columns).  spmm_bxt above reads X[c][j_t] once per
+// (row, entry, column) through L1 (18 TB/s of L1 traffic per launch: the texture path is what bounds it); here a
+// workgroup gathers X[c0 .. c0+15][distinct columns] ONCE per 16-column chunk (thread u = distinct column u: 16
+// independent 8-byte loads, coalesced along u, issued while the previous chunk is being multiplied), writes them as
+// swizzled 128-byte LDS rows [u][16] and then runs the multiply phase of csr_spmm_tiles_pad: lane (row, kq) owns the
+// columns 4 kq .. 4 kq + 3 of the chunk, entries padded to multiples of 8 per row (aligned 16-byte index / value
+// reads), fixed CSR summation order -- the results are bitwise those of spmm_bxt.  C leaves as 128-byte lines.
+struct BxtTileArgs {
+    const int* rowptr;        // this block's [bsp + 1] row pointers (absolute entry indices)
+    const uint16_t* lidx;     // per entry (absolute index): position of its column in the tile's list
+    const double* vals;       // [problems][n_entries]
+    int64_t n_entries;
+    const int* uptr;          // this block's [nrt + 1] offsets into ucols
+    const int* ucols;         // distinct columns (0-based inside the block), ascending per tile
+    const double* X;
+    double* C;
+    int64_t ld, ldc, pX, pC;
+    const int* kst;
+    int cm, rm, bsp;
+    int nch;                  // 16-column chunks per workgroup
+    int ecap;                 // padded entries per tile (LDS capacity, multiple of 8)
+};
+
+constexpr int BXT_UCAP = 256;             // distinct columns per tile (one per thread)
+
+inline size_t bxt_tile_lds_bytes(int ecap) {
+    return (size_t)BXT_UCAP * 16 * 8 + (size_t)ecap * 10 + (size_t)BXT_UCAP * 4 + (size_t)(2 * 64 + 2) * 4 + 16;
+}
+
+__global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* xs = smem;                                       // [BXT_UCAP][16], swizzled
+    double* vs = xs + BXT_UCAP * 16;                         // [ecap]
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + a.ecap); // [ecap]
+    int* uc = reinterpret_cast<int*>(ls + a.ecap);           // [BXT_UCAP]
+    int* rp = uc + BXT_UCAP;                                 // [65]
+    int* pp = rp + 65;                                       // [65]
+    const int t = threadIdx.x;
+    const int nrt = a.rm / 64;
+    const int W = a.bsp - a.cm;
+    const int ncg = (W / 16 + a.nch - 1) / a.nch;
+    const int nprob = (int)gridDim.x / (ncg * nrt);
+    int cg, rt, prob;
+    {
+        const int groups = (nprob % 8 == 0) ? 8 : 1;
+        const int xg = (int)blockIdx.x % groups, q = (int)blockIdx.x / groups;
+        rt = q % nrt;
+        cg = (q / nrt) % ncg;
+        prob = xg + groups * (q / (nrt * ncg));
+    }
+    const int r0 = rt * 64;
+    const int cfirst = a.cm + (a.kst ? a.kst[rt] : 0);
+    int cbeg = a.cm + cg * a.nch * 16;
+    const int cend = min(a.cm + W, cbeg + a.nch * 16);
+    cbeg = max(cbeg, (cfirst / 16) * 16);
+    if (cbeg >= cend) return;                                // whole column group left of the staircase (uniform per workgroup)
+    const double* __restrict__ X = a.X + (int64_t)prob * a.pX;
+    double* __restrict__ C = a.C + (int64_t)prob * a.pC;
+    const double* __restrict__ vals = a.vals + (int64_t)prob * a.n_entries;
+    const int e0 = a.rowptr[r0];
+    if (t < 64) {                                            // padded row starts: one wave scans
+        const int ea = a.rowptr[r0 + t] - e0, eb = a.rowptr[r0 + t + 1] - e0;
+        int x = (eb - ea + 7) & ~7;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_up(x, d, 64);
+            if (t >= d) x += y;
+        }
+        rp[t] = ea; pp[t + 1] = x;
+        if (t == 63) rp[64] = eb;
+        if (t == 0) pp[0] = 0;
+    }
+    const int u0 = a.uptr[rt];
+    const int U = a.uptr[rt + 1] - u0;
+    const int ucol = (t < U) ? a.ucols[u0 + t] : -1;
+    __syncthreads();
+    const int kq = t & 3, row = t >> 2;
+    {   // entries of this thread's row, 4 lanes per row, padded with (value 0, the row's first index)
+        const int ea = rp[row], len = rp[row + 1] - ea, pa = pp[row], plen = pp[row + 1] - pa;
+        const uint16_t first = (len > 0) ? a.lidx[e0 + ea] : (uint16_t)0;
+        for (int j = kq; j < plen; j += 4) {
+            const bool ok = j < len;
+            ls[pa + j] = ok ? a.lidx[e0 + ea + j] : first;
+            vs[pa + j] = ok ? vals[e0 + ea + j] : 0.0;
+        }
+    }
+    double g[16];
+    auto gather = [&](int c0) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) g[cc] = (ucol >= 0) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
+    };
+    gather(cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
+        if (t < U) {
+            // row t of the staged image: slot s (columns 2 s, 2 s + 1 of the chunk = lane kq = s >> 1, half s & 1 ->
+            // logical slot (half << 2 | kq)) at position logical ^ swizzle(t); swizzle keeps both the 16 rows a
+            // ds_write_b128 serves together and the 4 rows x 4 lanes of a read on distinct banks
+            const int swz = (((t >> 1) & 1) << 2) ^ ((t >> 2) & 3);
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int logical = ((s2 & 1) << 2) | (s2 >> 1);
+                *reinterpret_cast<v2d*>(xs + t * 16 + 2 * (logical ^ swz)) = (v2d){g[2 * s2], g[2 * s2 + 1]};
+            }
+        }
+        __syncthreads();                                     // (first chunk: also the staged entries)
+        if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
+        v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
+        for (int e = pp[row]; e < pp[row + 1]; e += 8) {
+            const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
+            const v2d v01 = *reinterpret_cast<const v2d*>(vs + e), v23 = *reinterpret_cast<const v2d*>(vs + e + 2);
+            const v2d v45 = *reinterpret_cast<const v2d*>(vs + e + 4), v67 = *reinterpret_cast<const v2d*>(vs + e + 6);
+            const int ii[8] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16),
+                               (int)(q.z & 0xffffu), (int)(q.z >> 16), (int)(q.w & 0xffffu), (int)(q.w >> 16)};
+            const double vv[8] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
+            v2d xa[8], xb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int swz = (((ii[u] >> 1) & 1) << 2) ^ ((ii[u] >> 2) & 3);
+                const int o = (ii[u] << 4) + 2 * (kq ^ swz);                 // in doubles: row * 16 + 2 * slot(kq, half 0)
+                xa[u] = *reinterpret_cast<const v2d*>(xs + o);
+                xb[u] = *reinterpret_cast<const v2d*>(xs + (o ^ 8));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a01.x = fma(vv[u], xa[u].x, a01.x); a01.y = fma(vv[u], xa[u].y, a01.y);
+                a23.x = fma(vv[u], xb[u].x, a23.x); a23.y = fma(vv[u], xb[u].y, a23.y);
+            }
+        }
+        double* cp = C + (int64_t)(r0 + row) * a.ldc + (c0 - a.cm) + 4 * kq;
+        *reinterpret_cast<v2d*>(cp) = a01;
+        *reinterpret_cast<v2d*>(cp + 2) = a23;
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------- K6
 // CSR SpMV/SpMM  Y = S X, X and Y stored one right-hand side after the other (strides
 // ldx/ldy).  Replaces SparseArrays' `Q * x` (scripts/solve_burger.jl:157-158,166,177 and the
