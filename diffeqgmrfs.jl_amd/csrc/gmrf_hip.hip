@@ -96,7 +96,7 @@ struct gmrf_csr {
     int32_t* d_ucols = nullptr;        // distinct columns of every tile, ascending
     uint16_t* d_lidx = nullptr;        // per entry: index of its column in the tile's list
     int64_t n_ucols = 0;
-    int plan_rows = 0, plan_ucap = 0, plan_ecap = 0, plan_ecap_pad = 0;   // rows per tile, LDS capacities (distinct columns, entries)
+    int plan_rows = 0, plan_ucap = 0, plan_ecap = 0, plan_ecap_pad = 0, plan_umax = 0;   // rows per tile, LDS capacities (distinct columns, entries)
 };
 
 // ------------------------------------------------------------------------------------ handle
@@ -2169,8 +2169,12 @@ static gmrf_status spmm_plan(gmrf_csr* m) {
         const int ucap = (int)std::max<int64_t>(32, (umax + 31) / 32 * 32), ecap = (int)std::max<int64_t>(256, (emax + 255) / 256 * 256);
         const int ecap_pad = (int)std::max<int64_t>(256, (pmax + 255) / 256 * 256);
         if (spmm_tile_lds_bytes(R, ucap, ecap) > lds_budget) continue;
-        m->plan_rows = R; m->plan_ucap = ucap; m->plan_ecap = ecap;
-        m->plan_ecap_pad = (spmm_tile_pad_lds_bytes(R, ucap, ecap_pad) <= lds_budget + 1024) ? ecap_pad : 0;
+        m->plan_rows = R; m->plan_ucap = ucap; m->plan_ecap = ecap; m->plan_umax = (int)umax;
+        // (the padded kernel sizes its LDS image by the distinct columns rounded to 8, the entries to 64: 39.3 KB on the
+        //  burgers4096x512 matrix -- four workgroups per CU)
+        const int ecap_pad64 = (int)std::max<int64_t>(64, (pmax + 63) / 64 * 64);
+        m->plan_ecap_pad = (spmm_tile_pad_lds_bytes(R, (int)((umax + 7) / 8 * 8), ecap_pad64) <= lds_budget + 1024) ? ecap_pad64 : 0;
+        (void)ecap_pad;
         m->n_ucols = (int64_t)ucols.size();
         HIPCHK(hipMalloc(&m->d_tile_uptr, sizeof(int64_t) * (T + 1)));
         HIPCHK(hipMalloc(&m->d_ucols, sizeof(int32_t) * std::max<size_t>(ucols.size(), 1)));
@@ -2199,14 +2203,15 @@ static gmrf_status spmm_rows_device(const gmrf_csr* S, hipStream_t st, const dou
         static const bool no_pad = [] { const char* e = getenv("GMRF_SPMM_PAD"); return e && atoi(e) == 0; }();   // tuning aid
         const bool pad = m->plan_ecap_pad > 0 && !no_pad;
         const int ecl = pad ? m->plan_ecap_pad : ec;
-        const size_t lds = pad ? spmm_tile_pad_lds_bytes(R, uc, ecl) : spmm_tile_lds_bytes(R, uc, ec);
+        const int ucl = pad ? (m->plan_umax + 7) / 8 * 8 : uc;          // LDS rows of the staged X image
+        const size_t lds = pad ? spmm_tile_pad_lds_bytes(R, ucl, ecl) : spmm_tile_lds_bytes(R, uc, ec);
         // 7 gather loads per thread and chunk serve up to 224 distinct columns per tile, 10 up to 320
 #define GMRF_SPMM_TILES(VT, VP)                                                                                          \
         do {                                                                                                             \
             if (pad && uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles_pad<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
-                                              S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ecl);  \
+                                              S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, ucl, ecl);  \
             else if (pad) hipLaunchKernelGGL((csr_spmm_tiles_pad<VT, SPMM_NG>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP,    \
-                                    S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ecl);            \
+                                    S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, ucl, ecl);            \
             else if (uc <= 224) hipLaunchKernelGGL((csr_spmm_tiles<VT, 7>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP, \
                                               S->d_tile_uptr, S->d_ucols, S->n_rows, d_X, ldx, d_Y, ldy, k, R, uc, ec);  \
             else hipLaunchKernelGGL((csr_spmm_tiles<VT, SPMM_NG>), grid, dim3(SPMM_THREADS), lds, st, S->d_rowptr, S->d_lidx, VP,    \

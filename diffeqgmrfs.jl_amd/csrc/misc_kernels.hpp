@@ -225,14 +225,14 @@ struct BxtTileArgs {
 constexpr int BXT_UCAP = 256;             // distinct columns per tile (one per thread)
 
 inline size_t bxt_tile_lds_bytes(int ecap) {
-    return (size_t)BXT_UCAP * 16 * 8 + (size_t)ecap * 10 + (size_t)BXT_UCAP * 4 + (size_t)(2 * 64 + 2) * 4 + 16;
+    return (size_t)BXT_UCAP * 16 * 8 + (size_t)ecap * 10 + 128 * 8 + (size_t)BXT_UCAP * 4 + (size_t)(2 * 64 + 2) * 4 + 16;
 }
 
 __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xs = smem;                                       // [BXT_UCAP][16], swizzled
-    double* vs = xs + BXT_UCAP * 16;                         // [ecap]
-    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + a.ecap); // [ecap]
+    double* vs = xs + BXT_UCAP * 16;                         // [ecap + 128]  (row r skewed by 2 r doubles, see csr_spmm_tiles_pad)
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + a.ecap + 128); // [ecap]
     int* uc = reinterpret_cast<int*>(ls + a.ecap);           // [BXT_UCAP]
     int* rp = uc + BXT_UCAP;                                 // [65]
     int* pp = rp + 65;                                       // [65]
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         for (int j = kq; j < plen; j += 4) {
             const bool ok = j < len;
             ls[pa + j] = ok ? a.lidx[e0 + ea + j] : first;
-            vs[pa + j] = ok ? vals[e0 + ea + j] : 0.0;
+            vs[pa + j + 2 * row] = ok ? vals[e0 + ea + j] : 0.0;
         }
     }
     double g[16];
@@ -308,8 +308,9 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
         for (int e = pp[row]; e < pp[row + 1]; e += 8) {
             const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
-            const v2d v01 = *reinterpret_cast<const v2d*>(vs + e), v23 = *reinterpret_cast<const v2d*>(vs + e + 2);
-            const v2d v45 = *reinterpret_cast<const v2d*>(vs + e + 4), v67 = *reinterpret_cast<const v2d*>(vs + e + 6);
+            const double* ve = vs + e + 2 * row;
+            const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
+            const v2d v45 = *reinterpret_cast<const v2d*>(ve + 4), v67 = *reinterpret_cast<const v2d*>(ve + 6);
             const int ii[8] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16),
                                (int)(q.z & 0xffffu), (int)(q.z >> 16), (int)(q.w & 0xffffu), (int)(q.w >> 16)};
             const double vv[8] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
@@ -623,8 +624,9 @@ __global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles_pad(const int6
                                                                    int R, int ucap, int ecap) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xs = smem;                                       // [ucap][16], swizzled (below)
-    double* vs = xs + (size_t)ucap * SPMM_KC;               // [ecap]   (padded rows)
-    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + ecap);   // [ecap]
+    double* vs = xs + (size_t)ucap * SPMM_KC;               // [ecap + 2 R]  (padded rows; row r skewed by 2 r doubles: rows 16 entries
+                                                             //               apart would put rows r and r + 2 on the same banks)
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + ecap + 2 * R);   // [ecap]
     int* uc = reinterpret_cast<int*>(ls + ecap);             // [ucap]   (ecap is a multiple of 8)
     int* rp = uc + ucap;                                     // [R + 1]  CSR offsets relative to the tile
     int* pp = rp + R + 1;                                    // [R + 1]  padded offsets
@@ -666,12 +668,12 @@ __global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles_pad(const int6
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int j = kq + 4 * i;
-                if (j < plen) { ls[pa + j] = (j < len) ? li[i] : first; vs[pa + j] = v[i]; }
+                if (j < plen) { ls[pa + j] = (j < len) ? li[i] : first; vs[pa + j + 2 * row] = v[i]; }
             }
             for (int j = 16 + kq; j < plen; j += 4) {
                 const bool ok = j < len;
                 ls[pa + j] = ok ? lidx[e0 + a + j] : first;
-                vs[pa + j] = ok ? (double)vals[e0 + a + j] : 0.0;
+                vs[pa + j + 2 * row] = ok ? (double)vals[e0 + a + j] : 0.0;
             }
         }
     }
@@ -710,8 +712,9 @@ __global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles_pad(const int6
             v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
             for (int e = e_begin; e < e_end; e += 8) {
                 const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
-                const v2d v01 = *reinterpret_cast<const v2d*>(vs + e), v23 = *reinterpret_cast<const v2d*>(vs + e + 2);
-                const v2d v45 = *reinterpret_cast<const v2d*>(vs + e + 4), v67 = *reinterpret_cast<const v2d*>(vs + e + 6);
+                const double* ve = vs + e + 2 * min(row, R);
+                const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
+                const v2d v45 = *reinterpret_cast<const v2d*>(ve + 4), v67 = *reinterpret_cast<const v2d*>(ve + 6);
                 const int ii[8] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16),
                                    (int)(q.z & 0xffffu), (int)(q.z >> 16), (int)(q.w & 0xffffu), (int)(q.w >> 16)};
                 const double vv[8] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
@@ -745,7 +748,7 @@ __global__ __launch_bounds__(SPMM_THREADS, 3) void csr_spmm_tiles_pad(const int6
 }
 
 inline size_t spmm_tile_pad_lds_bytes(int R, int ucap, int ecap_pad) {
-    return (size_t)ucap * SPMM_KC * 8 + (size_t)ecap_pad * 8 + (size_t)ecap_pad * 2 + (size_t)ucap * 4 + (size_t)(2 * R + 2) * 4 + 16;
+    return (size_t)ucap * SPMM_KC * 8 + (size_t)(ecap_pad + 2 * R) * 8 + (size_t)ecap_pad * 2 + (size_t)ucap * 4 + (size_t)(2 * R + 2) * 4 + 16;
 }
 
 // Node-major right-hand sides without a tile plan (a tile with too many entries or distinct columns,
