@@ -26,8 +26,14 @@
 
 namespace gmrf {
 
-constexpr int TLD = 68;                 // LDS row stride (doubles) of a 64x64 tile: 16-byte aligned rows,
-                                        // ds_read_b128 of MFMA operand pairs conflict free (stride = 4 mod 8)
+#ifndef GMRF_TLD
+#define GMRF_TLD 66
+#endif
+constexpr int TLD = GMRF_TLD;           // LDS row stride (doubles) of a 64x64 tile: 16-byte aligned rows; 66 doubles = 132 banks
+                                        // = 4 mod 64: the 16 rows a ds_read_b128 serves together (one row per lane, or MFMA
+                                        // operand pairs of 16 rows) start 4 banks apart and cover the 64 banks exactly once
+                                        // (68 = 8 mod 64 put rows r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT was
+                                        // 0.34 of the tile kernel's LDS-active cycles)
 constexpr int TILE_ELEMS = 64 * TLD;
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
