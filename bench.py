@@ -215,23 +215,26 @@ def spmm_roofline(pkg, torch):
     the stream the kernels run on.  bytes = nnz (vbytes + 4) + 8 (n + 1) + 16 n k."""
     w = pkg.workloads.make("burgers4096x512")
     out = {"matrix": f"{w.name}: n={w.n}, nnz={w.Q.nnz}", "bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "cases": {}}
-    st = torch.cuda.current_stream()
+    st = torch.cuda.Stream()          # an explicit stream: the null stream's handle is 0 = "make your own" for gmrf_csr_create,
+    torch.cuda.set_stream(st)         # and the async products below must run on the stream the events are recorded on
     for f32 in (False, True):
         S = pkg.CsrMatrix(w.Q, values_f32=f32, stream=st.cuda_stream)
         for k in (1, 64):
             X = torch.randn(w.n, dtype=torch.float64, device="cuda") if k == 1 else torch.randn(w.n, k, dtype=torch.float64, device="cuda")
             # warm up to steady clocks: the matrix was just built on the host (GPU idle for seconds), and the first
             # ~30 ms of launches after an idle period run 15-20 % slower (tools/spmm_clock_probe.py)
-            t_w = time.perf_counter()
-            while time.perf_counter() - t_w < 0.1:
-                for _ in range(10):
-                    S @ X
+            Y = torch.empty_like(X)
+            # (uninterrupted queues of launches: a warm-up that synchronises every few launches leaves the first timed
+            #  batch 8 % slow -- tools/spmm_mem_probe.py: 627 us, then 577 us for the following batches)
+            for _ in range(2):
+                for _ in range(60):
+                    S.matmul_into(X, Y)
                 torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 30
             e0.record(st)
             for _ in range(reps):
-                S @ X
+                S.matmul_into(X, Y)          # stream-ordered (gmrf_spmm*_async): launches back to back, no host sync in between
             e1.record(st)
             e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
@@ -239,6 +242,8 @@ def spmm_roofline(pkg, torch):
             out["cases"][f"{'fp32' if f32 else 'fp64'}_k{k}"] = {"us": us, "achieved": b / us / 1e3, "frac": b / us / 1e3 / PEAK_HBM_GBPS,
                                                                   "algorithmic_bytes": b}
         del S
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
     return out
 
 

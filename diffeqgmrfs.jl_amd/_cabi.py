@@ -32,7 +32,7 @@ EXPORTS = [
     "gmrf_bt_marginal_var_batch", "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_comm_unique_id", "gmrf_comm_create", "gmrf_comm_destroy", "gmrf_comm_bcast_host", "gmrf_comm_allreduce_sum",
     "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_streams_create", "gmrf_streams_destroy",
-    "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows",
+    "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows", "gmrf_spmm_async", "gmrf_spmm_rows_async",
     "gmrf_darcy_p1_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
     "gmrf_burgers_p1_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
@@ -151,6 +151,8 @@ def load() -> C.CDLL:
         "gmrf_burgers_p1_pattern": [vp, P(i64), vp, vp, i32],
         "gmrf_burgers_p1_tangent": [vp, vp, vp, vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
+        "gmrf_spmm_async": [vp, vp, vp, i64, i64, i64],
+        "gmrf_spmm_rows_async": [vp, vp, vp, i64, i64, i64],
         "gmrf_spmm_rows": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],
         "gmrf_test_gemm_rate": [i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, P(dbl)],

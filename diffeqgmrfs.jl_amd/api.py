@@ -93,6 +93,19 @@ class CsrMatrix:
     def __matmul__(self, X):
         return self.matmul(X)
 
+    def matmul_into(self, X, Y):
+        """Stream-ordered Y = S X for torch CUDA tensors, written into `Y`, without synchronising (gmrf_spmm_async /
+        gmrf_spmm_rows_async): X (n,) or C-contiguous (n, k) = node-major; Y of the matching shape."""
+        if not (_is_torch(X) and _is_torch(Y) and X.is_cuda and Y.is_cuda and X.is_contiguous() and Y.is_contiguous()):
+            raise TypeError("matmul_into takes contiguous torch CUDA tensors")
+        lib = _cabi.load()
+        if X.ndim == 1:
+            _cabi.check(lib.gmrf_spmm_async(self._h, _cabi.ptr(X), _cabi.ptr(Y), 1, self.shape[1], self.shape[0]))
+        else:
+            k = X.shape[1]
+            _cabi.check(lib.gmrf_spmm_rows_async(self._h, _cabi.ptr(X), _cabi.ptr(Y), k, k, k))
+        return Y
+
     def matmul_rows(self, X):
         """Y = S X for X stored node-major: an (n, k) C-contiguous NumPy array or torch CUDA tensor (the k
         values of a node side by side).  This is the layout of the LDS-tiled SpMM kernel."""

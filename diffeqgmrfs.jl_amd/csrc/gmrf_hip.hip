@@ -2298,6 +2298,24 @@ gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k, 
     return GMRF_OK;
 }
 
+// Stream-ordered variants for device-resident operands: no staging, no synchronisation -- the product is enqueued on
+// the matrix's stream and the call returns (pipelines of `Q * x` on the device: Gauss-Newton loops, estimators).
+gmrf_status gmrf_spmm_async(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy) {
+    if (!S || !X || !Y) return bad_shape("null pointer");
+    if (k <= 0 || ldx < S->n_cols || ldy < S->n_rows) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(S->device));
+    if (!is_device_ptr(X) || !is_device_ptr(Y)) return bad_shape("gmrf_spmm_async takes device pointers");
+    return spmm_device(S, S->stream, X, ldx, Y, ldy, (int)k);
+}
+
+gmrf_status gmrf_spmm_rows_async(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy) {
+    if (!S || !X || !Y) return bad_shape("null pointer");
+    if (k <= 0 || k > (1 << 20) || ldx < k || ldy < k) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(S->device));
+    if (!is_device_ptr(X) || !is_device_ptr(Y)) return bad_shape("gmrf_spmm_rows_async takes device pointers");
+    return spmm_rows_device(S, S->stream, X, ldx, Y, ldy, (int)k);
+}
+
 // --------------------------------------------------------------------------------- posterior assembly
 struct gmrf_assembler {
     int device = -1;                    // -1: symbolic only (pattern queries; no numeric phase)

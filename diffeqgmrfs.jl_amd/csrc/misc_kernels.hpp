@@ -402,10 +402,12 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
     const int64_t r0 = (int64_t)blockIdx.x * ROWS;
     const int nr = (int)min((int64_t)ROWS, n_rows - r0);
     const int t = threadIdx.x;
+    // the tile's entry range comes from two wave-uniform (scalar) loads, so the entry loads start at once; the row
+    // pointers of the tile travel to LDS beside them and are not needed before the row sums (the barrier below) --
+    // one vector-load latency and one barrier less on the dependent chain rowptr -> entries -> x
+    const int64_t e0 = rowptr[r0];
+    const int cnt = (int)(rowptr[r0 + nr] - e0);
     if (t <= nr) rp[t] = rowptr[r0 + t];
-    __syncthreads();
-    const int64_t e0 = rp[0];
-    const int cnt = (int)(rp[nr] - e0);
     // four entries per thread and pass, all loads issued before the first product is stored
     for (int base = 0; base < cnt; base += 1024) {
         int c[4];

@@ -308,6 +308,10 @@ gmrf_status gmrf_spmm(const gmrf_csr* S, const double* X, double* Y, int64_t k,
  * scripts/darcy/solve_darcy_gmrf-fem.jl:100,192). */
 gmrf_status gmrf_spmm_rows(const gmrf_csr* S, const double* X, double* Y, int64_t k,
                            int64_t ldx, int64_t ldy);
+/* Stream-ordered variants for DEVICE operands: the product is enqueued on the matrix's stream (gmrf_csr_create) and
+ * the call returns without synchronising -- `Q * x` inside a device-resident loop. */
+gmrf_status gmrf_spmm_async(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy);
+gmrf_status gmrf_spmm_rows_async(const gmrf_csr* S, const double* X, double* Y, int64_t k, int64_t ldx, int64_t ldy);
 
 /* ------------------------------------------------------------------ posterior assembly
  * The step before the factorisation in the reference's Gauss-Newton loop

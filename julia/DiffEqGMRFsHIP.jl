@@ -335,6 +335,16 @@ function mul_node_major(S::GmrfCsr, Xt::StridedMatrix{Float64})
     return Yt
 end
 
+"""
+Stream-ordered products for DEVICE arrays (raw device pointers, e.g. `pointer(::ROCArray)` of AMDGPU.jl): enqueued on
+the matrix's stream, no synchronisation.  `mul_async!(S, dY, dX, k)`: each right-hand side contiguous (n x k column-major);
+`mul_node_major_async!`: k x n (the k values of a node contiguous).
+"""
+mul_async!(S::GmrfCsr, dY::Ptr{Float64}, dX::Ptr{Float64}, k::Integer = 1) =
+    check(ccall((:gmrf_spmm_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64), S.handle, dX, dY, k, S.n, S.m))
+mul_node_major_async!(S::GmrfCsr, dYt::Ptr{Float64}, dXt::Ptr{Float64}, k::Integer) =
+    check(ccall((:gmrf_spmm_rows_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Int64), S.handle, dXt, dYt, k, k, k))
+
 # ------------------------------------------------------------------------------------------ gn_step assembly
 # Gauss-Newton assembly on the device (gn_step, scripts/solve_burger.jl:143-149)
 "Symbolic phase for A = Q + noise * J' * J with fixed patterns; J is passed through its transpose's CSC arrays (= CSR of J)."

@@ -1181,3 +1181,25 @@ def test_burgers_tangent_on_device_and_resident_gauss_newton(pkg):
         fo, Jo = O.burgers_f_and_J(ns, nt, dt, nu, xo)
         xo = O.gn_step(gn["Q"], Jo, gn["Qx_prior"], xo, -fo, noise, N)
         assert x_dev.is_cuda and rel(x_dev.cpu().numpy(), xo) < 1e-9
+
+
+def test_spmm_stream_ordered_variants(pkg):
+    """gmrf_spmm_async / gmrf_spmm_rows_async: device operands, enqueued on the matrix's stream without a host
+    synchronisation; results bitwise those of the synchronous calls; host pointers are refused."""
+    import torch
+    w = pkg.workloads.make("darcy64")
+    st = torch.cuda.current_stream()
+    S = pkg.CsrMatrix(w.Q, stream=st.cuda_stream)
+    x = torch.randn(w.n, dtype=torch.float64, device="cuda")
+    X = torch.randn(w.n, 16, dtype=torch.float64, device="cuda")
+    y, Y = torch.empty_like(x), torch.empty_like(X)
+    for _ in range(3):                                  # back to back, no synchronisation in between
+        S.matmul_into(x, y); S.matmul_into(X, Y)
+    torch.cuda.synchronize()
+    assert torch.equal(y, S @ x) and torch.equal(Y, S @ X)
+    assert np.max(np.abs(y.cpu().numpy() - w.Q @ x.cpu().numpy())) < 1e-12 * np.max(np.abs(y.cpu().numpy()))
+    with pytest.raises(TypeError):
+        S.matmul_into(x.cpu(), y)
+    lib = pkg._cabi.load()
+    xh = np.zeros(w.n)
+    assert lib.gmrf_spmm_async(S._h, pkg._cabi.ptr(xh), pkg._cabi.ptr(y), 1, w.n, w.n) == pkg._cabi.ERR_BAD_SHAPE
