@@ -162,6 +162,7 @@ class ProblemsJob:
                     e_t.F.set_eager(eager_flags)
                 j_t = post.ShardedPosterior(e_t, k_samples=samples, replicate_factor=True)
                 j_t.prepare()
+                j_t.step(1 << 20)     # set-up, untimed: captures the sweep / sample graphs too, whatever --warmup is
             self.jobs.append((st_t, e_t, j_t))
         self.eng, self.job = self.jobs[0][1], self.jobs[0][2]
 
@@ -338,6 +339,7 @@ def main():
         job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group,
                                     force_shared=args.force_shared)
         job.prepare()
+        job.step(1 << 20)             # set-up, untimed (every rank): graph captures, first broadcasts
         return eng, job
 
     if shared:
