@@ -2084,7 +2084,8 @@ static gmrf_status spmm_device(const gmrf_csr* S, hipStream_t st, const double* 
         static const int rows_env = [] { const char* e = getenv("GMRF_SPMV_ROWS"); return e ? atoi(e) : SPMV_ROWS; }();   // tuning aid: 64 / 128
         const bool tall = rows_env == 128 && S->tiles128_ok;
         const int rows = tall ? 128 : SPMV_ROWS;
-        const dim3 grid((unsigned)((S->n_rows + rows - 1) / rows));
+        static const int wg_cap = [] { const char* e = getenv("GMRF_SPMV_WGS"); return e ? atoi(e) : 256 * 8; }();   // tuning aid: resident workgroups
+        const dim3 grid((unsigned)std::min<int64_t>((S->n_rows + rows - 1) / rows, wg_cap > 0 ? wg_cap : (1 << 30)));
 #define GMRF_SPMV(VT, VP)                                                                                                   \
         do {                                                                                                                \
             if (tall) hipLaunchKernelGGL((csr_spmv_tiles<VT, 128>), grid, dim3(bl), 0, st, S->d_rowptr, S->d_colidx, VP, S->n_rows, d_X + r * ldx, d_Y + r * ldy); \

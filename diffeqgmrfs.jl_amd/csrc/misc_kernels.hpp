@@ -399,41 +399,46 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
                                                       const double* __restrict__ x, double* __restrict__ y) {
     __shared__ double prod[SPMV_CAP * (ROWS / SPMV_ROWS)];
     __shared__ int64_t rp[ROWS + 1];
-    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-    const int nr = (int)min((int64_t)ROWS, n_rows - r0);
     const int t = threadIdx.x;
-    // the tile's entry range comes from two wave-uniform (scalar) loads, so the entry loads start at once; the row
-    // pointers of the tile travel to LDS beside them and are not needed before the row sums (the barrier below) --
-    // one vector-load latency and one barrier less on the dependent chain rowptr -> entries -> x
-    const int64_t e0 = rowptr[r0];
-    const int cnt = (int)(rowptr[r0 + nr] - e0);
-    if (t <= nr) rp[t] = rowptr[r0 + t];
-    // four entries per thread and pass, all loads issued before the first product is stored
-    for (int base = 0; base < cnt; base += 1024) {
-        int c[4];
-        double v[4];
+    const int64_t ntiles = (n_rows + ROWS - 1) / ROWS;
+    // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher caps the grid at a few resident
+    // workgroups per CU: 32 768 four-wave workgroups of ~1.3 us each were bound by the dispatch rate, not by memory)
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * ROWS;
+        const int nr = (int)min((int64_t)ROWS, n_rows - r0);
+        // the tile's entry range comes from two wave-uniform (scalar) loads, so the entry loads start at once; the row
+        // pointers of the tile travel to LDS beside them and are not needed before the row sums (the barrier below)
+        const int64_t e0 = rowptr[r0];
+        const int cnt = (int)(rowptr[r0 + nr] - e0);
+        if (t <= nr) rp[t] = rowptr[r0 + t];
+        // four entries per thread and pass, all loads issued before the first product is stored
+        for (int base = 0; base < cnt; base += 1024) {
+            int c[4];
+            double v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = base + t + 256 * i;
-            const bool ok = e < cnt;
-            c[i] = ok ? colidx[e0 + e] : 0;
-            v[i] = ok ? (double)vals[e0 + e] : 0.0;
+            for (int i = 0; i < 4; ++i) {
+                const int e = base + t + 256 * i;
+                const bool ok = e < cnt;
+                c[i] = ok ? colidx[e0 + e] : 0;
+                v[i] = ok ? (double)vals[e0 + e] : 0.0;
+            }
+            double xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xv[i] = x[c[i]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = base + t + 256 * i;
+                if (e < cnt) prod[e] = v[i] * xv[i];
+            }
         }
-        double xv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = x[c[i]];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = base + t + 256 * i;
-            if (e < cnt) prod[e] = v[i] * xv[i];
+        __syncthreads();
+        if (t < nr) {
+            const int a = (int)(rp[t] - e0), b = (int)(rp[t + 1] - e0);
+            double s = 0.0;
+            for (int e = a; e < b; ++e) s += prod[e];
+            y[r0 + t] = s;
         }
-    }
-    __syncthreads();
-    if (t < nr) {
-        const int a = (int)(rp[t] - e0), b = (int)(rp[t + 1] - e0);
-        double s = 0.0;
-        for (int e = a; e < b; ++e) s += prod[e];
-        y[r0 + t] = s;
+        __syncthreads();                                   // prod / rp are rewritten by the next tile
     }
 }
 
