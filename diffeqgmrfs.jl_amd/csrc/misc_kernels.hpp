@@ -403,42 +403,71 @@ __global__ __launch_bounds__(256) void csr_spmv_tiles(const int64_t* __restrict_
     const int64_t ntiles = (n_rows + ROWS - 1) / ROWS;
     // a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher caps the grid at a few resident
     // workgroups per CU: 32 768 four-wave workgroups of ~1.3 us each were bound by the dispatch rate, not by memory)
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // software pipeline over the tiles of this workgroup: the entries (first pass of 1024) of the NEXT tile are requested
+    // while the current tile's x values are gathered and its rows are summed
+    int64_t tile = blockIdx.x;
+    int64_t e0 = 0;
+    int cnt = 0;
+    int c[4];
+    double v[4];
+    auto fetch = [&](int64_t tl, int64_t& e0o, int& cnto, int (&co)[4], double (&vo)[4]) {
+        const int64_t r0f = tl * ROWS;
+        const int nrf = (int)min((int64_t)ROWS, n_rows - r0f);
+        e0o = rowptr[r0f];
+        cnto = (int)(rowptr[r0f + nrf] - e0o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = t + 256 * i;
+            const bool ok = e < cnto;
+            co[i] = ok ? colidx[e0o + e] : 0;
+            vo[i] = ok ? (double)vals[e0o + e] : 0.0;
+        }
+    };
+    if (tile < ntiles) fetch(tile, e0, cnt, c, v);
+    for (; tile < ntiles; tile += gridDim.x) {
         const int64_t r0 = tile * ROWS;
         const int nr = (int)min((int64_t)ROWS, n_rows - r0);
-        // the tile's entry range comes from two wave-uniform (scalar) loads, so the entry loads start at once; the row
-        // pointers of the tile travel to LDS beside them and are not needed before the row sums (the barrier below)
-        const int64_t e0 = rowptr[r0];
-        const int cnt = (int)(rowptr[r0 + nr] - e0);
-        if (t <= nr) rp[t] = rowptr[r0 + t];
-        // four entries per thread and pass, all loads issued before the first product is stored
-        for (int base = 0; base < cnt; base += 1024) {
-            int c[4];
-            double v[4];
+        if (t <= nr) rp[t] = rowptr[r0 + t];               // not needed before the row sums (the barrier below)
+        double xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = x[c[i]];
+        int64_t e0n = 0;
+        int cntn = 0;
+        int cn[4] = {0, 0, 0, 0};
+        double vn[4] = {0.0, 0.0, 0.0, 0.0};
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, e0n, cntn, cn, vn);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = t + 256 * i;
+            if (e < cnt) prod[e] = v[i] * xv[i];
+        }
+        for (int base = 1024; base < cnt; base += 1024) {     // (tiles with more than 1024 entries: the rest, unpipelined)
+            int c2[4];
+            double v2[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = base + t + 256 * i;
                 const bool ok = e < cnt;
-                c[i] = ok ? colidx[e0 + e] : 0;
-                v[i] = ok ? (double)vals[e0 + e] : 0.0;
+                c2[i] = ok ? colidx[e0 + e] : 0;
+                v2[i] = ok ? (double)vals[e0 + e] : 0.0;
             }
-            double xv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] = x[c[i]];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = base + t + 256 * i;
-                if (e < cnt) prod[e] = v[i] * xv[i];
+                if (e < cnt) prod[e] = v2[i] * x[c2[i]];
             }
         }
         __syncthreads();
         if (t < nr) {
             const int a = (int)(rp[t] - e0), b = (int)(rp[t + 1] - e0);
-            double s = 0.0;
-            for (int e = a; e < b; ++e) s += prod[e];
-            y[r0 + t] = s;
+            double sacc = 0.0;
+            for (int e = a; e < b; ++e) sacc += prod[e];
+            y[r0 + t] = sacc;
         }
         __syncthreads();                                   // prod / rp are rewritten by the next tile
+        e0 = e0n; cnt = cntn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { c[i] = cn[i]; v[i] = vn[i]; }
     }
 }
 
