@@ -273,7 +273,26 @@ def main():
     ap.add_argument("--eager-flags", type=int, default=0, help="gmrf_bt_set_eager bits for every handle (experiments)")
     ap.add_argument("--force-shared", action="store_true",
                     help="rehearsal: run the shared-factor code (process group, communicator, broadcasts) with a world of one rank")
+    ap.add_argument("--regimes", default="256,1024",
+                    help="N > 1: further samples-per-rank-and-posterior regimes of the shared-factor job (side leg)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher: start the N ranks here (a torch.distributed.run child, spawned
+    # before this process makes any GPU call) and relay their output and exit code.
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+    if int(world_env or "1") != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env or 1}: start one rank per GPU "
+              f"(python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}), or "
+              f"run `python bench.py --gpus {args.gpus}` without a launcher", file=sys.stderr)
+        sys.exit(2)
 
     import numpy as np
     import torch
@@ -320,27 +339,51 @@ def main():
     if shared:
         want = args.transport
         if want in ("auto", "cabi") and not one_device:
-            try:
-                box = [pkg.api.Comm.unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(box, src=0)
-                comm = pkg.api.Comm(local, rank, world, box[0])
-                transport = "cabi"
-            except Exception as e:      # noqa: BLE001 -- any failure: RCCL through torch.distributed instead
-                extra["cabi_comm_error"] = repr(e)[:300]
-                comm, transport = None, "torch"
-            ok = torch.tensor([1 if transport == "cabi" else 0], device="cuda")
+            # Every rank takes part in every collective of the negotiation whatever fails where: rank 0 always
+            # broadcasts the box (None when librccl could not be opened), every rank then says whether it can open
+            # the library (all-reduce MIN), and only if all can does any rank enter ncclCommInitRank.
+            box = [None]
+            if rank == 0:
+                try:
+                    box = [pkg.api.Comm.unique_id()]
+                except Exception as e:      # noqa: BLE001
+                    extra["cabi_comm_error"] = repr(e)[:300]
+            dist.broadcast_object_list(box, src=0)
+            can = 0
+            if box[0] is not None:
+                try:
+                    pkg.api.Comm.unique_id()          # opens librccl in this process (the id itself is discarded)
+                    can = 1
+                except Exception as e:      # noqa: BLE001
+                    extra["cabi_comm_error"] = repr(e)[:300]
+            ok = torch.tensor([can], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                comm, transport = None, "torch"
+            if int(ok.item()) == 1:
+                comm = pkg.api.Comm(local, rank, world, box[0])   # a failure here is fatal on this rank (raises): the
+                transport = "cabi"                                # others sit in ncclCommInitRank until the launcher ends the job
 
     def shared_job(wl, batch, k_per_rank, values=None, rhs=None):
         eng = post.HipEngine(pkg, wl, device_index=local, batch=batch, values=values, rhs=rhs, keep_l=keep_l,
                              transport=transport, comm=comm)
         job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group,
-                                    force_shared=args.force_shared)
+                                    force_shared=args.force_shared, keep_samples=False, timing=True)
         job.prepare()
         job.step(1 << 20)             # set-up, untimed (every rank): graph captures, first broadcasts
         return eng, job
+
+    def gather_phases(j):
+        """Per-rank device phase times of the last step: the root's, and the slowest receiver's."""
+        torch.cuda.synchronize()
+        ph = j.phase_ms()
+        box = [None] * world
+        dist.all_gather_object(box, ph)
+        if rank != 0:
+            return None
+        recv = [b for b in box[1:] if b]
+        res = {"root": {k: round(v, 3) for k, v in box[0].items()}}
+        if recv:
+            res["receivers_max"] = {k: round(max(b[k] for b in recv), 3) for k in recv[0]}
+        return res
 
     if shared:
         B = max(1, args.shared_batch)
@@ -352,11 +395,22 @@ def main():
             for s in range(count):
                 job.step(first + s)
         run(0, args.warmup)
+        eng.transport_bytes(reset=True)
         elapsed = timed(run, sync, dist, torch, args.warmup, args.steps)
         per_step = job.solves_per_step()
+        moved = eng.transport_bytes(reset=True) / max(args.steps, 1)
+        phases = gather_phases(job)
+        # what the N > 1 line is made of (no scaling curve has been measured on real multi-GPU hardware before the
+        # driver's SCALE run; these fields say which regime a record is in): the root factors, every range crosses xGMI
+        # as a packed image (lower-triangular tiles of Linv + the stored C windows), every rank samples.
+        extra["shared_factor"] = {
+            "bytes_broadcast_per_step": moved, "bytes_broadcast_per_posterior": moved / B,
+            "transport": transport, "phase_ms_last_step": phases,
+            "reading": "root-bound when root.factor_ms dominates ms_per_step; broadcast-bound when transfer_wait_ms does; "
+                       "the samples-per-factor regimes of side_legs.regimes show where sharing the factor pays"}
         workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored by rank 0, "
-                    f"Linv / C ranges of {args.group} blocks broadcast to {world} ranks beside the factorisation, every rank: "
-                    f"{B} mean(s) + {args.samples} samples per posterior")
+                    f"Linv / C ranges of {args.group} blocks broadcast (packed lower-triangular tiles) to {world} ranks beside the "
+                    f"factorisation, every rank: {B} mean(s) + {args.samples} samples per posterior")
         sharding = f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), samples sharded by Philox sample id"
     else:
         pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l,
@@ -390,33 +444,71 @@ def main():
         # after --side-leg-limit seconds and rank 0 prints the line it already has.
         import threading
 
+        leg = {"name": "set-up"}
+
         def give_up():
+            # a rank that is still in a side leg after the limit is stuck (a collective that never completes = a GPU
+            # hang): rank 0 prints the headline line it already has, every rank leaves with a NON-ZERO code so that
+            # the launcher and the driver see the failure.  Nothing is restarted from here.
             if rank == 0:
-                out["side_legs"] = {"error": f"side legs exceeded {args.side_leg_limit} s and were abandoned"}
+                out["side_legs"] = dict(side, error=f"side legs exceeded {args.side_leg_limit} s and were abandoned "
+                                                    f"in leg '{leg['name']}'; exit code 3")
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            sys.stderr.write(f"bench.py rank {rank}: side-leg watchdog fired in leg '{leg['name']}'\n")
+            sys.stderr.flush()
+            os._exit(3)
+        side = {}
         watchdog = threading.Timer(args.side_leg_limit, give_up)
         watchdog.daemon = True
         watchdog.start()
         # (a) the same job on ONE rank (no broadcast): what sharing the factor is compared with
-        side = {}
+        # (r) the same shared-factor job at more samples per factor and rank: the factor (and its broadcast) is paid once
+        # per posterior, the sample sweeps scale with the ranks -- which regime reaches what multiple of one rank
+        leg["name"] = "regimes"
+        regimes = [int(x) for x in args.regimes.split(",") if x.strip()]
+        reg = {}
+        for kr in regimes:
+            jr = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=kr, group=args.group,
+                                       force_shared=args.force_shared, keep_samples=False, timing=True)
+            jr.step(1 << 21)
+
+            def run_r(first, count, jr=jr):
+                for s in range(count):
+                    jr.step(first + s)
+            el = timed(run_r, sync, dist, torch, 0, 3)
+            ph = gather_phases(jr)
+            if rank == 0:
+                reg[str(kr)] = {"value": jr.solves_per_step() * 3 / el, "unit": "solves/s", "ms_per_step": 1e3 * el / 3,
+                                "samples_per_posterior_and_rank": kr, "phase_ms_last_step": ph}
+        # (a) the same jobs on ONE rank (no broadcast): what sharing the factor is compared with
+        leg["name"] = "one_rank_same_job"
         if rank == 0:
             e1 = post.HipEngine(pkg, w, device_index=local, batch=eng.batch, values=eng.values_host, rhs=eng.rhs[:, 0, :].cpu().numpy(), keep_l=keep_l)
-            j1 = post.ShardedPosterior(e1, k_samples=args.samples, replicate_factor=True)
-            j1.prepare()
-            j1.step(0)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for s in range(3):
-                j1.step(1 + s)
-            torch.cuda.synchronize()
-            t1 = (time.perf_counter() - t0) / 3
-            side["one_rank_same_job"] = {"ms_per_step": 1e3 * t1, "value": e1.batch * (1 + args.samples) / t1,
-                                         "note": "rank 0 alone: factor + mean + 64 samples per posterior, no broadcast"}
+            for kr in [args.samples] + regimes:
+                j1 = post.ShardedPosterior(e1, k_samples=kr, replicate_factor=True, keep_samples=False)
+                if kr == args.samples:
+                    j1.prepare()
+                j1.step(0)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for s in range(3):
+                    j1.step(1 + s)
+                torch.cuda.synchronize()
+                t1 = (time.perf_counter() - t0) / 3
+                rec = {"ms_per_step": 1e3 * t1, "value": e1.batch * (1 + kr) / t1,
+                       "note": f"rank 0 alone: factor + mean + {kr} samples per posterior, no broadcast"}
+                if kr == args.samples:
+                    side["one_rank_same_job"] = rec
+                    rec["n_rank_over_one_rank"] = out["value"] / rec["value"]
+                else:
+                    reg[str(kr)]["one_rank"] = rec
+                    reg[str(kr)]["n_rank_over_one_rank"] = reg[str(kr)]["value"] / rec["value"]
+            side["regimes"] = reg
             e1.F.close()
         eng.F.close()
         sync()
         # (b) C4: elliptic 512^2, 256 samples sharded over the ranks, one shared factor
+        leg["name"] = "c4_elliptic512"
         try:
             w4 = pkg.workloads.make("elliptic512")
             k4 = max(1, 256 // world)
@@ -437,6 +529,7 @@ def main():
                 side["c4_elliptic512"] = {"error": repr(e)[:300]}
         sync()
         # (c) independent problems per rank (the N = 1 line's mode): no data-path collective
+        leg["name"] = "problems_mode"
         pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
         pj.run(0, 1)
         steps_p = max(2, args.steps // 4)
@@ -545,14 +638,32 @@ def main():
             out["cpu_baseline"] = base
             out["speedup_vs_cpu"] = out["value"] / base["value"]
             out["cpu_sparse_direct"] = cpu_sparse_direct(w, args.samples)
-            # parity of the HIP path on the CPU sample (the full-size oracle comparison lives in tests/test_gpu_parity.py)
-            Fs = pkg.tridiagonal_cholesky(Qs, nbs)
-            mu_h = pkg.ldiv(Fs, rhs_s)
-            Xh = Fs.sample(args.samples, mean=mu_o, z=Z)
-            out["parity"] = {"on": f"the CPU sample (leading {nbs} blocks)",
-                             "mean_rel_l2": float(np.linalg.norm(mu_h - mu_o) / np.linalg.norm(mu_o)),
-                             "samples_rel_l2": float(np.linalg.norm(Xh - X_o) / np.linalg.norm(X_o))}
-            Fs.close()
+            # parity of the TIMED route against the oracle (the full-size comparison of the same route lives in
+            # tests/test_gpu_parity.py::test_measured_path_darcy256_batch_against_oracle): a batch of 8 coefficient fields
+            # on the leading blocks of the workload, keep_l = 0, on a StreamSet stream, ShardedPosterior.step replayed
+            # from its graphs -- mean, 64 device-drawn samples, logdet, exact and RBMC(50) variances of one problem
+            from tests import measured_path as MP
+            from oracle import bt_oracle as O
+            fields = [w]
+            for p in range(1, 8):
+                wp = pkg.workloads.darcy(int(args.config[5:]), seed=523802340 + p) if args.config.startswith("darcy") else None
+                fields.append(wp if wp is not None and wp.Q.nnz == w.Q.nnz and np.array_equal(wp.Q.indices, w.Q.indices) else None)
+            ns_p = nbs * w.block_size
+            Qp0 = w.Q.tocsr()[:ns_p, :ns_p].tocsc(); Qp0.sort_indices()
+            vals_p, rhs_p = [], []
+            for p, f in enumerate(fields):
+                if f is None:
+                    vals_p.append(Qp0.data * (1.0 + 0.01 * p)); rhs_p.append(w.rhs[:ns_p])
+                else:
+                    Qf = f.Q.tocsr()[:ns_p, :ns_p].tocsc(); Qf.sort_indices()
+                    vals_p.append(Qf.data); rhs_p.append(f.rhs[:ns_p])
+            pb = max(8, args.batch // 8 * 8)              # the timed batch size: same grids and kernel symbols per launch
+            mp = MP.run(pkg, post, O, Qp0, nbs, np.stack([vals_p[p % 8] for p in range(pb)]),
+                        np.stack([rhs_p[p % 8] for p in range(pb)]), k_samples=args.samples, check=(5,),
+                        last_blocks=min(4, nbs), rbmc_k=50)
+            out["parity"] = {"on": f"problem 5 of a batch of {pb} (8 coefficient fields) on the leading {nbs} blocks of {w.name}, driven like the "
+                                   f"timed region (HipEngine / ShardedPosterior.step on a StreamSet stream, keep_l = 0, graph replay), "
+                                   f"against the oracle", **mp[5], "kernel_classes_launched": mp["route"]}
     if rank == 0:
         print(json.dumps(out))
     if comm is not None:

@@ -31,7 +31,8 @@ EXPORTS = [
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_bt_marginal_var_batch", "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_comm_unique_id", "gmrf_comm_create", "gmrf_comm_destroy", "gmrf_comm_bcast_host", "gmrf_comm_allreduce_sum",
-    "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_streams_create", "gmrf_streams_destroy",
+    "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_comm_bytes", "gmrf_streams_create", "gmrf_streams_destroy",
+    "gmrf_bt_packed_size", "gmrf_bt_pack_blocks_async", "gmrf_bt_unpack_blocks_async",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows", "gmrf_spmm_async", "gmrf_spmm_rows_async",
     "gmrf_darcy_p1_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
     "gmrf_burgers_p1_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
@@ -120,6 +121,10 @@ def load() -> C.CDLL:
         "gmrf_comm_allreduce_sum": [vp, vp, vp, i64],
         "gmrf_bt_bcast_blocks_async": [vp, vp, i32, i64, i64, i32],
         "gmrf_comm_wait": [vp, vp],
+        "gmrf_comm_bytes": [vp, i32, P(dbl)],
+        "gmrf_bt_packed_size": [vp, i64, i64, P(i64)],
+        "gmrf_bt_pack_blocks_async": [vp, i64, i64, vp],
+        "gmrf_bt_unpack_blocks_async": [vp, i64, i64, vp],
         "gmrf_streams_create": [i32, i32, vp, vp],
         "gmrf_streams_destroy": [i32, i32, vp],
         "gmrf_bt_factor_begin_csc": [vp, i64, i64, vp, vp, vp, i32],

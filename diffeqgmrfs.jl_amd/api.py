@@ -567,9 +567,18 @@ class TridiagonalCholeskyFactor:
         return v.value
 
     def normals(self, k: int, seed: int = 0x5EED, first_id: int = 0, like=None):
+        if self.batch != 1:
+            raise ValueError("a batched handle draws (batch, k, n) normals: normals_batch")
         store, view = _alloc_like(like if like is not None else np.empty(0), self.N, k, False)
         _cabi.check(self._lib.gmrf_bt_normals(self._h, seed, first_id, k, _cabi.ptr(store), self.N))
         return view
+
+    def normals_batch(self, k: int, seed: int = 0x5EED, first_id: int = 0):
+        """(B, k, n) host array of the N(0,1) draws `sample_batch(k, seed=, first_id=)` and the batched variance
+        estimators use: problem p, draw s = Philox id first_id + p*k + s."""
+        out = np.empty((self.batch, k, self.N), dtype=np.float64)
+        _cabi.check(self._lib.gmrf_bt_normals(self._h, seed, first_id, k, _cabi.ptr(out), self.N))
+        return out
 
     def sample(self, k: int, mean=None, z=None, seed: int = 0x5EED, first_id: int = 0, like=None):
         """k posterior samples mean + L^-T z as an n x k matrix (rand(rng, x_cond))."""
@@ -684,6 +693,19 @@ class TridiagonalCholeskyFactor:
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         _cabi.check(self._lib.gmrf_bt_block_range(self._h, kind, i0, i1, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
+
+    def packed_size(self, i0: int, i1: int) -> int:
+        """Doubles per problem of the packed transport image of blocks [i0, i1) (gmrf_bt_packed_size)."""
+        v = C.c_int64(0)
+        _cabi.check(self._lib.gmrf_bt_packed_size(self._h, i0, i1, C.byref(v)))
+        return v.value
+
+    def pack_blocks_async(self, i0: int, i1: int, dev_buf):
+        """Blocks [i0, i1) of every problem -> dev_buf ((batch, packed_size) torch CUDA tensor), stream-ordered."""
+        _cabi.check(self._lib.gmrf_bt_pack_blocks_async(self._h, i0, i1, _cabi.ptr(dev_buf)))
+
+    def unpack_blocks_async(self, i0: int, i1: int, dev_buf):
+        _cabi.check(self._lib.gmrf_bt_unpack_blocks_async(self._h, i0, i1, _cabi.ptr(dev_buf)))
 
     def factor_begin(self, A, N_blocks: int):
         A = sp.csc_matrix(A)
@@ -854,6 +876,12 @@ class Comm:
 
     def wait(self, F: TridiagonalCholeskyFactor):
         _cabi.check(self._lib.gmrf_comm_wait(F._h, self._h))
+
+    def bytes_moved(self, reset: bool = False) -> float:
+        """Factor bytes broadcast through this communicator so far."""
+        v = C.c_double(0.0)
+        _cabi.check(self._lib.gmrf_comm_bytes(self._h, int(reset), C.byref(v)))
+        return v.value
 
     def allreduce_sum(self, dev_tensor, F: Optional[TridiagonalCholeskyFactor] = None):
         _cabi.check(self._lib.gmrf_comm_allreduce_sum(self._h, F._h if F is not None else None, _cabi.ptr(dev_tensor),

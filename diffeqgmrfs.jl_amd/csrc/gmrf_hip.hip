@@ -147,6 +147,8 @@ struct gmrf_handle {
     bool external_storage = false;
     bool keep_l = true;                // false: L_i lives in a one-block work buffer (sweeps need Linv and C only)
     bool l_valid = false;              // d_L holds the blocks of the current factor (get_block / export / logdet from L)
+    bool logdet_valid = false;         // d_logdet holds every block's log-determinant part of the current factor
+    std::vector<char> got_block;       // blocks received through gmrf_bt_unpack_blocks_async since the last adopt / commit
     int64_t alloc_rm = 0, alloc_wc = 0;
     bool alloc_keep_l = true;
     double *d_S = nullptr, *d_B = nullptr, *d_T = nullptr, *d_W = nullptr;
@@ -341,6 +343,7 @@ static gmrf_status alloc_factor(gmrf_handle* h) {
         h->alloc_wc == c_ld(h) && h->alloc_keep_l == h->keep_l && h->d_Linv)
         return GMRF_OK;
     destroy_graphs(h);
+    h->logdet_valid = false;
     if (h->external_storage) {
         // caller-owned L / C / Linv (sized by gmrf_bt_storage_bytes for this shape and batch): only the
         // work buffers follow the layout
@@ -978,6 +981,7 @@ static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
     }
     h->factored = true;
     h->l_valid = h->keep_l;
+    h->logdet_valid = !h->keep_l;      // without the L blocks the factorisation left every block's part in d_logdet
     return GMRF_OK;
 }
 
@@ -1403,7 +1407,7 @@ gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, int
     h->d_S = h->d_B = h->d_T = h->d_W = h->d_logdet = nullptr;
     h->d_L = (double*)dev_L; h->d_C = (double*)dev_C; h->d_Linv = (double*)dev_Linv;
     h->external_storage = true;
-    h->factored = false; h->l_valid = false;          // whatever was factored lived in the old buffers
+    h->factored = false; h->l_valid = false; h->logdet_valid = false;   // whatever was factored lived in the old buffers
     if (!h->keep_l) {                                  // one-block work buffer for L_i
         HIPCHK(hipMalloc(&h->d_L, (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B));
         HIPCHK(hipMemsetAsync(h->d_L, 0, (size_t)blk_elems(h) * sizeof(double) * (size_t)h->B, h->stream));
@@ -1429,7 +1433,7 @@ gmrf_status gmrf_bt_set_keep_l(gmrf_handle* h, int32_t keep) {
     HIPCHK(hipStreamSynchronize(h->stream));
     destroy_graphs(h);
     h->keep_l = keep != 0;
-    h->factored = false; h->l_valid = false;
+    h->factored = false; h->l_valid = false; h->logdet_valid = false;
     return GMRF_OK;
 }
 
@@ -1466,7 +1470,8 @@ gmrf_status gmrf_bt_adopt_layout(gmrf_handle* h, int64_t n, int64_t n_blocks, co
         HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
         h->c_dirty = false;
     }
-    h->factored = false; h->l_valid = false;
+    h->factored = false; h->l_valid = false; h->logdet_valid = false;
+    h->got_block.assign((size_t)h->N, 0);
     HIPCHK(hipStreamSynchronize(h->stream));
     return GMRF_OK;
 }
@@ -1480,6 +1485,12 @@ gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid) {
     if (!h || !h->d_Linv) return bad_shape("no factor storage");
     h->factored = true;
     h->l_valid = l_blocks_valid != 0 && h->keep_l;
+    // the log-determinant parts travel inside the packed transport image (gmrf_bt_unpack_blocks_async): valid once
+    // every block of this factor came that way; a factor moved as raw buffers has none (logdet then needs the L blocks)
+    bool all = !h->got_block.empty();
+    for (char g : h->got_block) all = all && g;
+    h->logdet_valid = all;
+    h->got_block.assign((size_t)h->N, 0);
     return GMRF_OK;
 }
 
@@ -1512,6 +1523,79 @@ gmrf_status gmrf_bt_block_range(gmrf_handle* h, int32_t kind, int64_t i0, int64_
         *problem_stride = kind == GMRF_BLOCK_L ? stride_pL(h) : stride_pX(h);
     } else return bad_shape("bad block kind");
     return GMRF_OK;
+}
+
+// Packed transport image of the blocks [i0, i1) of every problem of the batch: per problem one segment of
+//   (i1 - i0) * ntri * 4096   lower-triangular 64 x 64 tiles of Linv_i0 .. Linv_{i1-1} (linv_tiles_copy),
+//   (c1 - c0) * c_blk          stored windows of the coupling blocks C_{i0-1} .. C_{i1-2},
+//   (i1 - i0) rounded to even  log-determinant parts of the blocks
+// doubles: darcy256 0.56 GB per posterior instead of the 0.83 GB of the raw Linv / C buffers.
+static void packed_counts(const gmrf_handle* h, int64_t i0, int64_t i1, int64_t* x_elems, int64_t* c_elems, int64_t* ld_elems,
+                          int64_t* c0_out) {
+    const int64_t nt = h->bsp / 64, ntri = nt * (nt + 1) / 2;
+    const int64_t c0 = std::max<int64_t>(i0 - 1, 0), c1 = std::max<int64_t>(i1 - 1, 0);
+    *x_elems = (i1 - i0) * ntri * 4096;
+    *c_elems = (c1 - c0) * c_blk(h);
+    *ld_elems = ((i1 - i0) + 1) / 2 * 2;
+    if (c0_out) *c0_out = c0;
+}
+
+gmrf_status gmrf_bt_packed_size(gmrf_handle* h, int64_t i0, int64_t i1, int64_t* elems_per_problem) {
+    if (!h || !elems_per_problem) return bad_shape("null pointer");
+    if (h->N <= 0 || i0 < 0 || i1 > h->N || i0 >= i1) return bad_shape("bad block range");
+    int64_t xe, ce, le;
+    packed_counts(h, i0, i1, &xe, &ce, &le, nullptr);
+    *elems_per_problem = xe + ce + le;
+    return GMRF_OK;
+}
+
+static gmrf_status pack_blocks_on(gmrf_handle* h, hipStream_t st, int64_t i0, int64_t i1, double* buf, bool pack) {
+    if (!h->d_Linv || h->N <= 0) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
+    if (i0 < 0 || i1 > h->N || i0 >= i1) return bad_shape("bad block range");
+    if (!buf || !is_device_ptr(buf)) return bad_shape("the transport image lives in device memory");
+    int64_t xe, ce, le, c0;
+    packed_counts(h, i0, i1, &xe, &ce, &le, &c0);
+    const int64_t seg = xe + ce + le;
+    const int nt = (int)(h->bsp / 64), ntri = nt * (nt + 1) / 2;
+    const dim3 grid((unsigned)(ntri * (i1 - i0)), (unsigned)h->B);
+    double* X = h->d_Linv + i0 * blk_elems(h);
+    if (pack) hipLaunchKernelGGL(linv_tiles_copy<true>, grid, dim3(256), 0, st, X, h->bsp, blk_elems(h), stride_pX(h), buf, seg, ntri);
+    else hipLaunchKernelGGL(linv_tiles_copy<false>, grid, dim3(256), 0, st, X, h->bsp, blk_elems(h), stride_pX(h), buf, seg, ntri);
+    HIPCHK(hipGetLastError());
+    if (ce > 0) {
+        double* Cw = h->d_C + c0 * c_blk(h);
+        if (pack) HIPCHK(hipMemcpy2DAsync(buf + xe, seg * sizeof(double), Cw, stride_pC(h) * sizeof(double), ce * sizeof(double),
+                                          (size_t)h->B, hipMemcpyDeviceToDevice, st));
+        else HIPCHK(hipMemcpy2DAsync(Cw, stride_pC(h) * sizeof(double), buf + xe, seg * sizeof(double), ce * sizeof(double),
+                                     (size_t)h->B, hipMemcpyDeviceToDevice, st));
+    }
+    if (pack && h->keep_l) {
+        // with the L blocks resident nobody has taken their log-determinant parts yet
+        hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)(i1 - i0), (unsigned)h->B), dim3(256), 0, st, h->d_L + i0 * blk_elems(h),
+                           blk_elems(h), h->bsp, (int)h->bs, h->d_logdet + i0, stride_pL(h), h->N);
+        HIPCHK(hipGetLastError());
+    }
+    if (pack) HIPCHK(hipMemcpy2DAsync(buf + xe + ce, seg * sizeof(double), h->d_logdet + i0, h->N * sizeof(double),
+                                      (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
+    else {
+        HIPCHK(hipMemcpy2DAsync(h->d_logdet + i0, h->N * sizeof(double), buf + xe + ce, seg * sizeof(double),
+                                (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
+        if (h->got_block.size() != (size_t)h->N) h->got_block.assign((size_t)h->N, 0);
+        for (int64_t i = i0; i < i1; ++i) h->got_block[(size_t)i] = 1;
+    }
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_bt_pack_blocks_async(gmrf_handle* h, int64_t i0, int64_t i1, double* dev_buf) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return pack_blocks_on(h, h->stream, i0, i1, dev_buf, true);
+}
+
+gmrf_status gmrf_bt_unpack_blocks_async(gmrf_handle* h, int64_t i0, int64_t i1, const double* dev_buf) {
+    if (!h) return bad_shape("null handle");
+    HIPCHK(hipSetDevice(h->device));
+    return pack_blocks_on(h, h->stream, i0, i1, const_cast<double*>(dev_buf), false);
 }
 
 gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* out, int64_t ld) {
@@ -1701,6 +1785,9 @@ struct gmrf_comm {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     void* d_small = nullptr;               // staging of small host records (layout, scalars)
     size_t small_cap = 0;
+    double* d_pack = nullptr;              // staging of the packed transport image of a block range
+    size_t pack_cap = 0;
+    double bytes_moved = 0.0;              // factor bytes broadcast so far (gmrf_comm_bytes)
 };
 
 gmrf_status gmrf_comm_unique_id(void* id128) {
@@ -1740,7 +1827,7 @@ gmrf_status gmrf_comm_destroy(gmrf_comm* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
-    free_dev(c->d_small);
+    free_dev(c->d_small); free_dev(c->d_pack);
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_out) (void)hipEventDestroy(c->ev_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1784,11 +1871,13 @@ gmrf_status gmrf_comm_allreduce_sum(gmrf_comm* c, gmrf_handle* stream_of, double
     return GMRF_OK;
 }
 
-// R1 of SURVEY 8e: broadcast of the factor blocks [i0, i1) -- Linv_i and the stored windows of the coupling
-// blocks C_{i0-1} .. C_{i1-2}, for every problem of the batch; with_l != 0 also L_i -- from `root` to all
-// ranks, enqueued on the communicator's stream behind whatever the handle's stream holds at the time
-// of the call (root: the factorisation of these blocks; receivers: the sweeps of the previous job
-// that still read the buffers).  The root goes on factoring the next range meanwhile.
+// R1 of SURVEY 8e: broadcast of the factor blocks [i0, i1) of every problem of the batch from `root` to all ranks
+// as ONE packed transport image (pack_blocks_on: lower-triangular tiles of Linv_i, the stored windows of the coupling
+// blocks C_{i0-1} .. C_{i1-2}, the blocks' log-determinant parts): the root packs into the communicator's staging
+// buffer, one ncclBroadcast moves it, the receivers unpack into their factor storage -- all three on the
+// communicator's stream, behind whatever the handle's stream holds at the time of the call (root: the factorisation
+// of these blocks; receivers: the sweeps of the previous job that still read the buffers).  The root goes on
+// factoring the next range meanwhile.  with_l != 0: the raw L_i blocks follow (full squares).
 gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t root, int64_t i0, int64_t i1, int32_t with_l) {
     if (!h || !c) return bad_shape("null pointer");
     if (!h->d_Linv || h->N <= 0) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
@@ -1796,23 +1885,42 @@ gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t roo
     if (with_l && !h->keep_l) return bad_shape("the L blocks are not kept on this handle");
     if (c->device != h->device) return bad_shape("communicator and handle live on different devices");
     HIPCHK(hipSetDevice(h->device));
+    int64_t seg = 0;
+    GCHK(gmrf_bt_packed_size(h, i0, i1, &seg));
+    const size_t need = (size_t)seg * (size_t)h->B * sizeof(double);
+    if (need > c->pack_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));          // earlier transfers still use the old staging buffer
+        free_dev(c->d_pack); c->d_pack = nullptr; c->pack_cap = 0;
+        HIPCHK(hipMalloc(&c->d_pack, need));
+        c->pack_cap = need;
+    }
     HIPCHK(hipEventRecord(c->ev_in, h->stream));
     HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
-    NCCLCHK(g_rccl.GroupStart());
-    int rc = 0;
-    for (int kind = 0; kind < 3 && rc == 0; ++kind) {
-        if (kind == GMRF_BLOCK_L && !with_l) continue;
+    if (c->rank == root) GCHK(pack_blocks_on(h, c->stream, i0, i1, c->d_pack, true));
+    NCCLCHK(g_rccl.Broadcast(c->d_pack, c->d_pack, (size_t)seg * (size_t)h->B, /*ncclFloat64*/ 8, root, c->comm, c->stream));
+    c->bytes_moved += (double)need;
+    if (c->rank != root) GCHK(pack_blocks_on(h, c->stream, i0, i1, c->d_pack, false));
+    if (with_l) {
         int64_t first = 0, cnt = 0, pstride = 0;
-        GCHK(gmrf_bt_block_range(h, kind, i0, i1, &first, &cnt, &pstride));
-        if (cnt == 0) continue;
-        double* base = kind == GMRF_BLOCK_L ? h->d_L : (kind == GMRF_BLOCK_C ? h->d_C : h->d_Linv);
+        GCHK(gmrf_bt_block_range(h, GMRF_BLOCK_L, i0, i1, &first, &cnt, &pstride));
+        NCCLCHK(g_rccl.GroupStart());
+        int rc = 0;
         for (int64_t p = 0; p < h->B && rc == 0; ++p) {
-            double* ptr = base + p * pstride + first;
+            double* ptr = h->d_L + p * pstride + first;
             rc = g_rccl.Broadcast(ptr, ptr, (size_t)cnt, /*ncclFloat64*/ 8, root, c->comm, c->stream);
         }
+        const int rg = g_rccl.GroupEnd();                  // the group is closed on the error path too
+        if (rc != 0 || rg != 0) { g_last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(rc ? rc : rg); return GMRF_ERR_RCCL; }
+        c->bytes_moved += (double)cnt * (double)h->B * sizeof(double);
     }
-    const int rg = g_rccl.GroupEnd();
-    if (rc != 0 || rg != 0) { g_last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(rc ? rc : rg); return GMRF_ERR_RCCL; }
+    return GMRF_OK;
+}
+
+// Bytes this communicator has broadcast so far (factor transport; reset = 1 clears the counter).
+gmrf_status gmrf_comm_bytes(gmrf_comm* c, int32_t reset, double* bytes) {
+    if (!c || !bytes) return bad_shape("null pointer");
+    *bytes = c->bytes_moved;
+    if (reset) c->bytes_moved = 0.0;
     return GMRF_OK;
 }
 
@@ -1979,7 +2087,11 @@ gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out) {
                            h->d_L + h->sel * stride_pL(h), blk_elems(h), h->bsp, (int)h->bs, h->d_logdet + h->sel * h->N,
                            (int64_t)0, (int64_t)0);
         HIPCHK(hipGetLastError());
-    }   // else: the factorisation left every block's part in d_logdet
+    } else if (!h->logdet_valid) {
+        // (a factor adopted as raw buffers: nothing ever filled d_logdet)
+        g_last_error = "the log-determinant parts of this factor are not resident (adopted without the packed transport image and without L)";
+        return GMRF_ERR_NO_FACTOR;
+    }   // else: the factorisation (or the transport image) left every block's part in d_logdet
     std::vector<double> part((size_t)h->N);
     HIPCHK(hipMemcpyAsync(part.data(), h->d_logdet + h->sel * h->N, sizeof(double) * h->N, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

@@ -37,6 +37,31 @@ __global__ void pad_identity(double* __restrict__ dst, int64_t ld, int bs, int b
     if (i < bsp) dst[(int64_t)blockIdx.y * pdst + (int64_t)i * ld + i] = 1.0;
 }
 
+// ------------------------------------------------------------------------------- factor transport
+// Lower-triangular 64 x 64 TILES of the block inverses Linv_i <-> a contiguous buffer (what travels over xGMI
+// when a factor is shared: the tiles above the block diagonal are zero and never read, so a bsp x bsp block
+// of nt x nt tiles moves as nt (nt + 1) / 2 of them: 136 of 256 for bsp = 1024).  Tile (r, c), c <= r, of block i
+// lands at ((i - i0) * ntri + r (r + 1) / 2 + c) * 4096 of the problem's segment, row-major inside the tile.
+// grid (ntri * blocks, problems), 256 threads: a thread moves 16 doubles of its tile as 16-byte pieces.
+template <bool PACK>
+__global__ __launch_bounds__(256) void linv_tiles_copy(double* __restrict__ X, int64_t ld, int64_t blk_stride,
+                                                       int64_t pX, double* __restrict__ buf, int64_t pbuf, int ntri) {
+    const int b = (int)blockIdx.x / ntri, tile = (int)blockIdx.x % ntri;
+    int r = (int)((sqrtf(8.0f * (float)tile + 1.0f) - 1.0f) * 0.5f);
+    while (r * (r + 1) / 2 > tile) --r;
+    while ((r + 1) * (r + 2) / 2 <= tile) ++r;
+    const int c = tile - r * (r + 1) / 2;
+    double* x = X + (int64_t)blockIdx.y * pX + (int64_t)b * blk_stride + (int64_t)r * 64 * ld + (int64_t)c * 64;
+    double* q = buf + (int64_t)blockIdx.y * pbuf + ((int64_t)b * ntri + tile) * 4096;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = (i * 256 + t) * 2, row = e >> 6, col = e & 63;       // a wave covers two 512-byte tile rows
+        if (PACK) *reinterpret_cast<v2d*>(q + e) = *reinterpret_cast<const v2d*>(x + (int64_t)row * ld + col);
+        else *reinterpret_cast<v2d*>(x + (int64_t)row * ld + col) = *reinterpret_cast<const v2d*>(q + e);
+    }
+}
+
 // ------------------------------------------------------------------------------- panels
 // user matrix (column-major n x k, leading dimension ld) <-> padded panel P[rhs][n_pad]
 // blockIdx.y = problem p: columns [p*k, (p+1)*k) of the user matrix <-> panel p (kp * n_pad doubles)

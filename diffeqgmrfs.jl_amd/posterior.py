@@ -9,7 +9,9 @@ Sharding across the GPUs of one node (one process per GPU):
   * the factor is shared: rank 0 factors block ranges and each finished range of Linv / C blocks
     (what the sweeps read; the L blocks stay on rank 0) is broadcast while the next range is being
     factored -- the only collective on the data path; variance accumulators are summed with one
-    all-reduce.
+    all-reduce.  A range travels as ONE packed image (gmrf_bt_pack_blocks_async: the lower-triangular
+    64 x 64 tiles of the block inverses, the stored windows of the coupling blocks, the blocks'
+    log-determinant parts): darcy256 0.56 GB per posterior instead of 0.83 GB of raw buffers.
 
 Two transports move the factor, both RCCL on a GPU box:
   * "cabi"  : the library's own communicator (gmrf_comm_*, include/gmrf_hip.h) -- what a Julia host
@@ -69,23 +71,9 @@ class HipEngine:
         self.values_host = np.ascontiguousarray(values, dtype=np.float64).reshape(batch, -1)
         self.nz = torch.from_numpy(self.values_host).to(self.dev)
         self.rhs = torch.from_numpy(np.ascontiguousarray(rhs, dtype=np.float64).reshape(batch, 1, -1)).to(self.dev)
-        self.buffers = None
+        self._stage = {}
+        self.bytes_moved = 0
         self._pending = []
-
-    # --- storage shared with torch (transport "torch")
-    def _attach_storage(self):
-        import ctypes as C
-        lib = self.pkg._cabi.load()
-        bl, bc, bi = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        self.pkg._cabi.check(lib.gmrf_bt_storage_bytes(self.w.n, self.w.n_blocks, self.batch, C.byref(bl), C.byref(bc),
-                                                       C.byref(bi)))
-        t = self.torch
-        # (C at its dense upper bound: the layout is not known on the receiving ranks yet)
-        self.buffers = [t.zeros(b.value // 8, dtype=t.float64, device=self.dev) if (i > 0 or self.keep_l) else None
-                        for i, b in enumerate((bl, bc, bi))]
-        self.pkg._cabi.check(lib.gmrf_bt_set_storage(self.F._h, self.w.n, self.w.n_blocks, self.batch,
-                                                     *[self.pkg._cabi.ptr(b) for b in self.buffers]))
-        self.F._set_shape(self.w.n, self.w.n_blocks)
 
     def prepare(self, is_root: bool, shared_storage: bool, dist=None):
         """Untimed set-up: symbolic analysis (root), the layout of the stored coupling blocks to every
@@ -93,8 +81,6 @@ class HipEngine:
         if not shared_storage:
             self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)   # analyse + first numeric factor
             return
-        if self.transport == "torch":
-            self._attach_storage()
         if is_root:
             self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)
             layout = self.F.get_layout()
@@ -129,37 +115,60 @@ class HipEngine:
     def adopt_commit(self):
         self.F.adopt_commit(False)
 
-    def _range_tensors(self, i0: int, i1: int):
-        """Views of the storage tensors that hold blocks [i0, i1) of Linv and C for every problem."""
-        out = []
-        for kind, buf in ((self.pkg._cabi.BLOCK_LINV, self.buffers[2]), (self.pkg._cabi.BLOCK_C, self.buffers[1])):
-            first, cnt, pstride = self.F.block_range(kind, i0, i1)
-            if cnt:
-                out.extend(buf[p * pstride + first:p * pstride + first + cnt] for p in range(self.batch))
-        return out
+    def _staging(self, i0: int, i1: int):
+        """(batch, packed_size) device tensor that holds the transport image of blocks [i0, i1) (transport "torch")."""
+        key = (i0, i1)
+        if key not in self._stage:
+            t = self.torch
+            self._stage[key] = t.empty((self.batch, self.F.packed_size(i0, i1)), dtype=t.float64, device=self.dev)
+        return self._stage[key]
 
-    def share_range(self, dist, i0: int, i1: int):
+    def share_range(self, dist, i0: int, i1: int, is_root: bool = True):
         """Enqueue the broadcast of the finished blocks [i0, i1) from rank 0 (every rank calls this)."""
         if self.transport == "cabi":
             self.comm.bcast_blocks_async(self.F, i0, i1, root=0, with_l=False)
-        else:
-            self._pending.extend(dist.broadcast(t, src=0, async_op=True) for t in self._range_tensors(i0, i1))
+            return
+        buf = self._staging(i0, i1)
+        if is_root:
+            self.F.pack_blocks_async(i0, i1, buf)          # on the handle's stream = torch's current stream
+        self._pending.append((dist.broadcast(buf, src=0, async_op=True), i0, i1, buf))
+        self.bytes_moved += buf.numel() * 8
 
-    def share_finish(self):
+    def share_finish(self, is_root: bool = True):
         if self.transport == "cabi":
             self.comm.wait(self.F)
-        else:
-            for hnd in self._pending:
-                hnd.wait()
-            self._pending = []
+            return
+        for hnd, i0, i1, buf in self._pending:
+            hnd.wait()                                     # the current stream waits for the transfer
+            if not is_root:
+                self.F.unpack_blocks_async(i0, i1, buf)
+        self._pending = []
+
+    def transport_bytes(self, reset: bool = False) -> float:
+        """Factor bytes this rank's transport has moved so far."""
+        if self.transport == "cabi":
+            return self.comm.bytes_moved(reset)
+        v = self.bytes_moved
+        if reset:
+            self.bytes_moved = 0
+        return float(v)
 
     def mean(self):
         """(batch, n) posterior means."""
         return self.F.solve_batch(self.rhs)[:, 0, :]
 
-    def sample(self, k: int, mean, seed: int, first_id: int):
-        """(batch, k, n) samples; problem p draws the ids first_id + p*k + s."""
-        return self.F.sample_batch(k, mean=mean, seed=seed, first_id=first_id, like=self.rhs)
+    def sample(self, k: int, mean, seed: int, first_id: int, keep: bool = True):
+        """(batch, k, n) samples; problem p draws the ids first_id + p*k + s.  A batched handle draws at most 128 per
+        call: larger k goes in chunks of 128 (chunk c of problem p: ids first_id + c*128*batch + p*kc + s); with
+        `keep` False only the last chunk is returned (throughput runs that do not hold k x n x batch doubles)."""
+        if self.batch == 1 or k <= 128:
+            return self.F.sample_batch(k, mean=mean, seed=seed, first_id=first_id, like=self.rhs)
+        outs = []
+        for c0 in range(0, k, 128):
+            kc = min(128, k - c0)
+            x = self.F.sample_batch(kc, mean=mean, seed=seed, first_id=first_id + c0 * self.batch, like=self.rhs)
+            outs = outs + [x] if keep else [x]
+        return self.torch.cat(outs, dim=1) if keep else outs[0]
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.dev)
@@ -169,29 +178,45 @@ class ShardedPosterior:
     """One posterior job across `world` ranks (see module docstring)."""
 
     def __init__(self, engine, dist=None, rank: int = 0, world: int = 1, k_samples: int = 64,
-                 seed: int = 0x5EED, group: int = 8, replicate_factor: bool = False, force_shared: bool = False):
+                 seed: int = 0x5EED, group: int = 8, replicate_factor: bool = False, force_shared: bool = False,
+                 keep_samples: bool = True, timing: bool = False):
         """`force_shared`: run the shared-factor protocol (ranged factorisation, broadcasts, commit) even
-        with a world of one rank -- rehearsals of the multi-GPU path on a one-GPU box."""
+        with a world of one rank -- rehearsals of the multi-GPU path on a one-GPU box.  `timing`: device events
+        around the phases of a step (`phase_ms()` after a synchronisation); HipEngine only."""
         self.e, self.dist, self.rank, self.world = engine, dist, rank, world
         self.k, self.seed, self.group = k_samples, seed, group
         self.replicate = replicate_factor or (world == 1 and not force_shared)
         self.groups = block_groups(engine.w.n_blocks, group)
+        self.keep_samples = keep_samples
+        self.timing = timing and hasattr(engine, "torch")
+        self._ev = None
 
     def prepare(self):
         self.e.prepare(is_root=(self.rank == 0), shared_storage=not self.replicate, dist=self.dist)
         if self.dist is not None and self.world > 1:
             self.dist.barrier()
 
+    def _mark(self, i: int):
+        if self.timing:
+            self._ev[i].record(self.e.torch.cuda.current_stream(self.e.dev))
+
     def _factor_and_share(self):
+        if self.timing and self._ev is None:
+            self._ev = [self.e.torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        self._mark(0)
         if self.replicate:
             self.e.factor()
+            self._mark(1); self._mark(2)
             return
+        root = self.rank == 0
         for gi, (i0, i1) in enumerate(self.groups):
-            if self.rank == 0:
+            if root:
                 self.e.factor_range_async(i0, i1, first=(gi == 0))
-            self.e.share_range(self.dist, i0, i1)
-        self.e.share_finish()
-        if self.rank == 0:
+            self.e.share_range(self.dist, i0, i1, root)
+        self._mark(1)                      # root: the last range has been enqueued behind the factorisation
+        self.e.share_finish(root)
+        self._mark(2)                      # the stream has waited for the last transfer (receivers: and unpacked)
+        if root:
             self.e.factor_end()
         else:
             self.e.adopt_commit()
@@ -202,8 +227,18 @@ class ShardedPosterior:
         mu = self.e.mean()
         nb = getattr(self.e, "batch", 1)
         first = (step_index * self.world + self.rank) * self.k * nb
-        X = self.e.sample(self.k, mu, self.seed, first)
+        X = self.e.sample(self.k, mu, self.seed, first) if self.keep_samples else self.e.sample(self.k, mu, self.seed, first, keep=False)
+        self._mark(3)
         return mu, X
+
+    def phase_ms(self):
+        """Device times of the last step on this rank (after a synchronisation): factorisation (root; receivers: 0),
+        what the stream then still waited for the transfers, mean + samples."""
+        if not self.timing or self._ev is None:
+            return None
+        e = self._ev
+        return {"factor_ms": e[0].elapsed_time(e[1]), "transfer_wait_ms": e[1].elapsed_time(e[2]),
+                "mean_and_samples_ms": e[2].elapsed_time(e[3])}
 
     def solves_per_step(self) -> int:
         """Posterior solves of one step over all ranks.  Shared factor (broadcast): per problem one

@@ -203,6 +203,20 @@ gmrf_status gmrf_bt_block_range(gmrf_handle* h, int32_t kind, int64_t i0, int64_
 gmrf_status gmrf_bt_set_keep_l(gmrf_handle* h, int32_t keep);
 gmrf_status gmrf_bt_get_layout(gmrf_handle* h, int64_t* out, int64_t cap, int64_t* count);
 
+/* Packed transport image of the blocks [i0, i1) -- the unit that moves when a factor is shared (over xGMI by
+ * gmrf_bt_bcast_blocks_async, or by a transport of the caller's own).  Per problem one segment of
+ * gmrf_bt_packed_size doubles: the lower-triangular 64 x 64 tiles of Linv_i0 .. Linv_{i1-1} (tile (r, c), c <= r, of
+ * block i at ((i - i0) * nt (nt + 1) / 2 + r (r + 1) / 2 + c) * 4096, row-major; nt = bsp / 64 -- the tiles above the
+ * block diagonal are zero and never read, so they do not travel: 136 of 256 tiles at bsp = 1024), the stored windows
+ * of the coupling blocks C_{i0-1} .. C_{i1-2}, and the blocks' log-determinant parts ((i1 - i0) doubles, rounded up to
+ * an even count).  darcy256: 0.56 GB per posterior instead of the 0.83 GB of the raw Linv / C buffers.  dev_buf:
+ * device memory, [batch][segment].  pack reads the handle's factor storage, unpack fills it (a receiving rank:
+ * gmrf_bt_adopt_layout first, gmrf_bt_adopt_commit after the last range; gmrf_bt_logdet then works there too).
+ * Both are enqueued on the handle's stream and return.  (No reference counterpart: the reference is one process.) */
+gmrf_status gmrf_bt_packed_size(gmrf_handle* h, int64_t i0, int64_t i1, int64_t* elems_per_problem);
+gmrf_status gmrf_bt_pack_blocks_async(gmrf_handle* h, int64_t i0, int64_t i1, double* dev_buf);
+gmrf_status gmrf_bt_unpack_blocks_async(gmrf_handle* h, int64_t i0, int64_t i1, const double* dev_buf);
+
 /* Caller-owned factor storage (e.g. torch tensors that RCCL broadcasts): upper bounds of the sizes
  * for a shape and batch (C at its dense size), then the three device buffers (dev_L may be NULL after
  * gmrf_bt_set_keep_l(h, 0)).  `batch` must equal the handle's batch.  Must be set before the first
@@ -231,7 +245,8 @@ gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid);
  *   ranks>0: gmrf_bt_adopt_layout(h, n, N, layout)   (layout: gmrf_bt_get_layout on rank 0, moved with
  *            gmrf_comm_bcast_host)
  *   per job, for each block range:  rank 0: gmrf_bt_factor_step_async(h, i0, i1);
- *                                   all:    gmrf_bt_bcast_blocks_async(h, c, 0, i0, i1, 0)
+ *                                   all:    gmrf_bt_bcast_blocks_async(h, c, 0, i0, i1, 0)   (one packed image per
+ *                                           range: gmrf_bt_pack_blocks_async -> ncclBroadcast -> _unpack_)
  *            then  all: gmrf_comm_wait(h, c);  rank 0: gmrf_bt_factor_end;  ranks>0: gmrf_bt_adopt_commit(h, 0)
  * librccl is opened with dlopen on first use (GMRF_RCCL_PATH overrides the search). */
 gmrf_status gmrf_comm_unique_id(void* id128);
@@ -244,6 +259,8 @@ gmrf_status gmrf_comm_allreduce_sum(gmrf_comm* c, gmrf_handle* stream_of, double
 gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t root, int64_t i0,
                                        int64_t i1, int32_t with_l);
 gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c);
+/* Factor bytes this communicator has broadcast so far (reset != 0 clears the counter afterwards). */
+gmrf_status gmrf_comm_bytes(gmrf_comm* c, int32_t reset, double* bytes);
 
 /* Streams for several handles driven side by side (one host thread and one stream per handle: the latency-bound
  * launches of one factorisation leave CUs to the others -- bench.py runs 4 handles x 32 problems).  The HIP runtime

@@ -14,7 +14,8 @@
 # problem; the library validates that the posterior precision is block tridiagonal in that partition
 # (GMRF_ERR_BAND otherwise).  The sparsity pattern is analysed once per solver chain: a solver built
 # from a previous one (`reuse = s`) re-factors VALUES ONLY (gmrf_bt_refactor_values), which is what the
-# per-problem loop (:176-198) and the Gauss-Newton loop (scripts/solve_burger.jl:143-149) need.
+# per-problem loop (:176-198) and the Gauss-Newton loop (scripts/solve_burger.jl:143-149) need; the reused solver is
+# CONSUMED (its handle moves to the new solver; using it afterwards raises).
 #
 # STATUS.  GaussianMarkovRandomFields.jl is not vendored in the reference (Project.toml:19, installed
 # from a GitHub URL, unpinned) and there is no Julia in the build image: the solver interface below
@@ -24,7 +25,7 @@
 # no `ccall`: everything goes through julia/DiffEqGMRFsHIP.jl, whose calls are checked statically
 # against include/gmrf_hip.h (tests/test_host_logic.py).  The executed twin of this file is
 # `api.ConditionedGMRF` / `api.gn_step` (diffeqgmrfs.jl_amd/api.py, tests/test_gpu_parity.py).
-module BlockTridiagonalSolver
+module BlockTridiagonalSolvers      # (plural: the solver type below is exported as `BlockTridiagonalSolver`)
 
 using SparseArrays, LinearAlgebra, Random
 import ..DiffEqGMRFsHIP as HIP
@@ -61,14 +62,20 @@ mutable struct BlockTridiagonalSolverState <: AbstractSolver
     csr::Union{Nothing,HIP.GmrfCsr}                    # device copy of the precision for RBMC (K6), built on demand
     computed_var::Union{Nothing,Vector{Float64}}
     n_draws::Int                                       # sample ids handed out so far (Philox stream position)
+    consumed::Bool                                     # a later solver re-factored this one's handle (`reuse = s`): s is spent
 end
 const BlockTridiagonalSolver = BlockTridiagonalSolverState
+_live(s::BlockTridiagonalSolverState) =
+    s.consumed ? error("this solver was passed as `reuse` to a later one: its factor handle now holds the later problem's values") : s
 
 _sparse(Q) = Q isa SparseMatrixCSC{Float64,Int} ? Q : SparseMatrixCSC{Float64,Int}(to_matrix(Q))
 
 function _factor(bp::BlockTridiagonalSolverBlueprint, Q::SparseMatrixCSC{Float64,Int}, reuse)
     if reuse !== nothing && size(reuse.precision) == size(Q) && reuse.precision.colptr == Q.colptr && reuse.precision.rowval == Q.rowval
-        return HIP.refactor!(reuse.precision_chol, Q)            # same pattern: values only, captured HIP graphs re-used
+        # same pattern: values only, captured HIP graphs re-used.  The handle MOVES to the new solver: `reuse` is
+        # consumed (its mean / variances / draws would silently come from the new factor otherwise)
+        _live(reuse).consumed = true
+        return HIP.refactor!(reuse.precision_chol, Q)
     end
     F = HIP.TridiagonalCholeskyFactor{Float64}(bp.device)
     bp.keep_l || HIP.set_keep_l!(F, false)
@@ -78,7 +85,7 @@ end
 "Solver of an unconditional GMRF N(mean, precision^-1)."
 function construct_solver(bp::BlockTridiagonalSolverBlueprint, mean::AbstractVector, precision; reuse = nothing)
     Q = _sparse(precision)
-    return BlockTridiagonalSolverState(bp, Vector{Float64}(mean), Q, _factor(bp, Q, reuse), nothing, nothing, 0)
+    return BlockTridiagonalSolverState(bp, Vector{Float64}(mean), Q, _factor(bp, Q, reuse), nothing, nothing, 0, false)
 end
 
 """
@@ -94,14 +101,15 @@ function construct_conditional_solver(bp::BlockTridiagonalSolverBlueprint, prior
     b === nothing || (r .-= b)
     rhs = Vector{Float64}(A' * (Q_eps isa Number ? Q_eps .* r : Q_eps * r))
     mean = prior_mean .+ HIP.ldiv(F, rhs)
-    return BlockTridiagonalSolverState(bp, Vector{Float64}(mean), Q, F, nothing, nothing, 0)
+    return BlockTridiagonalSolverState(bp, Vector{Float64}(mean), Q, F, nothing, nothing, 0, false)
 end
 
 gmrf_precision(s::BlockTridiagonalSolverState) = s.precision
-compute_mean(s::BlockTridiagonalSolverState) = s.mean
+compute_mean(s::BlockTridiagonalSolverState) = _live(s).mean
 
 "`rand(rng, x)`: mean + L^-T z.  z comes from the device Philox stream (seed of the blueprint, sample id = draw count) so that the draw does not depend on the number of GPUs; `rng` is accepted for interface compatibility."
 function compute_rand!(s::BlockTridiagonalSolverState, rng::Random.AbstractRNG, x::AbstractVector)
+    _live(s)
     x .= vec(HIP.sample(s.precision_chol, 1; mean = s.mean, seed = s.bp.seed, first_id = s.n_draws))
     s.n_draws += 1
     return x
@@ -109,6 +117,7 @@ end
 
 "`var(x)` / `std(x)` (scripts/darcy/solve_darcy_gmrf-fem.jl:192)."
 function compute_variance(s::BlockTridiagonalSolverState)
+    _live(s)
     s.computed_var === nothing || return s.computed_var
     if s.bp.var_strategy === :exact
         s.computed_var = HIP.marginal_var(s.precision_chol)
@@ -121,7 +130,7 @@ function compute_variance(s::BlockTridiagonalSolverState)
 end
 
 "log det of the precision: 2 sum log diag(L_i) (scripts/burgers/solve_burgers_gmrf-collocation.jl:208-211)."
-LinearAlgebra.logdet(s::BlockTridiagonalSolverState) = logdet(s.precision_chol)
+LinearAlgebra.logdet(s::BlockTridiagonalSolverState) = logdet(_live(s).precision_chol)
 
 """
     gn_step!(s, Q, Qx_prior, J, x, obs_diff, noise)  ->  new iterate

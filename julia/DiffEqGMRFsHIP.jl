@@ -512,6 +512,24 @@ bcast_blocks_async!(F::TridiagonalCholeskyFactor, c::GmrfComm, i0::Integer, i1::
     check(ccall((:gmrf_bt_bcast_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, Int32), F.handle, c.handle, root, i0, i1, with_l ? 1 : 0))
 comm_wait!(F::TridiagonalCholeskyFactor, c::GmrfComm) =
     check(ccall((:gmrf_comm_wait, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), F.handle, c.handle))
+"Factor bytes this communicator has broadcast so far."
+function comm_bytes(c::GmrfComm; reset::Bool = false)
+    b = Ref{Float64}(0.0)
+    check(ccall((:gmrf_comm_bytes, libgmrf), Int32, (Ptr{Cvoid}, Int32, Ref{Float64}), c.handle, reset ? 1 : 0, b))
+    return b[]
+end
+
+# Packed transport image of a block range (what gmrf_bt_bcast_blocks_async moves; for a transport of the caller's own,
+# e.g. MPI.jl on device pointers): doubles per problem, pack from / unpack into the handle's factor storage.
+function packed_size(F::TridiagonalCholeskyFactor, i0::Integer, i1::Integer)
+    v = Ref{Int64}(0)
+    check(ccall((:gmrf_bt_packed_size, libgmrf), Int32, (Ptr{Cvoid}, Int64, Int64, Ref{Int64}), F.handle, i0, i1, v))
+    return v[]
+end
+pack_blocks_async!(F::TridiagonalCholeskyFactor, i0::Integer, i1::Integer, dev_buf::Ptr{Float64}) =
+    check(ccall((:gmrf_bt_pack_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), F.handle, i0, i1, dev_buf))
+unpack_blocks_async!(F::TridiagonalCholeskyFactor, i0::Integer, i1::Integer, dev_buf::Ptr{Float64}) =
+    check(ccall((:gmrf_bt_unpack_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}), F.handle, i0, i1, dev_buf))
 
 """
     create_streams(n; device = 0) -> (streams::Vector{Ptr{Cvoid}}, n_distinct)

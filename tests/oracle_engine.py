@@ -48,14 +48,14 @@ class OracleEngine:
         self.F = O.TridiagonalCholeskyFactor(self.w.n, [np.linalg.inv(self.Li[i].numpy()) for i in range(N)],
                                              [self.C[i].numpy() for i in range(N - 1)])
 
-    def share_range(self, dist, i0, i1):
+    def share_range(self, dist, i0, i1, is_root=True):
         ts = [self.Li[i0:i1]]
         c0, c1 = max(i0 - 1, 0), max(i1 - 1, 0)
         if c1 > c0:
             ts.append(self.C[c0:c1])
         self._pending.extend(dist.broadcast(t, src=0, async_op=True) for t in ts)
 
-    def share_finish(self):
+    def share_finish(self, is_root=True):
         for hnd in self._pending:
             hnd.wait()
         self._pending = []
@@ -65,7 +65,7 @@ class OracleEngine:
     def mean(self):
         return O.ldiv(self.F, self.w.rhs)
 
-    def sample(self, k, mean, seed, first_id):
+    def sample(self, k, mean, seed, first_id, keep=True):
         Z = philox_normals_np(seed, self.w.n, first_id, k)
         return O.sample(self.F, mean, Z)
 

@@ -47,6 +47,9 @@ try:
         c["allreduce_equal"] = bool(np.array_equal(r0["acc"], r1["acc"]))
         c["layout_travelled"] = bool(np.array_equal(r0["layout"], r1["layout"]) and r0["layout"].size > 3)
         c["solves_per_step"] = int(r0["solves"]) == 2 * (1 + 6 * 2)
+        # the packed transport image (lower-triangular tiles of Linv + C windows + log-determinant parts) is what moved
+        c["logdet_travelled"] = bool(np.array_equal(r0["logdet"], r1["logdet"]) and np.all(np.isfinite(r1["logdet"])))
+        c["packed_bytes_below_raw"] = bool(0 < float(r0["bytes"][0]) < 2 * 2 * 8.0 * (16 * 256 * 256 + 15 * 256 * 256))
         # RCCL through the C ABI, world of one: same job, rank 0 of a world of one at step 1 draws ids (1*1+0)*6*2 = 12.. = step 0 / rank 1 above
         c["cabi_mean"] = bool(np.array_equal(s["mu_cabi"], s["mu"]))
         c["cabi_samples"] = bool(np.array_equal(s["X_cabi"], s["X0_1"]))

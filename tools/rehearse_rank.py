@@ -37,6 +37,12 @@ acc = ((X - mu[:, None, :]) ** 2).sum(dim=1)          # variance accumulators: o
 dist.all_reduce(acc)
 out["acc"] = acc.cpu().numpy()
 out["solves"] = job.solves_per_step()
+lds = []
+for p in range(batch):                      # rank 1 adopted the factor without its L blocks: the log-determinant parts
+    eng.F.select_problem(p)                 # travelled inside the packed transport image
+    lds.append(eng.F.logdet())
+out["logdet"] = np.array(lds)
+out["bytes"] = np.array([eng.transport_bytes()])
 out["layout"] = eng.F.get_layout()
 np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
 dist.barrier()
