@@ -45,6 +45,9 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
     0: ("gemm_f64_mfma<false,false>", "mfma"),   # 64 x 64 tile GEMM, B stored [n][k]
     11: ("gemm_f64_mfma<false,true>", "mfma"),   # 64 x 64 tile GEMM, B stored [k][n]
     13: ("gemm_f64_ll", "mfma"),                 # 32 x 32 tile GEMM of launches with <= 128 tiles of 64 x 64
+    14: ("gemm_f64_dma<B[n][k]>", "mfma"),       # LDS-DMA staged GEMM (gemm_f64_dma.hpp), B stored [n][k]
+    15: ("gemm_f64_dma<B[k][n]>", "mfma"),       # LDS-DMA staged GEMM, B stored [k][n]
+    12: ("gemm_f64_mfma<true,*>", "mfma"),       # A stored [k][m] (selected inversion only)
     6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
     7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
     1: ("potrf_step<false>", "mfma"),       # tile Cholesky + inverse (latency-bound, B workgroups)
@@ -569,7 +572,7 @@ def main():
                                f"{prof.get('head', '?')}, this run is {git_head()})")
         except Exception:
             pass
-        gemm_cls = [c for c in (0, 11) if ms[c] > 0]
+        gemm_cls = [c for c in (0, 11, 12, 13, 14, 15, 6, 7) if ms[c] > 0]
         tw = sum(work[c] for c in gemm_cls) / max(sum(ms[c] for c in gemm_cls), 1e-9) / 1e9 if gemm_cls else 0.0
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                            "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel": name,
@@ -577,8 +580,9 @@ def main():
                            "work": "executed flops (structurally skipped K ranges not counted)",
                            "timing": "one instrumented step of one handle; GEMM launches carry the dispatch's own begin / end time "
                                      "stamps (hipExtLaunchKernelGGL start / stop events) = the duration a rocprofv3 kernel trace reports",
-                           "gemm_f64_mfma_both_symbols_time_weighted": {"achieved": tw, "frac": tw / PEAK_FP64_MFMA_TFLOPS,
-                                                                        "ms_per_step": sum(ms[c] for c in gemm_cls)}}
+                           "all_gemm_symbols_time_weighted": {"achieved": tw, "frac": tw / PEAK_FP64_MFMA_TFLOPS,
+                                                              "ms_per_step": sum(ms[c] for c in gemm_cls),
+                                                              "symbols": [KERNEL_CLASSES[c][0] for c in gemm_cls]}}
         # the HBM-bound leg of the path (north_star: sweep HBM GB/s against the 8 TB/s roofline): the k = 1 GEMV
         # sweep kernels of the same instrumented step, on the bytes they stream (Linv triangles + C inside its staircase)
         out["kernels"] = {KERNEL_CLASSES[c][0]: {"ms_per_step": ms[c], "launches": int(cnt[c]),

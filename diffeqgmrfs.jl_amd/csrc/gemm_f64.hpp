@@ -747,6 +747,11 @@ inline bool gemm_uses_ll(const GemmArgs& g, int batch) {
     return tiles <= ll_max;
 }
 
+// The LDS-DMA kernels (gemm_f64_dma.hpp) take the launches that qualify; defined there.
+inline bool gemm_try_dma(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, int batch, hipEvent_t ev_start, hipEvent_t ev_stop,
+                         hipError_t* err);
+inline bool gemm_uses_dma(bool a_t, const GemmArgs& g, int batch);
+
 // Host-side launcher.  tri/lower_only semantics as in GemmArgs.
 // ev_start / ev_stop (optional, profiling): updated by the runtime with the dispatch's own begin / end time stamps
 // (hipExtLaunchKernelGGL) -- the kernel's duration as a rocprofv3 kernel trace reports it, without the gap an
@@ -770,6 +775,10 @@ inline hipError_t launch_gemm(hipStream_t st, bool a_t, bool b_n, const GemmArgs
         if (b_n) GMRF_KLAUNCH(gemm_f64_big<true>, bgrid, block, gemm_big_lds_bytes<true>(), st, g);
         else GMRF_KLAUNCH(gemm_f64_big<false>, bgrid, block, gemm_big_lds_bytes<false>(), st, g);
         return hipGetLastError();
+    }
+    if (!gemm_uses_ll(g, batch)) {
+        hipError_t derr = hipSuccess;
+        if (gemm_try_dma(st, a_t, b_n, g, batch, ev_start, ev_stop, &derr)) return derr;
     }
     static const bool force_bk16 = getenv("GMRF_GEMM_BK16") != nullptr;     // tuning aid
     // One LDS stage instead of two (two barriers per K step, half the LDS): four workgroups per CU instead of

@@ -26,6 +26,7 @@
 #include "assemble.hpp"
 #include "fem_assemble.hpp"
 #include "gemm_f64.hpp"
+#include "gemm_f64_dma.hpp"
 #include "microbench.hpp"
 #include "misc_kernels.hpp"
 #include "potrf_step.hpp"
@@ -262,7 +263,11 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     // statistics: launches of the 128 x 128 kernel are their own classes (6: B stored [n][k],
     // 7: B stored [k][n]) whoever calls, so that a class is one kernel symbol of a rocprof trace
     if (gemm_uses_big(a_t, g, batch * (int)h->B)) { pclass = b_n ? 7 : 6; pwork = -1.0; }
-    else if (pclass == 0) pclass = gemm_uses_ll(g, batch * (int)h->B) ? 13 : (a_t ? 12 : (b_n ? 11 : 0));
+    else if (pclass == 0) {
+        if (gemm_uses_ll(g, batch * (int)h->B)) pclass = 13;
+        else if (gemm_uses_dma(a_t, g, batch * (int)h->B)) pclass = b_n ? 15 : 14;     // gemm_f64_dma<.., B [n][k]> / <.., B [k][n]>
+        else pclass = a_t ? 12 : (b_n ? 11 : 0);
+    }
     if (h->profiling > 0) {
         // GEMM classes: the dispatch's own begin / end time stamps (see launch_gemm), not an event pair around the launch
         EvPair p;
@@ -1217,6 +1222,7 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(gemm_init());
+    HIPCHK(gemm_dma_init());
     *out = h;
     return GMRF_OK;
 }
@@ -3030,20 +3036,26 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     g.D = nullptr; g.ldd = 0; g.pD = 0;
     // tri_flags bit 2048: take the 128 x 128 kernel whatever the tile count
     // bit 4096: the 32 x 32 low-latency kernel (taken by launches of <= 128 tiles of 64 x 64)
+    // bits 8192 / 16384 / 32768: the LDS-DMA kernel with 64 x 64 / 128 x 64 / 64 x 128 tiles (gemm_f64_dma.hpp); none of
+    // them: the register-staged kernels only
     const bool force_big = (tri_flags & 2048) != 0, use_ll = (tri_flags & 4096) != 0;
-    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~(2048 | 4096); g.lower_only = lower_only;
+    const int dma_shape = (tri_flags & 8192) ? 1 : ((tri_flags & 16384) ? 2 : ((tri_flags & 32768) ? 3 : 0));
+    g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags & ~(2048 | 4096 | 8192 | 16384 | 32768); g.lower_only = lower_only;
     g.alpha = alpha; g.beta = beta;
     unsigned long long* dst = nullptr;
     HIPCHK(hipMalloc(&dst, 16));
     HIPCHK(hipMemset(dst, 0, 16));
-    g.stamps = (force_big || use_ll) ? nullptr : dst;
+    g.stamps = (force_big || use_ll || dma_shape) ? nullptr : dst;
     HIPCHK(gemm_init());
-    const int saved = gemm_big_policy(), saved_ll = gemm_ll_policy();
+    HIPCHK(gemm_dma_init());
+    const int saved = gemm_big_policy(), saved_ll = gemm_ll_policy(), saved_dma = gemm_dma_policy(), saved_force = gemm_dma_force();
     gemm_big_policy() = force_big ? 1 : 2;
     gemm_ll_policy() = use_ll ? 0 : 2;
+    gemm_dma_policy() = dma_shape ? 2 : 0;
+    gemm_dma_force() = dma_shape;
     // BLAS-style flags: op(A) is M x K, op(B) is K x N; B "not transposed" is stored K x N
     hipError_t le = launch_gemm(nullptr, transA != 0, transB == 0, g, 1);
-    gemm_big_policy() = saved; gemm_ll_policy() = saved_ll;
+    gemm_big_policy() = saved; gemm_ll_policy() = saved_ll; gemm_dma_policy() = saved_dma; gemm_dma_force() = saved_force;
     HIPCHK(le);
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(C, dC, sizeof(double) * M * ldc, hipMemcpyDeviceToHost));
@@ -3077,8 +3089,13 @@ gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K,
     g.M = (int)M; g.N = (int)N; g.K = (int)K; g.tri = tri_flags; g.lower_only = lower_only;
     g.alpha = 1.0; g.beta = 0.0; g.stamps = nullptr;
     HIPCHK(gemm_init());
-    const int saved = gemm_big_policy();
-    gemm_big_policy() = big == 1 ? 1 : (big == 0 ? 2 : 0);       // big = 2: the model's choice
+    HIPCHK(gemm_dma_init());
+    const int saved = gemm_big_policy(), saved_dma = gemm_dma_policy(), saved_force = gemm_dma_force();
+    gemm_big_policy() = big == 1 ? 1 : (big == 2 ? 0 : 2);       // big = 2: the model's choice
+    // big = 3 / 4 / 5: the LDS-DMA kernel with 64 x 64 / 128 x 64 / 64 x 128 tiles; 6: the production choice (all policies at their defaults)
+    gemm_dma_policy() = big >= 3 ? 2 : 0;
+    gemm_dma_force() = (big >= 3 && big <= 5) ? big - 2 : 0;
+    if (big == 6) gemm_big_policy() = 0;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     hipError_t le = hipSuccess;
@@ -3086,7 +3103,7 @@ gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K,
     HIPCHK(hipEventRecord(e0, nullptr));
     for (int r = 0; r < reps && le == hipSuccess; ++r) le = launch_gemm(nullptr, false, transB == 0, g, batch);
     HIPCHK(hipEventRecord(e1, nullptr));
-    gemm_big_policy() = saved;
+    gemm_big_policy() = saved; gemm_dma_policy() = saved_dma; gemm_dma_force() = saved_force;
     HIPCHK(le);
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0.f;
