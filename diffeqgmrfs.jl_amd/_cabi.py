@@ -52,7 +52,7 @@ class Stats(C.Structure):
         ("factor_flops", C.c_double), ("sweep_bytes", C.c_double), ("sweep_ms", C.c_double),
         ("n", C.c_int64), ("n_blocks", C.c_int64), ("block_size", C.c_int64),
         ("block_size_padded", C.c_int64), ("factor_bytes", C.c_int64),
-        ("kernel_ms", C.c_double * 16), ("kernel_work", C.c_double * 16), ("kernel_launches", C.c_int64 * 16),
+        ("kernel_ms", C.c_double * 24), ("kernel_work", C.c_double * 24), ("kernel_launches", C.c_int64 * 24),
         ("sweep_bytes_streamed", C.c_double),
     ]
 

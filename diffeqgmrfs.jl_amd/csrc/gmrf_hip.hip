@@ -176,6 +176,7 @@ struct gmrf_handle {
     bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
     bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
+    bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -729,6 +730,47 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         HIPCHK(hipGetLastError());
         return GMRF_OK;
     }
+    // Batches (round 3): 128-column diagonal blocks in one kernel each, everything below them on the GEMM kernel
+    // (potrf_diag128, see potrf_step.hpp).
+    if (!fused && !fused_in_panel && !h->left_looking && !h->rank64_panels && !overlap && nt >= 4 && nt % 4 == 0) {
+        StepArgs sa;
+        sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.nt = nt; sa.cend = nt;
+        sa.info = h->d_info; sa.blk = blk_id; sa.dbg = nullptr;
+        sa.pS = (int64_t)bsp * bsp; sa.pL = stride_pL(h); sa.pX = stride_pX(h); sa.blk_per_problem = (int)h->N;
+        const double t3 = 64.0 * 64.0 * 64.0, nb = (double)h->B;
+        for (int j = 0; j < nt; j += 2) {
+            sa.j = j;
+            {
+                // two tile Choleskys + four triangular 64^3 products (L10, S11 update, L10 X00, X11 W)
+                ProfScope ps(h, 16, (2.0 * t3 / 3.0 + 4.0 * 2.0 * t3 * 0.625) * nb);
+                hipLaunchKernelGGL(potrf_diag128, dim3(1, (unsigned)h->B), dim3(256), POTRF_DIAG128_LDS, h->stream, sa);
+                HIPCHK(hipGetLastError());
+            }
+            const int m2 = nt - j - 2;                         // row tiles below the diagonal block
+            if (m2 <= 0) continue;
+            const int64_t oj = (int64_t)j * 64, ob = oj + 128;
+            const double* Sb = S + ob * ld + oj;               // rows below, the block's 128 columns
+            const double* XA = X + oj * ld + oj;               // X_A = inverse of the diagonal block (lower triangular)
+            double* Lb = L + ob * ld + oj;
+            // L21 = S21 X_A^T: b(k, n) = X_A[n][k] (stored [n][k]), zero for k > n
+            GCHK(gemm(h, false, false, 64 * m2, 128, 128, TRI_B_UPPER, 0, 1.0, Sb, ld, XA, ld, 0.0, Lb, ld, sa.pS, sa.pX, sa.pL,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * m2 * nb));
+            if ((j / 2) % 2 == 0) {
+                // first half of a 256-column panel: its second half S[j+2.., j+2..j+3] -= L21 L21[0:128]^T (tile (0, 1) lies
+                // above the diagonal and is skipped)
+                GCHK(gemm(h, false, false, 64 * m2, 128, 128, 0, 1, -1.0, Lb, ld, Lb, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL, sa.pS,
+                          1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * (2.0 * m2 - 1.0) * nb));
+            } else {
+                // panel complete: S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the 256-column panel P
+                const double* Lp = L + ob * ld + (oj - 128);
+                GCHK(gemm(h, false, false, m2 * 64, m2 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL,
+                          sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m2 * (m2 + 1) / 2) * nb));
+            }
+        }
+        // X = L^-1 by recursive doubling over the 128-wide diagonal inverses
+        GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
+        return GMRF_OK;
+    }
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
@@ -1221,6 +1263,7 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_DIAG128_LDS));
     HIPCHK(gemm_init());
     HIPCHK(gemm_dma_init());
     *out = h;
@@ -1290,6 +1333,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 128) != 0) != h->doubling_x) { destroy_graphs(h); h->doubling_x = (eager & 128) != 0; }
     if (((eager & 256) != 0) != h->no_lookahead) { destroy_graphs(h); h->no_lookahead = (eager & 256) != 0; }
     if (((eager & 512) != 0) != h->update_via_gemm) { destroy_graphs(h); h->update_via_gemm = (eager & 512) != 0; }
+    if (((eager & 1024) != 0) != h->rank64_panels) { destroy_graphs(h); h->rank64_panels = (eager & 1024) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }

@@ -847,6 +847,139 @@ __global__ __launch_bounds__(256, 2) void potrf_panel_ll(PanelLLArgs pa) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Batches, round 3: the in-block Cholesky advances in 128-column DIAGONAL BLOCKS; everything below a diagonal block
+// is level-3 work on the GEMM kernel (K = 128 / 256) instead of rank-64 steps fed from HBM:
+//
+//   potrf_diag128(j)  one workgroup per problem: the 128 x 128 diagonal block at tile j (j even), in LDS --
+//                       L00 = chol(S00), X00 = L00^-1          (tile_potrf_inv)
+//                       L10 = S10 X00^T                          S11 -= L10 L10^T   (product from zero, one subtraction)
+//                       L11 = chol(S11), X11 = L11^-1
+//                       X10 = -X11 (L10 X00)                     (the 128 x 128 inverse X_A = [X00 0; X10 X11])
+//   GEMM              L[j+2.., j..j+1] = S[j+2.., j..j+1] X_A^T                          (K = 128, X_A lower triangular)
+//   GEMM              first half of a 256-column panel: its second half S[j+2.., j+2..j+3] -= L[j+2.., j..j+1] L[j+2..j+3, j..j+1]^T
+//                     second half: the rank-256 update of everything right of the panel (as before)
+//
+// 22 launches per 1024-block instead of 51 (16 x (tile, potrf_panel, potrf_update) + 3), 8 dependent tile kernels per
+// block instead of 16, and the level-64 doubling products of the block inverse come out of this kernel.  potrf_panel /
+// potrf_update moved 3.1 TB/s of S through HBM at 6 - 13 TF/s for 25 ms of every batch-32 factorisation.
+// The rows below a diagonal block now meet the 128 x 128 inverse (a product of two computed tile inverses, like every
+// level of the block inverse Linv_i itself) instead of two 64 x 64 ones: the factor's error carries cond(128-block) eps
+// where it carried cond(64-tile) eps (BASELINE workloads: cond(L_i) <= 840 for the whole 1024-block).
+// LDS: three tiles + scratch = 111 KB (a GEMM workgroup of another stream still fits beside it).
+__global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
+    sa.S += (int64_t)blockIdx.y * sa.pS;
+    sa.L += (int64_t)blockIdx.y * sa.pL;
+    sa.X += (int64_t)blockIdx.y * sa.pX;
+    sa.blk += (int)blockIdx.y * sa.blk_per_problem;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ts = smem;
+    double* Xs = Ts + TILE_ELEMS;
+    double* As = Xs + TILE_ELEMS;
+    double* Wk = As + TILE_ELEMS;               // 4 * 16 * 18
+    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld;
+    const int64_t o0 = (int64_t)sa.j * 64, o1 = o0 + 64;
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    // S11 (this wave's 16-row strip, MFMA C/D layout; lower blocks only): requested now, used after the first tile
+    v4d cpre[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            cpre[Jb][q] = (Jb <= wave) ? sa.S[(o1 + 16 * wave + lq + 4 * q) * ld + o1 + 16 * Jb + li] : 0.0;
+    bool bad = false;
+    tile_g2s(sa.S + o0 * ld + o0, ld, Ts, tid);
+    SideLoad side;
+    side.gA = sa.S + o1 * ld + o0; side.sA = As;          // S10, staged by waves 1-3 during the first 16-column panel
+    side.gB = nullptr; side.sB = nullptr; side.ld = ld; side.stamps = nullptr;
+    __syncthreads();
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
+    tile_s2g(Ts, sa.L + o0 * ld + o0, ld, tid);
+    tile_s2g(Xs, sa.X + o0 * ld + o0, ld, tid);
+    // ---- L10 = S10 X00^T (X00 lower triangular: column block Jb needs the k groups 0 .. 2 Jb + 1)
+    v4d lr[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) lr[Jb] = zero;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+        for (int Jb = kg / 2; Jb < 4; ++Jb) {
+            const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // every wave is done reading S10
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+    __syncthreads();
+    tile_s2g(As, sa.L + o1 * ld + o0, ld, tid);
+    // ---- S11 - L10 L10^T (lower 16 x 16 blocks) and W = L10 X00 (X00[k][c] = 0 for k < c: k groups 2 Jb .. 7)
+    v4d pacc[4], wv[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) { pacc[Jb] = zero; wv[Jb] = zero; }
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb <= wave) {
+                const v2d bv = *reinterpret_cast<const v2d*>(As + (16 * Jb + li) * TLD + k);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
+            }
+            if (kg >= 2 * Jb) {
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Xs[k * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Xs[(k + 1) * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // L10 (As) and X00 (Xs) have been read by everyone
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, wv[Jb], li, lq);            // W replaces L10
+        if (Jb <= wave) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ts[(16 * wave + lq + 4 * q) * TLD + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
+        }
+    }
+    __syncthreads();
+    SideLoad none;
+    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+    if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
+    tile_s2g(Ts, sa.L + o1 * ld + o1, ld, tid);
+    tile_s2g(Xs, sa.X + o1 * ld + o1, ld, tid);
+    // ---- X10 = -X11 W (X11 lower triangular: the rows of wave w need the k groups 0 .. 2 w + 1)
+    v4d xr[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) xr[Jb] = zero;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        if (kg < 2 * wave + 2) {
+            const int k = 8 * kg + 2 * lq;
+            const v2d av = *reinterpret_cast<const v2d*>(Xs + (16 * wave + li) * TLD + k);
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) {
+                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, As[k * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
+                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, As[(k + 1) * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sa.X[(o1 + 16 * wave + lq + 4 * q) * ld + o0 + 16 * Jb + li] = -xr[Jb][q];
+}
+constexpr size_t POTRF_DIAG128_LDS = (3 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+
 constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
 
 // Stand-alone tile kernel (tests): S (ld 64) -> L, X.

@@ -82,8 +82,10 @@ typedef struct {
      *  6 gemm_f64_big<false>                     7 gemm_f64_big<true>   (128 x 128 tile GEMM)
      *  8 potrf_panel                             9 potrf_update
      * 10 spmm_bxt (sparse C = B X^T)          13 gemm_f64_ll (32 x 32 tile GEMM of small launches)
-     * work = algorithmic flops (0-2, 6-9, 11-13) or algorithmic bytes (3-5, 10). */
-#define GMRF_KERNEL_CLASSES 16
+     * 14 / 15 gemm_f64_dma<.., B [n][k]> / <.., B [k][n]> (LDS-DMA staged GEMM: the batches' products since round 3)
+     * 16 potrf_diag128 (128 x 128 diagonal block of a batch: two tile Choleskys + the block's inverse)
+     * work = algorithmic flops (0-2, 6-9, 11-16) or algorithmic bytes (3-5, 10). */
+#define GMRF_KERNEL_CLASSES 24
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];
     int64_t kernel_launches[GMRF_KERNEL_CLASSES];
@@ -301,7 +303,9 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc); bit 6:
  * batches factor a panel left-looking (tile + potrf_panel_ll launches; measured slower, kept for comparison); bit 7:
  * one problem assembles Linv by recursive doubling after the panel steps instead of row by row inside them; bit 8:
- * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain. */
+ * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain; bit 10: batches
+ * factor a block by 64-column steps (tile, potrf_panel, potrf_update: the round-2 path) instead of 128-column diagonal
+ * blocks with GEMM panels (comparison). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 

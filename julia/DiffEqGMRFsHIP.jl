@@ -277,7 +277,7 @@ struct GmrfStats                             # gmrf_stats
     factor_ms::Float64; solve_ms::Float64; sample_ms::Float64
     factor_flops::Float64; sweep_bytes::Float64; sweep_ms::Float64
     n::Int64; n_blocks::Int64; block_size::Int64; block_size_padded::Int64; factor_bytes::Int64
-    kernel_ms::NTuple{16,Float64}; kernel_work::NTuple{16,Float64}; kernel_launches::NTuple{16,Int64}
+    kernel_ms::NTuple{24,Float64}; kernel_work::NTuple{24,Float64}; kernel_launches::NTuple{24,Int64}
     sweep_bytes_streamed::Float64
 end
 

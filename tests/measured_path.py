@@ -2,8 +2,8 @@
 
 bench.py's timed region is `ShardedPosterior.step` of a `HipEngine` with a batch of independent posteriors
 (distinct coefficient fields on one sparsity pattern), `keep_l = 0`, on a stream of a `StreamSet`, replayed
-from captured HIP graphs: two-level `potrf_panel` / `potrf_update` + rank-256 GEMM updates, doubling
-assembly of the block inverses, `spmm_bxt_tiles`, GEMM-route k = 64 sweeps, Philox `sample_batch`.
+from captured HIP graphs: `potrf_diag128` diagonal blocks + GEMM panels and rank-256 updates (`gemm_f64_dma`),
+doubling assembly of the block inverses, `spmm_bxt_tiles`, GEMM-route k = 64 sweeps, Philox `sample_batch`.
 `run` drives exactly that (second step = graph replay) and compares chosen problems of the batch with the
 oracle (/root/repo/oracle/bt_oracle.py, the restatement of /root/reference/src/tridiagonal_cholesky.jl:24-82
 and of `mean` / `rand` / `std`, scripts/darcy/solve_darcy_gmrf-fem.jl:190-192): posterior mean, the k samples

@@ -608,7 +608,7 @@ def test_config_burgers512x64_against_oracle(pkg):
 
 
 def test_two_level_panel_factor_of_batches(pkg):
-    """Batches factor a block in 256-column panels (rank-256 trailing updates on the GEMM kernel).
+    """Batches factor a block in 128-column diagonal blocks (potrf_diag128) with GEMM panels and rank-256 trailing updates.
     burgers512x64 (8 tiles per block) as a batch of two: against the oracle, and bitwise against a
     single problem driven through the same three-launch / two-level path (set_eager bit 1)."""
     w = pkg.workloads.make("burgers512x64")
@@ -631,6 +631,14 @@ def test_two_level_panel_factor_of_batches(pkg):
     F1.set_eager(0)                      # fused one-launch step: same factor up to rounding
     F1.refactor(w.Q.data)
     assert 0 < np.max(np.abs(F1.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
+    # the round-2 in-block Cholesky of batches (64-column steps: tile, potrf_panel, potrf_update; set_eager bit 10), kept
+    # for comparison: same factor up to rounding, same oracle tolerance
+    Fr = pkg.TridiagonalCholeskyFactor(batch=2)
+    Fr.set_eager(1024)
+    Fr.factor(w.Q, w.n_blocks, values=vals)
+    Fr.select_problem(0)
+    assert 0 < np.max(np.abs(Fr.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
+    assert rel(Fr.solve_batch(rhs[:, None, :])[0, 0], O.ldiv(Fo, w.rhs)) < solve_tol(w)
 
 
 def test_config_elliptic_long_chain_properties(pkg):
@@ -1224,8 +1232,8 @@ def test_measured_path_darcy256_batch_against_oracle(pkg):
     """The code path the headline number is measured on -- darcy256, a batch of 32 problems (8 distinct coefficient
     fields, as bench.py cycles them: every launch has the grid and the kernel symbol of the timed job),
     keep_l = 0, on a StreamSet stream, HipEngine / ShardedPosterior.step with the second step replayed from the
-    captured graphs (two-level potrf_panel / potrf_update + rank-256 GEMM updates, doubling assembly of Linv,
-    spmm_bxt_tiles, GEMM-route k = 64 sweeps, Philox sample_batch) -- against the oracle at FULL size for two
+    captured graphs (128-column diagonal blocks + GEMM panels + rank-256 GEMM updates on the LDS-DMA kernel, doubling
+    assembly of Linv, spmm_bxt_tiles, GEMM-route k = 64 sweeps, Philox sample_batch) -- against the oracle at FULL size for two
     problems of the batch: mean, the 64 samples (device draws fetched with gmrf_bt_normals), logdet, exact and
     RBMC(50) variances of the last eight blocks.  Tolerances as in test_config_darcy256_against_oracle; the
     variance tolerance is backed here by an extended-precision reference (HIP error <= 2 x the oracle's)."""
@@ -1239,11 +1247,13 @@ def test_measured_path_darcy256_batch_against_oracle(pkg):
                  true_var_samples=24)
     print("measured path:", res)
     route = res["route"]
-    # the launch classes of the timed route (include/gmrf_hip.h, gmrf_stats): both 64 x 64 GEMM symbols, tile
-    # Cholesky, potrf_panel, potrf_update, the sparse coupling product, k = 1 sweeps; no one-problem kernels
-    for cls in (0, 11, 1, 8, 9, 10, 3):
+    # the launch classes of the timed route (include/gmrf_hip.h, gmrf_stats): both symbols of the LDS-DMA GEMM, the
+    # 128-column diagonal-block kernel, the sparse coupling product, k = 1 sweeps; none of the one-problem kernels
+    # (fused potrf_step, sweep_mm) and none of the round-2 rank-64 step kernels
+    for cls in (14, 15, 16, 10, 3):
         assert route.get(cls, 0) > 0, (cls, route)
-    assert route.get(2, 0) == 0 and route.get(13, 0) == 0, route
+    for cls in (1, 2, 8, 9):
+        assert route.get(cls, 0) == 0, (cls, route)
     for p in (1, 30):
         r = res[p]
         assert r["mean_rel_l2"] < tol and r["samples_rel_l2"] < tol, r
