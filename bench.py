@@ -132,6 +132,127 @@ def cpu_baseline(w, k_samples: int, sample_blocks: int = 8):
             }, (Qs, nb, rhs, Z, res)
 
 
+def full_loop(pkg, torch, n_xy: int, batch: int, local: int, with_cpu: bool, sample_blocks: int = 8):
+    """The reference's WHOLE per-problem loop (scripts/darcy/solve_darcy_gmrf-fem.jl:176-198) for a batch of data-set
+    problems, everything after the coefficient table on the device, under its four timers:
+      "PDE Discretization"  coefficient table -> gmrf_darcy_p1_assemble (A, y)                      (:179-187)
+      "Conditioning"        gmrf_assemble_precision (Q + Q_eps A'A) + information vector, re-factorisation on the
+                            analysed pattern, posterior mean                                         (:188-190)
+      "Sampling"            one posterior sample                                                     (:191)
+      "Std dev"             RBMCStrategy(50) as the reference configures it (:174), and block-tridiagonal selected
+                            inversion beside it                                                      (:192)
+    Device times (events on the stream) of one pass over the batch, median of 3, per problem = / batch."""
+    import numpy as np
+    W = pkg.workloads
+    q_eps = 1e8
+    Q0, _, N = W.darcy_conditioning(n_xy)
+    n = n_xy * n_xy
+    gq = np.linspace(0.0, 1.0, 241)
+    GX, GY = np.meshgrid(gq, gq, indexing="ij")
+    tabs = [W.darcy_coefficient(523802340 + p)(GX.ravel(), GY.ravel()).reshape(241, 241) for p in range(min(8, batch))]
+    dev = torch.device("cuda", local)
+    st = torch.cuda.current_stream(dev)
+    tables = torch.from_numpy(np.stack([tabs[p % len(tabs)] for p in range(batch)])).to(dev)
+    d = pkg.DarcyP1Assembler(n_xy, n_xy, device=local, stream=st.cuda_stream)
+    asm = pkg.PosteriorAssembler(Q0, d.pattern, device=local, stream=st.cuda_stream)
+    qd = torch.from_numpy(Q0.data).to(dev)
+    zero = torch.zeros(n, dtype=torch.float64, device=dev)
+    nz = torch.empty((batch, asm.nnz_out), dtype=torch.float64, device=dev)
+    rhs = torch.empty((batch, 1, n), dtype=torch.float64, device=dev)
+    F = pkg.TridiagonalCholeskyFactor(device=local, stream=st.cuda_stream, batch=batch)
+    F.set_keep_l(False)
+    Qc = None
+
+    def one_pass(first):
+        nonlocal Qc
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record(st)
+        av, yv = [], []
+        for p in range(batch):                               # "PDE Discretization"
+            a, y = d.assemble(tables[p])
+            av.append(a); yv.append(y)
+        ev[1].record(st)
+        for p in range(batch):                               # "Conditioning"
+            nz[p] = asm.precision(qd, av[p], q_eps)
+            rhs[p, 0] = asm.rhs(None, av[p], zero, yv[p], q_eps)
+        if first:
+            P = asm.pattern.copy()
+            P.data = nz[0].cpu().numpy()
+            F.factor(P, N, values=nz.cpu().numpy())           # symbolic analysis once (the reference's permutation, :166-174)
+            Qc = pkg.CsrMatrix(P, device=local, stream=st.cuda_stream)
+        else:
+            F.refactor(nz)
+        mu = F.solve_batch(rhs)[:, 0, :]
+        ev[2].record(st)
+        F.sample_batch(1, mean=mu, seed=7, like=rhs)          # "Sampling"
+        ev[3].record(st)
+        v_rb = F.marginal_var("rbmc", k=50, seed=9, Q=Qc, q_values=nz)     # "Std dev", the reference's estimator
+        ev[4].record(st)
+        v_ex = F.marginal_var("exact")                        # the deterministic alternative
+        ev[5].record(st)
+        ev[5].synchronize()
+        return [ev[i].elapsed_time(ev[i + 1]) for i in range(5)], mu, v_rb, v_ex
+
+    one_pass(True)
+    runs = [one_pass(False) for _ in range(3)]
+    ms = np.median(np.array([r[0] for r in runs]), axis=0)
+    _, mu, v_rb, v_ex = runs[-1]
+    names = ["pde_discretization", "conditioning_incl_mean", "sampling_1", "std_rbmc50", "std_selected_inversion"]
+    out = {"workload": f"darcy{n_xy}: batch of {batch} data-set problems (8 coefficient fields), prior + pattern fixed",
+           "ms_per_batch": {k: float(v) for k, v in zip(names, ms)},
+           "ms_per_problem": {k: float(v) / batch for k, v in zip(names, ms)},
+           "problems_per_s_reference_loop": batch / (1e-3 * float(ms[0] + ms[1] + ms[2] + ms[3])),
+           "std_rbmc_vs_selected_inversion_median_rel": float(np.median(np.abs(np.sqrt(v_rb[0]) - np.sqrt(v_ex[0])) / np.sqrt(v_ex[0])))}
+    # the K6 product inside the RBMC estimator: Q x on 50 node-major right-hand sides, posterior pattern of this workload
+    X = torch.randn(n, 50, dtype=torch.float64, device=dev)
+    Y = torch.empty_like(X)
+    for _ in range(20):
+        Qc.matmul_into(X, Y)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(50):
+        Qc.matmul_into(X, Y)
+    e1.record(st); e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / 50
+    b = asm.nnz_out * 12 + 8 * (n + 1) + 16 * n * 50
+    out["rbmc_k6"] = {"kernel": "csr_spmm_tiles_pad (k = 50 node-major)", "us": us, "algorithmic_bytes": b, "achieved": b / us / 1e3,
+                      "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": b / us / 1e3 / PEAK_HBM_GBPS,
+                      "note": "11 MB of matrix + 52 MB of operands per call: L2 / Infinity-Cache resident at this size, "
+                              "roofline_spmm has the HBM-sized case"}
+    F.close()
+    if with_cpu:
+        # the oracle's same loop on the host: discretisation and assembly at full size (one problem), factor / mean /
+        # sample / RBMC(50) on the leading blocks scaled by n_blocks / sample_blocks (as cpu_baseline does)
+        from oracle import bt_oracle as O
+        t0 = time.perf_counter()
+        A_o, y_o = O.assemble_darcy_diff_matrix(n_xy, n_xy, gq, gq, tabs[0], 1.0)
+        t1 = time.perf_counter()
+        Qp = (Q0 + q_eps * (A_o.T @ A_o)).tocsc()
+        b_o = q_eps * (A_o.T @ y_o)
+        t2 = time.perf_counter()
+        nb = min(sample_blocks, N)
+        ns = nb * (n // N)
+        Qs = Qp.tocsr()[:ns, :ns].tocsc()
+        scale = N / nb
+        t3 = time.perf_counter()
+        Fo = O.tridiagonal_cholesky(Qs, nb)
+        mu_o = O.ldiv(Fo, b_o[:ns])
+        t4 = time.perf_counter()
+        rng = np.random.default_rng(0)
+        O.sample(Fo, mu_o, rng.standard_normal((ns, 1)))
+        t5 = time.perf_counter()
+        Xs = O.backward_solve(Fo, rng.standard_normal((ns, 50)))
+        O.marginal_variances_rbmc(Qs, Xs)
+        t6 = time.perf_counter()
+        out["cpu_oracle_ms_per_problem"] = {
+            "pde_discretization": 1e3 * (t1 - t0), "conditioning_incl_mean": 1e3 * ((t2 - t1) + (t4 - t3) * scale),
+            "sampling_1": 1e3 * (t5 - t4) * scale, "std_rbmc50": 1e3 * (t6 - t5) * scale,
+            "note": f"oracle (NumPy / SciPy, {os.cpu_count()} host cores available): discretisation and assembly at full size, "
+                    f"factor + mean / sample / RBMC(50) on the leading {nb} of {N} blocks scaled x{scale:g}; single shot"}
+    return out
+
+
+
 class ProblemsJob:
     """T handles x batch B of independent posteriors on T streams / host threads (no collective)."""
 
@@ -272,6 +393,7 @@ def main():
     ap.add_argument("--no-single-problem", action="store_true",
                     help="skip the batch-1 latency probe (profile runs: keeps one launch shape per kernel)")
     ap.add_argument("--no-spmm", action="store_true", help="skip the K6 roofline leg (burgers4096x512 matrix)")
+    ap.add_argument("--no-full-loop", action="store_true", help="skip the leg that times the reference's whole per-problem loop")
     ap.add_argument("--no-side-legs", action="store_true", help="N > 1: skip the problems-mode and C4 legs")
     ap.add_argument("--side-leg-limit", type=float, default=360.0, help="N > 1: seconds after which the side legs are abandoned")
     ap.add_argument("--eager-flags", type=int, default=0, help="gmrf_bt_set_eager bits for every handle (experiments)")
@@ -633,6 +755,11 @@ def main():
             out["single_problem"] = {"latency_ms": 1e3 * lat1, "solves_per_s": (1 + args.samples) / lat1, "factor_ms": f1,
                                      "factor_tflops_lapack_count": F1.stats()["factor_flops"] / (f1 * 1e-3) / 1e12}
             F1.close()
+        if not args.no_full_loop and args.config.startswith("darcy"):
+            try:
+                out["full_loop"] = full_loop(pkg, torch, int(args.config[5:]), args.batch, local, not args.no_cpu_baseline)
+            except Exception as e:      # noqa: BLE001
+                out["full_loop"] = {"error": repr(e)[:300]}
         if not args.no_spmm:
             try:
                 out["roofline_spmm"] = spmm_roofline(pkg, torch)

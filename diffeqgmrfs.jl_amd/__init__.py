@@ -12,11 +12,11 @@ Layout:
     workloads.py    synthetic FEM precision matrices for the BASELINE configs (inputs only)
 """
 from . import _cabi, api, workloads  # noqa: F401
-from .api import (BurgersP1Tangent, Comm, StreamSet, ConditionedGMRF, CsrMatrix, DarcyP1Assembler, GmrfError, NotPositiveDefinite, PosteriorAssembler,  # noqa: F401
+from .api import (BurgersP1Tangent, ShallowWaterP1, Comm, StreamSet, ConditionedGMRF, CsrMatrix, DarcyP1Assembler, GmrfError, NotPositiveDefinite, PosteriorAssembler,  # noqa: F401
                   TridiagonalCholeskyFactor, backward_solve, condition_on_observations, extract_blocks, forward_solve,
                   gn_step, ldiv, ldiv_,
                   logdet, make_chunks, tridiagonal_cholesky)
 
 __all__ = ["TridiagonalCholeskyFactor", "tridiagonal_cholesky", "forward_solve", "backward_solve",
            "ldiv", "ldiv_", "make_chunks", "extract_blocks", "logdet", "CsrMatrix", "GmrfError",
-           "NotPositiveDefinite", "PosteriorAssembler", "DarcyP1Assembler", "BurgersP1Tangent", "Comm", "StreamSet", "gn_step", "ConditionedGMRF", "condition_on_observations", "workloads", "api"]
+           "NotPositiveDefinite", "PosteriorAssembler", "DarcyP1Assembler", "BurgersP1Tangent", "ShallowWaterP1", "Comm", "StreamSet", "gn_step", "ConditionedGMRF", "condition_on_observations", "workloads", "api"]

@@ -35,7 +35,9 @@ EXPORTS = [
     "gmrf_bt_packed_size", "gmrf_bt_pack_blocks_async", "gmrf_bt_unpack_blocks_async",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows", "gmrf_spmm_async", "gmrf_spmm_rows_async",
     "gmrf_darcy_p1_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
-    "gmrf_burgers_p1_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
+    "gmrf_burgers_p1_create", "gmrf_burgers_p2_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
+    "gmrf_shallow_water_p1_create", "gmrf_shallow_water_p1_destroy", "gmrf_shallow_water_p1_pattern", "gmrf_shallow_water_p1_qpoints",
+    "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
@@ -152,9 +154,16 @@ def load() -> C.CDLL:
         "gmrf_darcy_p1_pattern": [vp, P(i64), vp, vp, i32],
         "gmrf_darcy_p1_assemble": [vp, vp, i64, dbl, vp, vp],
         "gmrf_burgers_p1_create": [i32, vp, i64, i64, dbl, dbl, P(vp)],
+        "gmrf_burgers_p2_create": [i32, vp, i64, i64, dbl, dbl, P(vp)],
         "gmrf_burgers_p1_destroy": [vp],
         "gmrf_burgers_p1_pattern": [vp, P(i64), vp, vp, i32],
         "gmrf_burgers_p1_tangent": [vp, vp, vp, vp],
+        "gmrf_shallow_water_p1_create": [i32, vp, i64, i64, P(vp)],
+        "gmrf_shallow_water_p1_destroy": [vp],
+        "gmrf_shallow_water_p1_pattern": [vp, i32, P(i64), vp, vp, i32],
+        "gmrf_shallow_water_p1_qpoints": [vp, vp],
+        "gmrf_shallow_water_p1_assemble": [vp, vp, dbl, dbl, dbl, vp, vp, vp, vp],
+        "gmrf_shallow_water_p1_operators": [vp, vp, vp, vp, vp, dbl, dbl, dbl, vp, vp, vp, vp],
         "gmrf_spmm": [vp, vp, vp, i64, i64, i64],
         "gmrf_spmm_async": [vp, vp, vp, i64, i64, i64],
         "gmrf_spmm_rows_async": [vp, vp, vp, i64, i64, i64],

@@ -267,15 +267,18 @@ class BurgersP1Tangent:
     piece): `f_and_J` of /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149 with
     `assemble_burgers_advection_matrix` (src/problems/burgers.jl:5-59) per time slice and the static part of
     `assemble_burgers_mass_diffusion_matrices` (:60-98), on the periodic P1 line (ns nodes on [0,1), nt slices,
-    time-major index).  `pattern` is the CSR matrix (values 1, (nt-1) ns x nt ns, 6 entries per row) whose `.data`
+    time-major index) or, with order = 2, the quadratic periodic line.  `pattern` is the CSR matrix (values 1, (nt-1) ns x nt ns, 6 entries per row) whose `.data`
     order `tangent()` fills -- the `J` of `PosteriorAssembler`.  device = -1: pattern only (no GPU needed)."""
 
-    def __init__(self, ns: int, nt: int, dt: float, nu: float, device: int = 0, stream: int = 0):
-        self.ns, self.nt, self.dt, self.nu = int(ns), int(nt), float(dt), float(nu)
+    def __init__(self, ns: int, nt: int, dt: float, nu: float, device: int = 0, stream: int = 0, order: int = 1):
+        """order = 2: the quadratic periodic line of the reference's scripts (src/utils.jl:42-49): ns = 2 N_x dofs numbered by
+        position, vertex rows of J with 10 entries, midpoint rows with 6 (gmrf_burgers_p2_create)."""
+        self.ns, self.nt, self.dt, self.nu, self.order = int(ns), int(nt), float(dt), float(nu), int(order)
         self.rows, self.n = (self.nt - 1) * self.ns, self.nt * self.ns
         self._h = C.c_void_p()
         lib = _cabi.load()
-        _cabi.check(lib.gmrf_burgers_p1_create(device, C.c_void_p(stream), ns, nt, float(dt), float(nu), C.byref(self._h)))
+        create = lib.gmrf_burgers_p2_create if self.order == 2 else lib.gmrf_burgers_p1_create
+        _cabi.check(create(device, C.c_void_p(stream), ns, nt, float(dt), float(nu), C.byref(self._h)))
         nnz = C.c_int64(0)
         _cabi.check(lib.gmrf_burgers_p1_pattern(self._h, C.byref(nnz), None, None, 0))
         self.nnz = int(nnz.value)
@@ -306,6 +309,85 @@ class BurgersP1Tangent:
             raise ValueError(f"w must have {self.n} entries")
         _cabi.check(_cabi.load().gmrf_burgers_p1_tangent(self._h, _cabi.ptr(wv), _cabi.ptr(vals), _cabi.ptr(f)))
         return vals, f
+
+
+class ShallowWaterP1:
+    """Element kernels of the linear shallow-water SPDE on the device (third piece):
+    `assemble_system!` of /root/reference/src/spdes/shallow_water.jl:17-122 (coupling K, element-lumped mass M, stiffness S
+    of the three fields h, u, v) and the per-step operators of `discretize` (:170-217), on the structured P1 triangle mesh
+    (nx x ny nodes, x fastest, quads cut by the diagonal n00 - n11; dof = 3 * node + field; symmetric 3-point quadrature).
+    `pattern_K` / `pattern_S` are CSR matrices (values 1) whose `.data` order `assemble()` / `operators()` fill;
+    `qpoints` (cells, 3, 2) are the quadrature points at which the caller evaluates its H(x).  device = -1: patterns and
+    quadrature points only (no GPU needed)."""
+
+    def __init__(self, nx: int, ny: int, device: int = 0, stream: int = 0):
+        self.nx, self.ny, self.nn, self.n = int(nx), int(ny), int(nx) * int(ny), 3 * int(nx) * int(ny)
+        self.cells = 2 * (self.nx - 1) * (self.ny - 1)
+        self._h = C.c_void_p()
+        lib = _cabi.load()
+        _cabi.check(lib.gmrf_shallow_water_p1_create(device, C.c_void_p(stream), nx, ny, C.byref(self._h)))
+        pats = []
+        for which in (0, 1):
+            nnz = C.c_int64(0)
+            _cabi.check(lib.gmrf_shallow_water_p1_pattern(self._h, which, C.byref(nnz), None, None, 0))
+            rp, ci = np.empty(self.n + 1, dtype=np.int64), np.empty(nnz.value, dtype=np.int64)
+            _cabi.check(lib.gmrf_shallow_water_p1_pattern(self._h, which, None, _cabi.ptr(rp), _cabi.ptr(ci), 0))
+            pats.append(sp.csr_matrix((np.ones(nnz.value), ci, rp), shape=(self.n, self.n)))
+        self.pattern_K, self.pattern_S = pats
+        self.qpoints = np.empty((self.cells, 3, 2), dtype=np.float64)
+        _cabi.check(lib.gmrf_shallow_water_p1_qpoints(self._h, _cabi.ptr(self.qpoints)))
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                _cabi.load().gmrf_shallow_water_p1_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _mask(prescribed, n):
+        if prescribed is None:
+            return None
+        if _is_torch(prescribed):
+            import torch
+            m = prescribed.to(torch.uint8).contiguous()
+            if m.numel() != n:
+                raise ValueError(f"prescribed: expected {n} entries")
+            return m
+        m = np.ascontiguousarray(np.asarray(prescribed) != 0, dtype=np.uint8)
+        if m.size != n:
+            raise ValueError(f"prescribed: expected {n} entries")
+        return m
+
+    def _out(self, ref, count):
+        if _is_torch(ref):
+            import torch
+            return torch.empty(count, dtype=torch.float64, device=ref.device)
+        return np.empty(count, dtype=np.float64)
+
+    def assemble(self, H_q, k: float = 0.0, f: float = 0.0, g: float = 9.81, prescribed=None):
+        """H_q: (cells, 3) values of H at `qpoints` (NumPy array or torch CUDA tensor).  Returns (K values, lumped M, S values),
+        same kind as H_q, with `apply!` of the prescribed dofs done."""
+        hq = H_q.contiguous() if _is_torch(H_q) else np.ascontiguousarray(H_q, dtype=np.float64)
+        if (hq.numel() if _is_torch(hq) else hq.size) != self.cells * 3:
+            raise ValueError(f"H_q must have {self.cells} x 3 entries")
+        kv, ml, sv = self._out(hq, self.pattern_K.nnz), self._out(hq, self.n), self._out(hq, self.pattern_S.nnz)
+        m = self._mask(prescribed, self.n)
+        _cabi.check(_cabi.load().gmrf_shallow_water_p1_assemble(self._h, _cabi.ptr(hq), float(k), float(f), float(g), _cabi.ptr(m),
+                                                                _cabi.ptr(kv), _cabi.ptr(ml), _cabi.ptr(sv)))
+        return kv, ml, sv
+
+    def operators(self, K_vals, M_lumped, S_vals, prescribed=None, kappa_matern: float = 1.0, tau: float = 1.0, dt: float = 1.0):
+        """The operators of one time step (`discretize`, :170-217): dict with G_dt (values in pattern_K: M~ + dt K, constraints
+        applied), J (values in pattern_S: sqrt(ratio) M~^-1/2 (kappa^2 M~ + G); Q_matern = J'J), M_tilde, beta."""
+        g_v, j_v = self._out(K_vals, self.pattern_K.nnz), self._out(K_vals, self.pattern_S.nnz)
+        mt, be = self._out(K_vals, self.n), self._out(K_vals, self.n)
+        m = self._mask(prescribed, self.n)
+        _cabi.check(_cabi.load().gmrf_shallow_water_p1_operators(self._h, _cabi.ptr(K_vals), _cabi.ptr(M_lumped), _cabi.ptr(S_vals),
+                                                                 _cabi.ptr(m), float(kappa_matern), float(tau), float(dt),
+                                                                 _cabi.ptr(g_v), _cabi.ptr(j_v), _cabi.ptr(mt), _cabi.ptr(be)))
+        return {"G_dt": g_v, "J": j_v, "M_tilde": mt, "beta": be}
 
 
 def gn_step(F: "TridiagonalCholeskyFactor", asm: PosteriorAssembler, q_values, Qx_prior, j_values, x, obs_diff,

@@ -232,4 +232,96 @@ __global__ __launch_bounds__(256) void burgers_p1_rows(BurgersP1Args a) {
     a.f[gid] = acc + a.dt * v_i;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same residual and tangent on the QUADRATIC periodic line -- the element the reference's Burgers scripts run on
+// (`periodic_unit_interval_discretization`, /root/reference/src/utils.jl:42-49: generate_grid(QuadraticLine, (N_x,)),
+// Lagrange{RefLine,2}, QuadratureRule{RefLine}(3)).  ns = 2 N_x dofs numbered by position (x_i = i / ns): even i are cell
+// boundaries, odd i midpoints; cell e has the local dofs (left, right, middle) = (2 e, 2 e + 2 mod ns, 2 e + 1) with
+// N = (xi (xi - 1) / 2, xi (xi + 1) / 2, 1 - xi^2).  A vertex row couples with its two cells (columns i-2 .. i+2), a
+// midpoint row with its own cell (i-1, i, i+1): 10 / 6 entries per row of J (slices t-1 and t), ascending columns.
+__host__ __device__ inline void burgers_p2_cell(double h, const double (&w)[3], double (&Ge)[3][3], double (&ve)[3],
+                                                double (&Me)[3][3], double (&De)[3][3]) {
+    const double xi[3] = {-0.7745966692414834, 0.0, 0.7745966692414834};
+    const double wq[3] = {0.5555555555555556, 0.8888888888888888, 0.5555555555555556};
+    const double jac = 0.5 * h;
+    for (int i = 0; i < 3; ++i) { ve[i] = 0.0; for (int j = 0; j < 3; ++j) { Ge[i][j] = 0.0; Me[i][j] = 0.0; De[i][j] = 0.0; } }
+    for (int q = 0; q < 3; ++q) {
+        const double x = xi[q], dOm = jac * wq[q];
+        const double N[3] = {0.5 * x * (x - 1.0), 0.5 * x * (x + 1.0), 1.0 - x * x};
+        const double dN[3] = {(x - 0.5) / jac, (x + 0.5) / jac, (-2.0 * x) / jac};
+        double cur_u = 0.0, grad_u = 0.0;
+        for (int k = 0; k < 3; ++k) cur_u += N[k] * w[k];         // function_value :34
+        for (int k = 0; k < 3; ++k) grad_u += dN[k] * w[k];       // :36-39
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) {
+                Ge[i][j] += N[i] * (N[j] * grad_u + cur_u * dN[j]) * dOm;      // :46
+                Me[i][j] += N[i] * N[j] * dOm;
+                De[i][j] += dN[i] * dN[j] * dOm;
+            }
+            ve[i] += N[i] * cur_u * grad_u * dOm;                 // :48
+        }
+    }
+}
+
+// first entry of row (t, i) in the value array: 16 entries per cell and slice (10 for the vertex row, 6 for the midpoint row)
+__host__ __device__ inline int64_t burgers_p2_row_offset(int64_t ns, int64_t t1, int64_t i) {      // t1 = t - 1 >= 0
+    return (t1 * (ns / 2) + i / 2) * 16 + ((i & 1) ? 10 : 0);
+}
+
+__global__ __launch_bounds__(256) void burgers_p2_rows(BurgersP1Args a) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t rows = (int64_t)(a.nt - 1) * a.ns;
+    if (gid >= rows) return;
+    const int ns = a.ns, nc = ns / 2;
+    const int t = (int)(gid / ns) + 1, i = (int)(gid % ns);
+    const double h = 1.0 / (double)nc;
+    const double* wt = a.w + (int64_t)t * ns;
+    const double* wp = a.w + (int64_t)(t - 1) * ns;
+    auto wrap = [ns](int c) { return c < 0 ? c + ns : (c >= ns ? c - ns : c); };
+    // the row's columns (before the wrap) and its assembled mass / diffusion / advection entries
+    int cols[5]; double m[5], d[5], g[5]; int cnt; double v_i;
+    double Ge[3][3], ve[3], Me[3][3], De[3][3];
+    if (i & 1) {                                       // midpoint of cell e = (i - 1) / 2: local dof 2
+        const double w3[3] = {wt[i - 1], wt[wrap(i + 1)], wt[i]};
+        burgers_p2_cell(h, w3, Ge, ve, Me, De);
+        cnt = 3;
+        cols[0] = i - 1; cols[1] = i; cols[2] = i + 1;
+        const int loc[3] = {0, 2, 1};                  // columns left, middle, right in local numbering
+        for (int c = 0; c < 3; ++c) { m[c] = Me[2][loc[c]]; d[c] = De[2][loc[c]]; g[c] = Ge[2][loc[c]]; }
+        v_i = ve[2];
+    } else {                                           // vertex: right end (local 1) of cell i/2 - 1, left end (local 0) of cell i/2
+        const double wl[3] = {wt[wrap(i - 2)], wt[i], wt[wrap(i - 1)]};
+        const double wr[3] = {wt[i], wt[wrap(i + 2)], wt[wrap(i + 1)]};
+        double GeR[3][3], veR[3], MeR[3][3], DeR[3][3];
+        burgers_p2_cell(h, wl, Ge, ve, Me, De);
+        burgers_p2_cell(h, wr, GeR, veR, MeR, DeR);
+        cnt = 5;
+        for (int c = 0; c < 5; ++c) cols[c] = i - 2 + c;
+        m[0] = Me[1][0]; m[1] = Me[1][2]; m[2] = Me[1][1] + MeR[0][0]; m[3] = MeR[0][2]; m[4] = MeR[0][1];
+        d[0] = De[1][0]; d[1] = De[1][2]; d[2] = De[1][1] + DeR[0][0]; d[3] = DeR[0][2]; d[4] = DeR[0][1];
+        g[0] = Ge[1][0]; g[1] = Ge[1][2]; g[2] = Ge[1][1] + GeR[0][0]; g[3] = GeR[0][2]; g[4] = GeR[0][1];
+        v_i = ve[1] + veR[0];
+    }
+    // ascending column order after the wrap: a rotation of the list (columns < 0 move to the end, columns >= ns to the front)
+    int first = 0;
+    for (int c = 0; c < cnt; ++c) if (cols[c] >= ns) { first = c; break; }
+    if (cols[0] < 0) { first = 0; while (cols[first] < 0) ++first; }
+    const double dtnu = a.dt * a.nu;
+    double* v = a.vals + burgers_p2_row_offset(ns, t - 1, i);
+    double acc = 0.0;
+    double prev_terms[5], cur_terms[5];
+    for (int k = 0; k < cnt; ++k) {
+        const int c = (first + k) % cnt, col = wrap(cols[c]);
+        const double sp = -m[c], st = m[c] + dtnu * d[c];          // J_static = M_{t+1} - M_t + dt nu G_{t+1}
+        v[k] = sp;
+        v[cnt + k] = st + a.dt * g[c];
+        prev_terms[k] = sp * wp[col];
+        cur_terms[k] = st * wt[col];
+    }
+    // f = J_static * w + dt * v_adv: the product sums a row in ascending column order (slice t-1 first)
+    for (int k = 0; k < cnt; ++k) acc += prev_terms[k];
+    for (int k = 0; k < cnt; ++k) acc += cur_terms[k];
+    a.f[gid] = acc + a.dt * v_i;
+}
+
 }  // namespace gmrf

@@ -31,6 +31,7 @@
 #include "misc_kernels.hpp"
 #include "potrf_step.hpp"
 #include "sweep.hpp"
+#include "swe_assemble.hpp"
 
 using namespace gmrf;
 
@@ -176,6 +177,7 @@ struct gmrf_handle {
     bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
     bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
+    bool panels128 = false;            // batches: rows below a diagonal block meet the 128 x 128 inverses one by one (K = 128 products; comparison)
     bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
@@ -730,45 +732,83 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         HIPCHK(hipGetLastError());
         return GMRF_OK;
     }
-    // Batches (round 3): 128-column diagonal blocks in one kernel each, everything below them on the GEMM kernel
-    // (potrf_diag128, see potrf_step.hpp).
+    // Batches (round 3): 256-column panels whose diagonal block is two potrf_diag128 launches (see potrf_step.hpp); the
+    // rows below a panel meet the 256 x 256 inverse of its diagonal block in ONE product on the GEMM kernel (K = 256):
+    //   potrf_diag128(A)                              A, B: the panel's two 128 x 128 diagonal blocks
+    //   L_BA = S_BA X_A^T,  S_BB -= L_BA L_BA^T       (two 128^3 products)
+    //   potrf_diag128(B)
+    //   X_BA = -X_B (L_BA X_A)                        (the level-128 doubling step of this pair: X_P = [X_A 0; X_BA X_B])
+    //   L[below, P] = S[below, P] X_P^T               (K = 256, X_P lower triangular)
+    //   S[below, below] -= L[below, P] L[below, P]^T  (rank-256 update)
+    // (set_eager bit 11: the rows below meet the two 128 x 128 inverses one after the other instead -- three K = 128 products
+    //  of full height per panel; measured slower: the short-K launches run at ~32 TF/s.)
     if (!fused && !fused_in_panel && !h->left_looking && !h->rank64_panels && !overlap && nt >= 4 && nt % 4 == 0) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.nt = nt; sa.cend = nt;
         sa.info = h->d_info; sa.blk = blk_id; sa.dbg = nullptr;
         sa.pS = (int64_t)bsp * bsp; sa.pL = stride_pL(h); sa.pX = stride_pX(h); sa.blk_per_problem = (int)h->N;
+        const int64_t pW = (int64_t)bsp * bsp;
         const double t3 = 64.0 * 64.0 * 64.0, nb = (double)h->B;
-        for (int j = 0; j < nt; j += 2) {
+        auto diag128 = [&](int j) -> gmrf_status {
             sa.j = j;
-            {
-                // two tile Choleskys + four triangular 64^3 products (L10, S11 update, L10 X00, X11 W)
-                ProfScope ps(h, 16, (2.0 * t3 / 3.0 + 4.0 * 2.0 * t3 * 0.625) * nb);
-                hipLaunchKernelGGL(potrf_diag128, dim3(1, (unsigned)h->B), dim3(256), POTRF_DIAG128_LDS, h->stream, sa);
-                HIPCHK(hipGetLastError());
+            // two tile Choleskys + four triangular 64^3 products (L10, S11 update, L10 X00, X11 W)
+            ProfScope ps(h, 16, (2.0 * t3 / 3.0 + 4.0 * 2.0 * t3 * 0.625) * nb);
+            static const size_t lds_pad = [] { const char* e = getenv("GMRF_DIAG128_LDS_PAD_KB"); return (size_t)(e ? atoi(e) : 0) * 1024; }();   // tuning aid
+            static const bool fat = [] { const char* e = getenv("GMRF_DIAG128_FAT"); return e && atoi(e) != 0; }();      // tuning aid: the three-tile form
+            if (fat) hipLaunchKernelGGL(potrf_diag128, dim3(1, (unsigned)h->B), dim3(256), POTRF_DIAG128_LDS + lds_pad, h->stream, sa);
+            else hipLaunchKernelGGL(potrf_diag128_slim, dim3(1, (unsigned)h->B), dim3(256), POTRF_DIAG128_SLIM_LDS + lds_pad, h->stream, sa);
+            HIPCHK(hipGetLastError());
+            return GMRF_OK;
+        };
+        if (h->panels128) {
+            for (int j = 0; j < nt; j += 2) {
+                GCHK(diag128(j));
+                const int m2 = nt - j - 2;                         // row tiles below the diagonal block
+                if (m2 <= 0) continue;
+                const int64_t oj = (int64_t)j * 64, ob = oj + 128;
+                double* Lb = L + ob * ld + oj;
+                // L21 = S21 X_A^T: b(k, n) = X_A[n][k] (stored [n][k]), zero for k > n
+                GCHK(gemm(h, false, false, 64 * m2, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oj, ld, X + oj * ld + oj, ld, 0.0, Lb, ld,
+                          sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * m2 * nb));
+                if ((j / 2) % 2 == 0) {
+                    // first half of a 256-column panel: its second half S[j+2.., j+2..j+3] -= L21 L21[0:128]^T
+                    GCHK(gemm(h, false, false, 64 * m2, 128, 128, 0, 1, -1.0, Lb, ld, Lb, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL, sa.pS,
+                              1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * (2.0 * m2 - 1.0) * nb));
+                } else {
+                    const double* Lp = L + ob * ld + (oj - 128);
+                    GCHK(gemm(h, false, false, m2 * 64, m2 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL,
+                              sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m2 * (m2 + 1) / 2) * nb));
+                }
             }
-            const int m2 = nt - j - 2;                         // row tiles below the diagonal block
-            if (m2 <= 0) continue;
-            const int64_t oj = (int64_t)j * 64, ob = oj + 128;
-            const double* Sb = S + ob * ld + oj;               // rows below, the block's 128 columns
-            const double* XA = X + oj * ld + oj;               // X_A = inverse of the diagonal block (lower triangular)
-            double* Lb = L + ob * ld + oj;
-            // L21 = S21 X_A^T: b(k, n) = X_A[n][k] (stored [n][k]), zero for k > n
-            GCHK(gemm(h, false, false, 64 * m2, 128, 128, TRI_B_UPPER, 0, 1.0, Sb, ld, XA, ld, 0.0, Lb, ld, sa.pS, sa.pX, sa.pL,
-                      1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * m2 * nb));
-            if ((j / 2) % 2 == 0) {
-                // first half of a 256-column panel: its second half S[j+2.., j+2..j+3] -= L21 L21[0:128]^T (tile (0, 1) lies
-                // above the diagonal and is skipped)
-                GCHK(gemm(h, false, false, 64 * m2, 128, 128, 0, 1, -1.0, Lb, ld, Lb, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL, sa.pS,
-                          1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * (2.0 * m2 - 1.0) * nb));
-            } else {
-                // panel complete: S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the 256-column panel P
-                const double* Lp = L + ob * ld + (oj - 128);
-                GCHK(gemm(h, false, false, m2 * 64, m2 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL,
-                          sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m2 * (m2 + 1) / 2) * nb));
-            }
+            GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
+            return GMRF_OK;
         }
-        // X = L^-1 by recursive doubling over the 128-wide diagonal inverses
-        GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
+        for (int j = 0; j < nt; j += 4) {
+            const int64_t oa = (int64_t)j * 64, ob = oa + 128, oc = oa + 256;
+            GCHK(diag128(j));
+            // L_BA = S_BA X_A^T (X_A lower triangular, stored [n][k]);  S_BB -= L_BA L_BA^T (lower tiles)
+            GCHK(gemm(h, false, false, 128, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + ob * ld + oa, ld,
+                      sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * 2.0 * nb));
+            GCHK(gemm(h, false, false, 128, 128, 128, 0, 1, -1.0, L + ob * ld + oa, ld, L + ob * ld + oa, ld, 1.0, S + ob * ld + ob, ld,
+                      sa.pL, sa.pL, sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * 3.0 * nb));
+            GCHK(diag128(j + 2));
+            // X_BA = -X_B (L_BA X_A): the level-128 doubling step of this pair (T is the work block doubling_levels uses)
+            GCHK(gemm(h, false, true, 128, 128, 128, TRI_B_LOWER, 0, 1.0, L + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, T + ob * ld + oa, ld,
+                      sa.pL, sa.pX, pW));
+            GCHK(gemm(h, false, true, 128, 128, 128, TRI_A_LOWER, 0, -1.0, X + ob * ld + ob, ld, T + ob * ld + oa, ld, 0.0, X + ob * ld + oa, ld,
+                      sa.pX, pW, sa.pX));
+            const int m3 = nt - j - 4;                             // row tiles below the panel
+            if (m3 <= 0) continue;
+            // L[below, P] = S[below, P] X_P^T: b(k, n) = X_P[n][k], zero for k > n (tile-K units: 1 + 2 + 3 + 4 of 16)
+            GCHK(gemm(h, false, false, 64 * m3, 256, 256, TRI_B_UPPER, 0, 1.0, S + oc * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + oc * ld + oa, ld,
+                      sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 10.0 * m3 * nb));
+            // S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the panel
+            const double* Lp = L + oc * ld + oa;
+            GCHK(gemm(h, false, false, m3 * 64, m3 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + oc * ld + oc, ld, sa.pL, sa.pL, sa.pS,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m3 * (m3 + 1) / 2) * nb));
+        }
+        // X = L^-1 by recursive doubling over the 256-wide diagonal inverses
+        GCHK(doubling_levels(h, L, X, T, 256, bsp / 2, -1));
         return GMRF_OK;
     }
     for (int j = 0; j < nt; ++j) {
@@ -1263,7 +1303,8 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_DIAG128_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128_slim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(gemm_init());
     HIPCHK(gemm_dma_init());
     *out = h;
@@ -1334,6 +1375,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 256) != 0) != h->no_lookahead) { destroy_graphs(h); h->no_lookahead = (eager & 256) != 0; }
     if (((eager & 512) != 0) != h->update_via_gemm) { destroy_graphs(h); h->update_via_gemm = (eager & 512) != 0; }
     if (((eager & 1024) != 0) != h->rank64_panels) { destroy_graphs(h); h->rank64_panels = (eager & 1024) != 0; }
+    if (((eager & 2048) != 0) != h->panels128) { destroy_graphs(h); h->panels128 = (eager & 2048) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -2785,16 +2827,18 @@ struct gmrf_burgers_p1 {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t ns = 0, nt = 0, rows = 0, nnz = 0;
+    int order = 1;                      // 1: P1 line (6 entries per row), 2: quadratic line (10 / 6 entries per row)
     double dt = 0.0, nu = 0.0;
     double *d_w = nullptr, *d_vals = nullptr, *d_f = nullptr;       // staging for host callers
 };
 
-gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu,
-                                   gmrf_burgers_p1** out) {
+static gmrf_status burgers_line_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu, int order,
+                                       gmrf_burgers_p1** out) {
     if (!out || ns < 3 || nt < 2 || ns > (1 << 24) || nt > (1 << 20) || !(dt > 0.0) || !(nu >= 0.0))
         return bad_shape("bad Burgers mesh (ns >= 3 nodes, nt >= 2 slices, dt > 0, nu >= 0)");
+    if (order == 2 && (ns % 2 || ns < 6)) return bad_shape("the quadratic line has an even number of dofs (>= 6): two per cell");
     auto* b = new gmrf_burgers_p1();
-    b->ns = ns; b->nt = nt; b->rows = (nt - 1) * ns; b->nnz = b->rows * 6; b->dt = dt; b->nu = nu;
+    b->ns = ns; b->nt = nt; b->rows = (nt - 1) * ns; b->nnz = b->rows * (order == 2 ? 8 : 6); b->dt = dt; b->nu = nu; b->order = order;
     if (device >= 0) {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
@@ -2810,6 +2854,13 @@ gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int
     }
     *out = b;
     return GMRF_OK;
+}
+
+gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu, gmrf_burgers_p1** out) {
+    return burgers_line_create(device, stream, ns, nt, dt, nu, 1, out);
+}
+gmrf_status gmrf_burgers_p2_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu, gmrf_burgers_p1** out) {
+    return burgers_line_create(device, stream, ns, nt, dt, nu, 2, out);
 }
 
 gmrf_status gmrf_burgers_p1_destroy(gmrf_burgers_p1* b) {
@@ -2830,6 +2881,24 @@ gmrf_status gmrf_burgers_p1_pattern(const gmrf_burgers_p1* b, int64_t* nnz_out, 
                                     int32_t index_base) {
     if (!b) return bad_shape("null handle");
     if (nnz_out) *nnz_out = b->nnz;
+    if (b->order == 2) {
+        // quadratic line: vertex rows (even i) hold the columns i-2 .. i+2, midpoint rows i-1 .. i+1 (periodic), of slices t-1 and t
+        if (rowptr) {
+            for (int64_t r = 0; r < b->rows; ++r) rowptr[r] = burgers_p2_row_offset(b->ns, r / b->ns, r % b->ns) + index_base;
+            rowptr[b->rows] = b->nnz + index_base;
+        }
+        if (colidx)
+            for (int64_t r = 0; r < b->rows; ++r) {
+                const int64_t t = r / b->ns + 1, i = r % b->ns;
+                const int cnt = (i & 1) ? 3 : 5;
+                int64_t c[5];
+                for (int k = 0; k < cnt; ++k) c[k] = (i - cnt / 2 + k + b->ns) % b->ns;
+                std::sort(c, c + cnt);
+                int64_t* out = colidx + burgers_p2_row_offset(b->ns, t - 1, i);
+                for (int k = 0; k < cnt; ++k) { out[k] = (t - 1) * b->ns + c[k] + index_base; out[cnt + k] = t * b->ns + c[k] + index_base; }
+            }
+        return GMRF_OK;
+    }
     if (rowptr) for (int64_t r = 0; r <= b->rows; ++r) rowptr[r] = 6 * r + index_base;
     if (colidx)
         for (int64_t r = 0; r < b->rows; ++r) {
@@ -2861,11 +2930,233 @@ gmrf_status gmrf_burgers_p1_tangent(gmrf_burgers_p1* b, const double* w, double*
     BurgersP1Args a;
     a.ns = (int)b->ns; a.nt = (int)b->nt; a.dt = b->dt; a.nu = b->nu; a.w = d_w;
     a.vals = v_dev ? vals_out : b->d_vals; a.f = f_dev ? f_out : b->d_f;
-    hipLaunchKernelGGL(burgers_p1_rows, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, b->stream, a);
+    if (b->order == 2) hipLaunchKernelGGL(burgers_p2_rows, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, b->stream, a);
+    else hipLaunchKernelGGL(burgers_p1_rows, dim3((unsigned)((b->rows + 255) / 256)), dim3(256), 0, b->stream, a);
     HIPCHK(hipGetLastError());
     if (!v_dev) HIPCHK(hipMemcpyAsync(vals_out, b->d_vals, sizeof(double) * b->nnz, hipMemcpyDeviceToHost, b->stream));
     if (!f_dev) HIPCHK(hipMemcpyAsync(f_out, b->d_f, sizeof(double) * b->rows, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    return GMRF_OK;
+}
+
+// --------------------------------------------------------------------------------- shallow-water element kernels
+struct gmrf_swe_p1 {
+    int device = -1;                    // -1: patterns / quadrature points only
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t nx = 0, ny = 0, nn = 0, n = 0, cells = 0, nnz_k = 0, nnz_s = 0;
+    std::vector<int64_t> rowptr_k, col_k, rowptr_s, col_s;     // 0-based
+    int64_t *d_rowptr_k = nullptr, *d_rowptr_s = nullptr;
+    int32_t *d_col_k = nullptr, *d_col_s = nullptr;
+    double *d_dk = nullptr, *d_ds = nullptr, *d_mean = nullptr;   // |diagonals|, three meandiag scalars
+    // staging for host callers
+    double *d_hq = nullptr, *d_kv = nullptr, *d_sv = nullptr, *d_ml = nullptr, *d_g = nullptr, *d_j = nullptr, *d_mt = nullptr, *d_beta = nullptr;
+    uint8_t* d_pres = nullptr;
+};
+
+gmrf_status gmrf_shallow_water_p1_destroy(gmrf_swe_p1* w) {
+    if (!w) return GMRF_OK;
+    if (w->device >= 0) {
+        (void)hipSetDevice(w->device);
+        if (w->stream) (void)hipStreamSynchronize(w->stream);
+        free_dev(w->d_rowptr_k); free_dev(w->d_rowptr_s); free_dev(w->d_col_k); free_dev(w->d_col_s);
+        free_dev(w->d_dk); free_dev(w->d_ds); free_dev(w->d_mean);
+        free_dev(w->d_hq); free_dev(w->d_kv); free_dev(w->d_sv); free_dev(w->d_ml); free_dev(w->d_g); free_dev(w->d_j);
+        free_dev(w->d_mt); free_dev(w->d_beta); free_dev(w->d_pres);
+        if (w->own_stream) (void)hipStreamDestroy(w->stream);
+    }
+    delete w;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_shallow_water_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_swe_p1** out) {
+    if (!out || nx < 2 || ny < 2 || nx > 16384 || ny > 16384) return bad_shape("bad shallow-water mesh size");
+    auto* w = new gmrf_swe_p1();
+    w->nx = nx; w->ny = ny; w->nn = nx * ny; w->n = 3 * w->nn; w->cells = 2 * (nx - 1) * (ny - 1);
+    w->rowptr_k.assign((size_t)w->n + 1, 0); w->rowptr_s.assign((size_t)w->n + 1, 0);
+    w->col_k.reserve((size_t)w->n * 21); w->col_s.reserve((size_t)w->n * 7);
+    const int dxs[7] = {-1, 0, -1, 0, 1, 0, 1}, dys[7] = {-1, -1, 0, 0, 0, 1, 1};
+    for (int64_t node = 0; node < w->nn; ++node) {
+        const int64_t ix = node % nx, iy = node / nx;
+        for (int fa = 0; fa < 3; ++fa) {
+            const int64_t row = 3 * node + fa;
+            for (int s7 = 0; s7 < 7; ++s7) {
+                const int64_t jx = ix + dxs[s7], jy = iy + dys[s7];
+                if (jx < 0 || jy < 0 || jx >= nx || jy >= ny) continue;
+                const int64_t nj = jy * nx + jx;
+                for (int fb = 0; fb < 3; ++fb) w->col_k.push_back(3 * nj + fb);      // full field coupling (:140)
+                w->col_s.push_back(3 * nj + fa);                                     // block-diagonal coupling (:141-150)
+            }
+            w->rowptr_k[(size_t)row + 1] = (int64_t)w->col_k.size();
+            w->rowptr_s[(size_t)row + 1] = (int64_t)w->col_s.size();
+        }
+    }
+    w->nnz_k = (int64_t)w->col_k.size(); w->nnz_s = (int64_t)w->col_s.size();
+    if (device >= 0) {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device >= count) {
+            (void)hipGetLastError();
+            delete w;
+            g_last_error = "no HIP device visible (libgmrf_hip needs an MI355X / gfx950 GPU)";
+            return GMRF_ERR_NO_DEVICE;
+        }
+        w->device = device;
+        std::vector<int32_t> ck(w->col_k.begin(), w->col_k.end()), cs(w->col_s.begin(), w->col_s.end());
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess) { if (stream) w->stream = (hipStream_t)stream; else { e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking); w->own_stream = (e == hipSuccess); } }
+        if (e == hipSuccess) e = hipMalloc(&w->d_rowptr_k, sizeof(int64_t) * (w->n + 1));
+        if (e == hipSuccess) e = hipMalloc(&w->d_rowptr_s, sizeof(int64_t) * (w->n + 1));
+        if (e == hipSuccess) e = hipMalloc(&w->d_col_k, sizeof(int32_t) * w->nnz_k);
+        if (e == hipSuccess) e = hipMalloc(&w->d_col_s, sizeof(int32_t) * w->nnz_s);
+        if (e == hipSuccess) e = hipMalloc(&w->d_dk, sizeof(double) * w->n);
+        if (e == hipSuccess) e = hipMalloc(&w->d_ds, sizeof(double) * w->n);
+        if (e == hipSuccess) e = hipMalloc(&w->d_mean, sizeof(double) * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(w->d_rowptr_k, w->rowptr_k.data(), sizeof(int64_t) * (w->n + 1), hipMemcpyHostToDevice, w->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(w->d_rowptr_s, w->rowptr_s.data(), sizeof(int64_t) * (w->n + 1), hipMemcpyHostToDevice, w->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(w->d_col_k, ck.data(), sizeof(int32_t) * w->nnz_k, hipMemcpyHostToDevice, w->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(w->d_col_s, cs.data(), sizeof(int32_t) * w->nnz_s, hipMemcpyHostToDevice, w->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+        if (e != hipSuccess) {
+            g_last_error = std::string("gmrf_shallow_water_p1_create: ") + hipGetErrorString(e);
+            (void)gmrf_shallow_water_p1_destroy(w);
+            return GMRF_ERR_HIP;
+        }
+    }
+    *out = w;
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_shallow_water_p1_pattern(const gmrf_swe_p1* w, int32_t which, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
+                                          int32_t index_base) {
+    if (!w || (which != 0 && which != 1)) return bad_shape("pattern: 0 = K (coupling), 1 = S / M (block diagonal)");
+    const auto& rp = which == 0 ? w->rowptr_k : w->rowptr_s;
+    const auto& ci = which == 0 ? w->col_k : w->col_s;
+    if (nnz_out) *nnz_out = (int64_t)ci.size();
+    if (rowptr) for (int64_t i = 0; i <= w->n; ++i) rowptr[i] = rp[(size_t)i] + index_base;
+    if (colidx) for (size_t p = 0; p < ci.size(); ++p) colidx[p] = ci[p] + index_base;
+    return GMRF_OK;
+}
+
+// spatial_coordinate(cvh, qp, cell_coords) (:52) of every cell: xy[cell][q][2]
+gmrf_status gmrf_shallow_water_p1_qpoints(const gmrf_swe_p1* w, double* xy) {
+    if (!w || !xy) return bad_shape("null pointer");
+    if (is_device_ptr(xy)) return bad_shape("quadrature points are written to host memory");
+    const int64_t nx = w->nx, ny = w->ny, nlow = (nx - 1) * (ny - 1);
+    auto lin = [](int64_t i, int64_t n) { return (i == n - 1) ? 1.0 : (double)i * (1.0 / (double)(n - 1)); };
+    const double bary[3][3] = {{1.0 / 6, 1.0 / 6, 2.0 / 3}, {1.0 / 6, 2.0 / 3, 1.0 / 6}, {2.0 / 3, 1.0 / 6, 1.0 / 6}};
+    for (int up = 0; up < 2; ++up)
+        for (int64_t qy = 0; qy < ny - 1; ++qy)
+            for (int64_t qx = 0; qx < nx - 1; ++qx) {
+                const int64_t cell = up * nlow + qy * (nx - 1) + qx;
+                const int64_t nxs[3] = {qx, qx + 1, up ? qx : qx + 1}, nys[3] = {qy, up ? qy + 1 : qy, qy + 1};
+                for (int q = 0; q < 3; ++q) {
+                    xy[(cell * 3 + q) * 2 + 0] = (bary[q][0] * lin(nxs[0], nx) + bary[q][1] * lin(nxs[1], nx)) + bary[q][2] * lin(nxs[2], nx);
+                    xy[(cell * 3 + q) * 2 + 1] = (bary[q][0] * lin(nys[0], ny) + bary[q][1] * lin(nys[1], ny)) + bary[q][2] * lin(nys[2], ny);
+                }
+            }
+    return GMRF_OK;
+}
+
+static gmrf_status swe_ready(gmrf_swe_p1* w) {
+    if (!w) return bad_shape("null handle");
+    if (w->device < 0) { g_last_error = "pattern-only shallow-water handle (created with device -1)"; return GMRF_ERR_NO_DEVICE; }
+    HIPCHK(hipSetDevice(w->device));
+    return GMRF_OK;
+}
+
+static gmrf_status swe_in_bytes(gmrf_swe_p1* w, const void* p, size_t bytes, void** buf, const void** d) {
+    if (!p) { *d = nullptr; return GMRF_OK; }
+    if (is_device_ptr(p)) { *d = p; return GMRF_OK; }
+    if (!*buf) HIPCHK(hipMalloc(buf, std::max<size_t>(bytes, 8)));
+    HIPCHK(hipMemcpyAsync(*buf, p, bytes, hipMemcpyHostToDevice, w->stream));
+    *d = *buf;
+    return GMRF_OK;
+}
+static gmrf_status swe_in(gmrf_swe_p1* w, const double* p, int64_t count, double** buf, const double** d) {
+    return swe_in_bytes(w, p, sizeof(double) * (size_t)count, (void**)buf, (const void**)d);
+}
+static gmrf_status swe_in(gmrf_swe_p1* w, const uint8_t* p, int64_t count, uint8_t** buf, const uint8_t** d) {
+    return swe_in_bytes(w, p, (size_t)count, (void**)buf, (const void**)d);
+}
+
+static gmrf_status swe_out(gmrf_swe_p1* w, double* user, int64_t count, double** buf, double** d) {
+    if (is_device_ptr(user)) { *d = user; return GMRF_OK; }
+    if (!*buf) HIPCHK(hipMalloc(buf, sizeof(double) * std::max<int64_t>(count, 1)));
+    *d = *buf;
+    return GMRF_OK;
+}
+
+// meandiag of a vector of |diagonal| values + apply! on CSR values
+static gmrf_status swe_constrain(gmrf_swe_p1* w, const int64_t* d_rowptr, const int32_t* d_col, const uint8_t* d_pres, const double* d_absdiag,
+                                 double* d_mean, double* d_vals) {
+    hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, w->stream, d_absdiag, w->n, d_mean);
+    hipLaunchKernelGGL(csr_apply_constraints, dim3((unsigned)((w->n + 255) / 256)), dim3(256), 0, w->stream, d_rowptr, d_col, d_pres, w->n,
+                       d_mean, d_vals);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_shallow_water_p1_assemble(gmrf_swe_p1* w, const double* H_q, double k, double f, double g, const uint8_t* prescribed,
+                                           double* K_vals, double* M_lumped, double* S_vals) {
+    GCHK(swe_ready(w));
+    if (!H_q || !K_vals || !M_lumped || !S_vals) return bad_shape("null pointer");
+    const double* d_hq; const uint8_t* d_pres;
+    GCHK(swe_in(w, H_q, w->cells * 3, &w->d_hq, &d_hq));
+    GCHK(swe_in(w, prescribed, w->n, &w->d_pres, &d_pres));
+    double *d_kv, *d_sv, *d_ml;
+    GCHK(swe_out(w, K_vals, w->nnz_k, &w->d_kv, &d_kv));
+    GCHK(swe_out(w, S_vals, w->nnz_s, &w->d_sv, &d_sv));
+    GCHK(swe_out(w, M_lumped, w->n, &w->d_ml, &d_ml));
+    SweP1Args a;
+    a.nx = (int)w->nx; a.ny = (int)w->ny; a.Hq = d_hq; a.k = k; a.f = f; a.g = g;
+    a.rowptr_k = w->d_rowptr_k; a.rowptr_s = w->d_rowptr_s; a.kv = d_kv; a.sv = d_sv; a.ml = d_ml; a.dk = w->d_dk; a.ds = w->d_ds;
+    hipLaunchKernelGGL(swe_p1_rows, dim3((unsigned)((w->n + 255) / 256)), dim3(256), 0, w->stream, a);
+    HIPCHK(hipGetLastError());
+    if (d_pres) {
+        // apply!(K, ..), apply!(M, ..), apply!(S, ..)  (:119-121)
+        GCHK(swe_constrain(w, w->d_rowptr_k, w->d_col_k, d_pres, w->d_dk, w->d_mean, d_kv));
+        GCHK(swe_constrain(w, w->d_rowptr_s, w->d_col_s, d_pres, w->d_ds, w->d_mean + 1, d_sv));
+        hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, w->stream, d_ml, w->n, w->d_mean + 2);      // M >= 0: |M_ii| = M_ii
+        hipLaunchKernelGGL(vec_set_prescribed, dim3((unsigned)((w->n + 255) / 256)), dim3(256), 0, w->stream, d_pres, w->n,
+                           (const double*)(w->d_mean + 2), 0.0, d_ml);
+        HIPCHK(hipGetLastError());
+    }
+    if (d_kv != K_vals) HIPCHK(hipMemcpyAsync(K_vals, d_kv, sizeof(double) * w->nnz_k, hipMemcpyDeviceToHost, w->stream));
+    if (d_sv != S_vals) HIPCHK(hipMemcpyAsync(S_vals, d_sv, sizeof(double) * w->nnz_s, hipMemcpyDeviceToHost, w->stream));
+    if (d_ml != M_lumped) HIPCHK(hipMemcpyAsync(M_lumped, d_ml, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
+    return GMRF_OK;
+}
+
+gmrf_status gmrf_shallow_water_p1_operators(gmrf_swe_p1* w, const double* K_vals, const double* M_lumped, const double* S_vals,
+                                            const uint8_t* prescribed, double kappa_matern, double tau, double dt, double* G_vals,
+                                            double* J_vals, double* M_tilde, double* beta) {
+    GCHK(swe_ready(w));
+    if (!K_vals || !M_lumped || !S_vals || !G_vals || !J_vals || !M_tilde || !beta) return bad_shape("null pointer");
+    if (!(kappa_matern > 0.0) || !(dt > 0.0)) return bad_shape("kappa_matern and dt must be positive");
+    SweOpArgs a;
+    const uint8_t* d_pres;
+    // (inputs that live on the host are staged into the buffers the assemble call uses for its outputs)
+    GCHK(swe_in(w, K_vals, w->nnz_k, &w->d_kv, &a.kv));
+    GCHK(swe_in(w, S_vals, w->nnz_s, &w->d_sv, &a.sv));
+    GCHK(swe_in(w, M_lumped, w->n, &w->d_ml, &a.ml));
+    GCHK(swe_in(w, prescribed, w->n, &w->d_pres, &d_pres));
+    GCHK(swe_out(w, G_vals, w->nnz_k, &w->d_g, &a.Gd));
+    GCHK(swe_out(w, J_vals, w->nnz_s, &w->d_j, &a.J));
+    GCHK(swe_out(w, M_tilde, w->n, &w->d_mt, &a.Mt));
+    GCHK(swe_out(w, beta, w->n, &w->d_beta, &a.beta));
+    a.n = w->n; a.rowptr_k = w->d_rowptr_k; a.col_k = w->d_col_k; a.rowptr_s = w->d_rowptr_s; a.col_s = w->d_col_s;
+    a.pres = d_pres; a.kappa2 = kappa_matern * kappa_matern; a.tau = tau; a.dt = dt; a.dg = w->d_dk;
+    const double nu = 2.0;                                     // :180
+    a.sqrt_ratio = std::sqrt(std::tgamma(nu) / (std::tgamma(nu + 1.0) * (4.0 * M_PI) * std::pow(kappa_matern, 2.0 * nu)));
+    hipLaunchKernelGGL(swe_p1_operators, dim3((unsigned)((w->n + 255) / 256)), dim3(256), 0, w->stream, a);
+    HIPCHK(hipGetLastError());
+    if (d_pres) GCHK(swe_constrain(w, w->d_rowptr_k, w->d_col_k, d_pres, w->d_dk, w->d_mean + 3, a.Gd));      // apply!(S_tmp, f, ch) :213
+    if (a.Gd != G_vals) HIPCHK(hipMemcpyAsync(G_vals, a.Gd, sizeof(double) * w->nnz_k, hipMemcpyDeviceToHost, w->stream));
+    if (a.J != J_vals) HIPCHK(hipMemcpyAsync(J_vals, a.J, sizeof(double) * w->nnz_s, hipMemcpyDeviceToHost, w->stream));
+    if (a.Mt != M_tilde) HIPCHK(hipMemcpyAsync(M_tilde, a.Mt, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+    if (a.beta != beta) HIPCHK(hipMemcpyAsync(beta, a.beta, sizeof(double) * w->n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(hipStreamSynchronize(w->stream));
     return GMRF_OK;
 }
 

@@ -980,6 +980,126 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
 }
 constexpr size_t POTRF_DIAG128_LDS = (3 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
 
+// The same block with TWO LDS tiles (77 KB: two GEMM workgroups of another stream fit beside it instead of one): S10 goes
+// straight from L2 into registers as the MFMA A operand of L10 = S10 X00^T (as potrf_panel did), L10 takes the place of
+// L00 once that is stored, and W = L10 X00 waits in registers (16 doubles per thread) across the second tile
+// factorisation before it takes the place of L11.  Same operations in the same order as potrf_diag128: bitwise equal.
+__global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
+    sa.S += (int64_t)blockIdx.y * sa.pS;
+    sa.L += (int64_t)blockIdx.y * sa.pL;
+    sa.X += (int64_t)blockIdx.y * sa.pX;
+    sa.blk += (int)blockIdx.y * sa.blk_per_problem;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ts = smem;
+    double* Xs = Ts + TILE_ELEMS;
+    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
+    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = sa.ld;
+    const int64_t o0 = (int64_t)sa.j * 64, o1 = o0 + 64;
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    v4d cpre[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            cpre[Jb][q] = (Jb <= wave) ? sa.S[(o1 + 16 * wave + lq + 4 * q) * ld + o1 + 16 * Jb + li] : 0.0;
+    // S10 as the A operand of this wave's 16-row strip: two consecutive k per 8-wide k group
+    v2d s10[8];
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg)
+        s10[kg] = *reinterpret_cast<const v2d*>(sa.S + (o1 + 16 * wave + li) * ld + o0 + 8 * kg + 2 * lq);
+    bool bad = false;
+    tile_g2s(sa.S + o0 * ld + o0, ld, Ts, tid);
+    SideLoad none;
+    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+    __syncthreads();
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+    tile_s2g(Ts, sa.L + o0 * ld + o0, ld, tid);
+    tile_s2g(Xs, sa.X + o0 * ld + o0, ld, tid);
+    // ---- L10 = S10 X00^T
+    v4d lr[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) lr[Jb] = zero;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+#pragma unroll
+        for (int Jb = kg / 2; Jb < 4; ++Jb) {
+            const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(s10[kg].x, xv.x, lr[Jb], 0, 0, 0);
+            lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(s10[kg].y, xv.y, lr[Jb], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                   // L00 has left Ts (tile_s2g reads complete before the stores below)
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) store_d16(Ts + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+    __syncthreads();
+    tile_s2g(Ts, sa.L + o1 * ld + o0, ld, tid);
+    // ---- S11 - L10 L10^T (lower 16 x 16 blocks) and W = L10 X00
+    v4d pacc[4], wv[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) { pacc[Jb] = zero; wv[Jb] = zero; }
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(Ts + (16 * wave + li) * TLD + k);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb <= wave) {
+                const v2d bv = *reinterpret_cast<const v2d*>(Ts + (16 * Jb + li) * TLD + k);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
+            }
+            if (kg >= 2 * Jb) {
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Xs[k * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Xs[(k + 1) * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();                                   // L10 (Ts) and X00 (Xs) have been read by everyone
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) {
+        if (Jb <= wave) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ts[(16 * wave + lq + 4 * q) * TLD + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
+        }
+    }
+    __syncthreads();
+    tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+    if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
+    tile_s2g(Ts, sa.L + o1 * ld + o1, ld, tid);
+    tile_s2g(Xs, sa.X + o1 * ld + o1, ld, tid);
+    __syncthreads();                                   // L11 has left Ts
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) store_d16(Ts + (16 * wave) * TLD + 16 * Jb, TLD, wv[Jb], li, lq);     // W takes its place
+    __syncthreads();
+    // ---- X10 = -X11 W
+    v4d xr[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) xr[Jb] = zero;
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        if (kg < 2 * wave + 2) {
+            const int k = 8 * kg + 2 * lq;
+            const v2d av = *reinterpret_cast<const v2d*>(Xs + (16 * wave + li) * TLD + k);
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) {
+                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Ts[k * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
+                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Ts[(k + 1) * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sa.X[(o1 + 16 * wave + lq + 4 * q) * ld + o0 + 16 * Jb + li] = -xr[Jb][q];
+}
+constexpr size_t POTRF_DIAG128_SLIM_LDS = (2 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+
+
 constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
 
 // Stand-alone tile kernel (tests): S (ld 64) -> L, X.

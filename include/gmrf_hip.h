@@ -305,7 +305,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * one problem assembles Linv by recursive doubling after the panel steps instead of row by row inside them; bit 8:
  * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain; bit 10: batches
  * factor a block by 64-column steps (tile, potrf_panel, potrf_update: the round-2 path) instead of 128-column diagonal
- * blocks with GEMM panels (comparison). */
+ * blocks with GEMM panels (comparison); bit 11: the rows below a 256-column panel meet its two 128 x 128 inverses one after the
+ * other (three K = 128 products per panel) instead of the panel's 256 x 256 inverse in one K = 256 product (comparison). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 
@@ -391,10 +392,44 @@ gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, 
 typedef struct gmrf_burgers_p1 gmrf_burgers_p1;
 gmrf_status gmrf_burgers_p1_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu,
                                    gmrf_burgers_p1** out);
+/* The same on the QUADRATIC periodic line, the element the reference's Burgers scripts run on
+ * (periodic_unit_interval_discretization, /root/reference/src/utils.jl:42-49: QuadraticLine cells, Lagrange{RefLine,2},
+ * 3-point Gauss rule): ns = 2 N_x dofs numbered by position, even = cell boundaries, odd = midpoints; vertex rows of J hold
+ * 10 entries (columns i-2 .. i+2 of slices t-1 and t), midpoint rows 6.  The handle is a gmrf_burgers_p1: _pattern,
+ * _tangent and _destroy serve both element orders. */
+gmrf_status gmrf_burgers_p2_create(int32_t device, void* stream, int64_t ns, int64_t nt, double dt, double nu,
+                                   gmrf_burgers_p1** out);
 gmrf_status gmrf_burgers_p1_destroy(gmrf_burgers_p1* b);
 gmrf_status gmrf_burgers_p1_pattern(const gmrf_burgers_p1* b, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
                                     int32_t index_base);
 gmrf_status gmrf_burgers_p1_tangent(gmrf_burgers_p1* b, const double* w, double* vals_out, double* f_out);
+
+/* Linear shallow-water SPDE (FEM block assembly, third piece): the element loops of `assemble_system!`,
+ * /root/reference/src/spdes/shallow_water.jl:17-122 -- coupling matrix K (h-u, h-v: -H grad(phi_i) phi_j; u-h, v-h:
+ * -g grad(phi_i) phi_j; u-u, v-v: k phi_i phi_j; u-v / v-u: -+ f phi_i phi_j), element-lumped mass M (`lump_matrix`, :116),
+ * stiffness S, `apply!` of the constraint handler to all three (:119-121) -- and the per-step operators `discretize` forms
+ * from them (:170-217), on the structured P1 triangle mesh of the Darcy configs (nx x ny nodes, x fastest, quads cut by the
+ * diagonal n00 - n11; cell numbering: all lower triangles (n00, n10, n11), then all upper (n00, n11, n01)) with
+ *   dof = 3 * node + field, fields (h, u, v) = (0, 1, 2)        (Ferrite numbers dofs in cell-visit order: a permutation)
+ *   the symmetric 3-point quadrature rule of order 2; H enters through H_q[cell][q] = H(x_q), x_q from _qpoints.
+ * pattern 0: K, 3 nn rows with the full field coupling over the 7-point node stencil (create_sparsity_pattern(dh, ch),
+ * :140; explicit zeros kept); pattern 1: S (and M~ / the Matern factor), block-diagonal coupling (:141-150).  M is lumped and
+ * comes back as a vector.  prescribed: 3 nn bytes (non-zero = dof of the constraint handler) or NULL.
+ * _operators, for one time step dt: G_vals = (M~ + dt K) with the constraints applied (K's pattern, :212-217), J_vals =
+ * sqrt(ratio) M~^-1/2 (kappa^2 M~ + G) in S's pattern -- the transposed square root of the initial precision, Q_matern = J'J
+ * (:178-189; feed J to gmrf_assemble_precision with a zero Q), M_tilde (:172-174), beta(dt) = sqrt(dt) tau (1e-2 on prescribed
+ * dofs, :198-211).  Values: host or device pointers; device -1: patterns and quadrature points only. */
+typedef struct gmrf_swe_p1 gmrf_swe_p1;
+gmrf_status gmrf_shallow_water_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_swe_p1** out);
+gmrf_status gmrf_shallow_water_p1_destroy(gmrf_swe_p1* w);
+gmrf_status gmrf_shallow_water_p1_pattern(const gmrf_swe_p1* w, int32_t which, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
+                                          int32_t index_base);
+gmrf_status gmrf_shallow_water_p1_qpoints(const gmrf_swe_p1* w, double* xy);   /* xy: [cells][3][2] doubles in host memory */
+gmrf_status gmrf_shallow_water_p1_assemble(gmrf_swe_p1* w, const double* H_q, double k, double f, double g, const uint8_t* prescribed,
+                                           double* K_vals, double* M_lumped, double* S_vals);
+gmrf_status gmrf_shallow_water_p1_operators(gmrf_swe_p1* w, const double* K_vals, const double* M_lumped, const double* S_vals,
+                                            const uint8_t* prescribed, double kappa_matern, double tau, double dt, double* G_vals,
+                                            double* J_vals, double* M_tilde, double* beta);
 
 /* ------------------------------------------------------------------ test hooks
  * Direct access to the dense device kernels for the parity tests (row-major operands on

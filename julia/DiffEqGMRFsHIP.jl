@@ -421,10 +421,15 @@ mutable struct BurgersP1Tangent
     rows::Int
 end
 
-function BurgersP1Tangent(ns::Integer, nt::Integer, dt::Real, nu::Real; device::Integer = 0)
+function BurgersP1Tangent(ns::Integer, nt::Integer, dt::Real, nu::Real; device::Integer = 0, order::Integer = 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:gmrf_burgers_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ref{Ptr{Cvoid}}),
-                device, C_NULL, ns, nt, Float64(dt), Float64(nu), h))
+    if order == 2       # the quadratic periodic line of periodic_unit_interval_discretization (src/utils.jl:42-49): ns = 2 N_x dofs by position
+        check(ccall((:gmrf_burgers_p2_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ref{Ptr{Cvoid}}),
+                    device, C_NULL, ns, nt, Float64(dt), Float64(nu), h))
+    else
+        check(ccall((:gmrf_burgers_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Float64, Float64, Ref{Ptr{Cvoid}}),
+                    device, C_NULL, ns, nt, Float64(dt), Float64(nu), h))
+    end
     nnz_out = Ref{Int64}(0)
     check(ccall((:gmrf_burgers_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, C_NULL, C_NULL, 1))
     rows = (nt - 1) * ns
@@ -440,6 +445,57 @@ function tangent!(vals::Vector{Float64}, f::Vector{Float64}, b::BurgersP1Tangent
     GC.@preserve w vals f check(ccall((:gmrf_burgers_p1_tangent, libgmrf), Int32,
         (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), b.handle, w, vals, f))
     return vals, f
+end
+
+# Linear shallow-water SPDE (src/spdes/shallow_water.jl): element kernels of assemble_system! (:17-122) and the per-step
+# operators of discretize (:170-217) on the structured P1 triangle mesh; dof = 3 * node + field, fields (h, u, v)
+mutable struct ShallowWaterP1
+    handle::Ptr{Cvoid}
+    n::Int                                       # 3 nx ny dofs
+    pattern_K::SparseMatrixCSC{Float64,Int}      # TRANSPOSE patterns (CSC of A' = CSR of A), values 1.0: `nzval` order of the value arrays
+    pattern_S::SparseMatrixCSC{Float64,Int}
+    qpoints::Array{Float64,3}                    # (2, 3, cells): x / y of quadrature point q of a cell -- evaluate H there
+end
+
+function ShallowWaterP1(nx::Integer, ny::Integer; device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:gmrf_shallow_water_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), device, C_NULL, nx, ny, h))
+    n = 3 * nx * ny
+    pats = SparseMatrixCSC{Float64,Int}[]
+    for which in (0, 1)
+        nnz_out = Ref{Int64}(0)
+        check(ccall((:gmrf_shallow_water_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], which, nnz_out, C_NULL, C_NULL, 1))
+        rowptr = Vector{Int64}(undef, n + 1); colidx = Vector{Int64}(undef, nnz_out[])
+        check(ccall((:gmrf_shallow_water_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Int32, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], which, nnz_out, rowptr, colidx, 1))
+        push!(pats, SparseMatrixCSC(n, n, rowptr, colidx, ones(nnz_out[])))
+    end
+    cells = 2 * (nx - 1) * (ny - 1)
+    qp = Array{Float64,3}(undef, 2, 3, cells)
+    check(ccall((:gmrf_shallow_water_p1_qpoints, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Float64}), h[], qp))
+    w = ShallowWaterP1(h[], n, pats[1], pats[2], qp)
+    finalizer(x -> ccall((:gmrf_shallow_water_p1_destroy, libgmrf), Int32, (Ptr{Cvoid},), x.handle), w)
+    return w
+end
+
+"`assemble_system!`: H_q[q, cell] = H(qpoints[:, q, cell]); prescribed: the constraint handler's dofs as a byte mask (or nothing).  Returns (K values, lumped M, S values)."
+function assemble_system(w::ShallowWaterP1, H_q::Matrix{Float64}; k::Real = 0.0, f::Real = 0.0, g::Real = 9.81, prescribed::Union{Nothing,Vector{UInt8}} = nothing)
+    kv = Vector{Float64}(undef, nnz(w.pattern_K)); ml = Vector{Float64}(undef, w.n); sv = Vector{Float64}(undef, nnz(w.pattern_S))
+    pm = prescribed === nothing ? Ptr{UInt8}(C_NULL) : pointer(prescribed)
+    GC.@preserve H_q prescribed kv ml sv check(ccall((:gmrf_shallow_water_p1_assemble, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Float64, Float64, Float64, Ptr{UInt8}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        w.handle, H_q, Float64(k), Float64(f), Float64(g), pm, kv, ml, sv))
+    return kv, ml, sv
+end
+
+"The operators `discretize` forms for one time step dt: (G(dt) values in K's pattern, J values in S's pattern with Q_matern = J'J, M~, beta(dt))."
+function step_operators(w::ShallowWaterP1, kv::Vector{Float64}, ml::Vector{Float64}, sv::Vector{Float64}; prescribed::Union{Nothing,Vector{UInt8}} = nothing,
+                        kappa_matern::Real = 1.0, tau::Real = 1.0, dt::Real = 1.0)
+    gv = similar(kv); jv = similar(sv); mt = similar(ml); be = similar(ml)
+    pm = prescribed === nothing ? Ptr{UInt8}(C_NULL) : pointer(prescribed)
+    GC.@preserve kv ml sv prescribed gv jv mt be check(ccall((:gmrf_shallow_water_p1_operators, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{UInt8}, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        w.handle, kv, ml, sv, pm, Float64(kappa_matern), Float64(tau), Float64(dt), gv, jv, mt, be))
+    return gv, jv, mt, be
 end
 
 # ------------------------------------------------------------------------------------------ multi-GPU

@@ -376,60 +376,91 @@ def _p1_line_cellvalues(h: float):
     return [(jac * wq[q], (0.5 * (1.0 - xi[q]), 0.5 * (1.0 + xi[q])), dN) for q in range(3)]
 
 
-def assemble_burgers_advection_matrix(ns: int, cur_weights):
+def _p2_line_cellvalues(h: float):
+    """CellValues of one cell of the uniform QUADRATIC line (`generate_grid(QuadraticLine, ...)`, `Lagrange{RefLine,2}`,
+    `QuadratureRule{RefLine}(3)`: /root/reference/src/utils.jl:42-49): local dofs (left, right, middle) with
+    N = (xi (xi - 1) / 2, xi (xi + 1) / 2, 1 - xi^2) on xi in [-1, 1]."""
+    xi = (-np.sqrt(3.0 / 5.0), 0.0, np.sqrt(3.0 / 5.0))
+    wq = (5.0 / 9.0, 8.0 / 9.0, 5.0 / 9.0)
+    jac = 0.5 * h
+    out = []
+    for q in range(3):
+        x = xi[q]
+        N = (0.5 * x * (x - 1.0), 0.5 * x * (x + 1.0), 1.0 - x * x)
+        dN = ((x - 0.5) / jac, (x + 0.5) / jac, (-2.0 * x) / jac)
+        out.append((jac * wq[q], N, dN))
+    return out
+
+
+def _line_cells(ns: int, order: int):
+    """(cell values, list of the cells' dof tuples) of the periodic line with ns dofs on [0,1).  order 1: ns cells
+    (e, e + 1 mod ns).  order 2: ns / 2 cells with the dofs (2 e, 2 e + 2 mod ns, 2 e + 1) in Ferrite's local order
+    (left, right, middle); the dofs are numbered by position (x_i = i / ns), the periodic constraint of the
+    reference's mesh (get_periodic_constraint, src/utils.jl:5-18) is the wrap-around."""
+    if order == 1:
+        return _p1_line_cellvalues(1.0 / ns), [(e, (e + 1) % ns) for e in range(ns)]
+    if order != 2 or ns % 2:
+        raise ValueError("order 1, or order 2 with an even number of dofs")
+    nc = ns // 2
+    return _p2_line_cellvalues(1.0 / nc), [(2 * e, (2 * e + 2) % ns, 2 * e + 1) for e in range(nc)]
+
+
+def assemble_burgers_advection_matrix(ns: int, cur_weights, order: int = 1):
     """Parity oracle of /root/reference/src/problems/burgers.jl:5-59 (`assemble_burgers_advection_matrix`) on the
-    periodic P1 line with ns nodes on [0,1): cell e has the dofs (e, e + 1 mod ns) -- the periodic constraint of
-    the reference's mesh condensed into the wrap-around, so there are no prescribed dofs left to zero (:53-57).
-    Returns (G as CSR, v).  Line-by-line: the cell loop :22-51, quadrature loop :30-50."""
-    cv = _p1_line_cellvalues(1.0 / ns)
+    periodic line with ns dofs on [0,1) (P1: cell e has the dofs (e, e + 1 mod ns); P2: see _line_cells) -- the
+    periodic constraint of the reference's mesh condensed into the wrap-around, so there are no prescribed dofs
+    left to zero (:53-57).  Returns (G as CSR, v).  Line-by-line: the cell loop :22-51, quadrature loop :30-50."""
+    cv, cells = _line_cells(ns, order)
+    nb = order + 1
     G = sp.lil_matrix((ns, ns))
     v = np.zeros(ns)
-    for e in range(ns):                                        # CellIterator(dh)
-        dofs = (e, (e + 1) % ns)
-        Ge = np.zeros((2, 2)); ve = np.zeros(2)
-        w = (cur_weights[dofs[0]], cur_weights[dofs[1]])       # :28
+    for dofs in cells:                                         # CellIterator(dh)
+        Ge = np.zeros((nb, nb)); ve = np.zeros(nb)
+        w = [cur_weights[d] for d in dofs]                     # :28
         for dOm, N, dN in cv:                                  # :30
-            cur_u = N[0] * w[0] + N[1] * w[1]                  # :34 function_value
+            cur_u = 0.0                                        # :34 function_value
+            for k in range(nb):
+                cur_u += N[k] * w[k]
             grad_u = 0.0                                       # :36-39
-            for k in range(2):
+            for k in range(nb):
                 grad_u += dN[k] * w[k]
-            for i in range(2):                                 # :40
-                for j in range(2):                             # :43
+            for i in range(nb):                                # :40
+                for j in range(nb):                            # :43
                     Ge[i, j] += N[i] * (N[j] * grad_u + cur_u * dN[j]) * dOm        # :46
                 ve[i] += N[i] * cur_u * grad_u * dOm           # :48
-        for i in range(2):                                     # :51 assemble!
-            for j in range(2):
+        for i in range(nb):                                    # :51 assemble!
+            for j in range(nb):
                 G[dofs[i], dofs[j]] += Ge[i, j]
             v[dofs[i]] += ve[i]
     return G.tocsr(), v
 
 
-def assemble_burgers_mass_diffusion_matrices(ns: int):
+def assemble_burgers_mass_diffusion_matrices(ns: int, order: int = 1):
     """/root/reference/src/problems/burgers.jl:60-98 on the same mesh (consistent mass, lumping = false):
     Me[i][j] = sum_q N_i N_j dOmega, Ge[i][j] = sum_q grad N_i grad N_j dOmega per cell (:80-83), assembled."""
-    cv = _p1_line_cellvalues(1.0 / ns)
+    cv, cells = _line_cells(ns, order)
+    nb = order + 1
     M = sp.lil_matrix((ns, ns)); G = sp.lil_matrix((ns, ns))
-    for e in range(ns):
-        dofs = (e, (e + 1) % ns)
-        Me = np.zeros((2, 2)); Ge = np.zeros((2, 2))
+    for dofs in cells:
+        Me = np.zeros((nb, nb)); Ge = np.zeros((nb, nb))
         for dOm, N, dN in cv:
-            for i in range(2):
-                for j in range(2):
+            for i in range(nb):
+                for j in range(nb):
                     Me[i, j] += N[i] * N[j] * dOm
                     Ge[i, j] += dN[i] * dN[j] * dOm
-        for i in range(2):
-            for j in range(2):
+        for i in range(nb):
+            for j in range(nb):
                 M[dofs[i], dofs[j]] += Me[i, j]
                 G[dofs[i], dofs[j]] += Ge[i, j]
     return M.tocsr(), G.tocsr()
 
 
-def burgers_f_and_J(ns: int, nt: int, dt: float, nu: float, w):
+def burgers_f_and_J(ns: int, nt: int, dt: float, nu: float, w, order: int = 1):
     """`f_and_J(w)` of /root/reference/scripts/burgers/solve_burgers_gmrf-fem.jl:118-149:
     J_static = M_{t+1} - M_t + dt nu G_{t+1} (:123-130), per slice t = 2 .. nt the advection tangent and residual
     (:132-144), f = J_static w + dt f_adv, J = J_static + dt J_adv (:146-149).  Returns (f, J as CSR with sorted
     indices, (nt - 1) ns x nt ns)."""
-    M, G = assemble_burgers_mass_diffusion_matrices(ns)
+    M, G = assemble_burgers_mass_diffusion_matrices(ns, order)
     Z = sp.csr_matrix((ns, ns))
 
     def s2st(A, t):                                            # spatial_to_spatiotemporal(A, t, nt), t 1-based
@@ -442,10 +473,146 @@ def burgers_f_and_J(ns: int, nt: int, dt: float, nu: float, w):
     Js, vs = [], []
     w = np.asarray(w, dtype=np.float64)
     for t in range(2, nt + 1):
-        Gt, vt = assemble_burgers_advection_matrix(ns, w[(t - 1) * ns:t * ns])
+        Gt, vt = assemble_burgers_advection_matrix(ns, w[(t - 1) * ns:t * ns], order)
         Js.append(s2st(Gt, t)); vs.append(vt)
     J_adv = sp.vstack(Js, format="csr"); f_adv = np.concatenate(vs)
     f = J_static @ w + dt * f_adv
     J = (J_static + dt * J_adv).tocsr()
     J.sort_indices()
     return f, J
+
+
+# ------------------------------------------------------------------------------------------------
+# Linear shallow-water SPDE: element loops and per-step operators of /root/reference/src/spdes/shallow_water.jl
+# on the structured P1 triangle mesh that stands in for the reference's Gmsh mesh.
+# Ferrite is absent, so two conventions are this restatement's own (both stated to the device kernel too):
+#   * dof numbering: node-major, dof = 3 * node + field with fields (h, u, v) = (0, 1, 2) -- Ferrite numbers dofs
+#     in cell-visit order; the operators are the same up to that permutation;
+#   * quadrature: the symmetric 3-point rule of QuadratureRule{2,RefTetrahedron}(2) (weights 1/6 on the reference
+#     triangle, so dOmega = |T| / 3); point q carries the barycentric weight 2/3 on cell vertex 2 - q and 1/6 on
+#     the other two.  The rule is symmetric: the assembled matrices depend on the order only through rounding.
+
+def _p1_triangle_cells(nx: int, ny: int):
+    """Cells of the structured mesh (all lower triangles (n00, n10, n11) first, then all upper (n00, n11, n01)),
+    their P1 gradient coefficients and areas: grad phi_v = (b_v, c_v) / (2 |T|) * sign."""
+    xs, ys = np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny)
+    qx, qy = np.meshgrid(np.arange(nx - 1), np.arange(ny - 1), indexing="xy")
+    n00 = (qy * nx + qx).ravel(); n10 = n00 + 1; n01 = n00 + nx; n11 = n01 + 1
+    cells = np.concatenate([np.stack([n00, n10, n11], axis=1), np.stack([n00, n11, n01], axis=1)], axis=0)
+    X, Y = xs[cells % nx], ys[cells // nx]
+    b = np.stack([Y[:, 1] - Y[:, 2], Y[:, 2] - Y[:, 0], Y[:, 0] - Y[:, 1]], axis=1)
+    c = np.stack([X[:, 2] - X[:, 1], X[:, 0] - X[:, 2], X[:, 1] - X[:, 0]], axis=1)
+    area2 = X[:, 0] * b[:, 0] + X[:, 1] * b[:, 1] + X[:, 2] * b[:, 2]          # signed 2 |T|
+    return cells, X, Y, b / area2[:, None], c / area2[:, None], 0.5 * np.abs(area2)
+
+
+SWE_Q_BARY = np.array([[1 / 6, 1 / 6, 2 / 3], [1 / 6, 2 / 3, 1 / 6], [2 / 3, 1 / 6, 1 / 6]])   # phi_v at point q: [q][v]
+
+
+def shallow_water_qpoints(nx: int, ny: int) -> np.ndarray:
+    """spatial_coordinate(cvh, qp, cell_coords) (:52) of every cell: (cells, 3, 2)."""
+    _, X, Y, _, _, _ = _p1_triangle_cells(nx, ny)
+    xq = (SWE_Q_BARY[None, :, 0] * X[:, None, 0] + SWE_Q_BARY[None, :, 1] * X[:, None, 1]) + SWE_Q_BARY[None, :, 2] * X[:, None, 2]
+    yq = (SWE_Q_BARY[None, :, 0] * Y[:, None, 0] + SWE_Q_BARY[None, :, 1] * Y[:, None, 1]) + SWE_Q_BARY[None, :, 2] * Y[:, None, 2]
+    return np.stack([xq, yq], axis=2)
+
+
+def _apply_constraints(A: sp.spmatrix, prescribed) -> sp.csr_matrix:
+    """Ferrite `apply!(A, zeros(n), ch)` for homogeneous data (:119-121): constrained rows and columns zeroed, their
+    diagonal set to meandiag(A) = sum |A_ii| / n."""
+    A = sp.coo_matrix(A)
+    n = A.shape[0]
+    if prescribed is None or not np.any(prescribed):
+        out = sp.csr_matrix(A); out.sort_indices(); return out
+    pres = np.asarray(prescribed, dtype=bool)
+    m = np.abs(sp.csr_matrix(A).diagonal()).sum() / n
+    data = A.data.copy()
+    hit = pres[A.row] | pres[A.col]
+    data[hit] = 0.0
+    data[hit & (A.row == A.col)] = m
+    out = sp.csr_matrix((data, (A.row, A.col)), shape=A.shape)
+    out.sort_indices()
+    return out
+
+
+def assemble_shallow_water_system(nx: int, ny: int, H_q, k: float, f: float, g: float, prescribed=None):
+    """`assemble_system!`, /root/reference/src/spdes/shallow_water.jl:17-122.  H_q[cell, q] = H(x_q) (:53).
+    Per cell and quadrature point (:51-111), with I = 3 * vertex + field:
+        h-h  me += phi_i phi_j dO            se += grad phi_i . grad phi_j dO                      :68-71
+        h-u  ke += -H dx(phi_i) phi_j dO     h-v  ke += -H dy(phi_i) phi_j dO                      :73-79
+        u-h  ke += -g dx(phi_i) phi_j dO     v-h  ke += -g dy(phi_i) phi_j dO                      :82-84, :99-101
+        u-u / v-v  me += phi_i phi_j dO, ke += k phi_i phi_j dO, se += grad . grad dO              :86-91, :107-112
+        u-v  ke += -f phi_i phi_j dO         v-u  ke += f phi_i phi_j dO                           :93-95, :103-105
+    then `assemble!` of ke, of the element-lumped me (`lump_matrix(me, ip)`, :116: row sums on the diagonal for
+    the linear Lagrange interpolation) and of se (:114-118), and `apply!` of the constraint handler to all three
+    (:119-121).  Returns (K: CSR 3 nn x 3 nn with the full field coupling over the 7-point node stencil, explicit
+    zeros kept, like create_sparsity_pattern(dh, ch) :140; M: lumped mass as a vector (its off-diagonal pattern
+    entries are zeros); S: CSR with the block-diagonal coupling of :141-150)."""
+    cells, X, Y, gx, gy, area = _p1_triangle_cells(nx, ny)
+    nc, nn = cells.shape[0], nx * ny
+    H_q = np.asarray(H_q, dtype=np.float64).reshape(nc, 3)
+    dO = area / 3.0
+    ke = np.zeros((nc, 9, 9)); me = np.zeros((nc, 9, 9)); se = np.zeros((nc, 9, 9))
+    rh, ru, rv = 0, 1, 2                                          # field of local dof I = 3 * vertex + field
+    for qp in range(3):                                           # :51
+        phi = SWE_Q_BARY[qp]                                      # shape_value: the same for the three fields (:56-66)
+        Hv = H_q[:, qp]
+        for i in range(3):
+            for j in range(3):
+                pp = phi[i] * phi[j] * dO
+                gg = (gx[:, i] * gx[:, j] + gy[:, i] * gy[:, j]) * dO
+                Ih, Iu, Iv = 3 * i + rh, 3 * i + ru, 3 * i + rv
+                Jh, Ju, Jv = 3 * j + rh, 3 * j + ru, 3 * j + rv
+                me[:, Ih, Jh] += pp; se[:, Ih, Jh] += gg                                  # h - h
+                ke[:, Ih, Ju] += -Hv * gx[:, i] * phi[j] * dO                             # h - u
+                ke[:, Ih, Jv] += -Hv * gy[:, i] * phi[j] * dO                             # h - v
+                ke[:, Iu, Jh] += -g * gx[:, i] * phi[j] * dO                              # u - h
+                me[:, Iu, Ju] += pp; ke[:, Iu, Ju] += k * pp; se[:, Iu, Ju] += gg         # u - u
+                ke[:, Iu, Jv] += -f * pp                                                  # u - v
+                ke[:, Iv, Jh] += -g * gy[:, i] * phi[j] * dO                              # v - h
+                ke[:, Iv, Ju] += f * pp                                                   # v - u
+                me[:, Iv, Jv] += pp; ke[:, Iv, Jv] += k * pp; se[:, Iv, Jv] += gg         # v - v
+    dofs = (3 * cells[:, :, None] + np.arange(3)[None, None, :]).reshape(nc, 9)           # celldofs!: I = 3 * vertex + field
+    rows = np.repeat(dofs[:, :, None], 9, axis=2).ravel()
+    cols = np.repeat(dofs[:, None, :], 9, axis=1).ravel()
+    n = 3 * nn
+    K = sp.coo_matrix((ke.ravel(), (rows, cols)), shape=(n, n)).tocsr()                   # duplicates summed in cell order
+    K.sort_indices()
+    # block-diagonal coupling of M and S (:141-150): entries between different fields are not part of the pattern
+    same = (rows % 3) == (cols % 3)
+    S = sp.coo_matrix((se.ravel()[same], (rows[same], cols[same])), shape=(n, n)).tocsr()
+    S.sort_indices()
+    ml = me.sum(axis=2)                                                                   # lump_matrix: row sums (:116)
+    M = np.zeros(n)
+    np.add.at(M, dofs.ravel(), ml.ravel())
+    if prescribed is not None and np.any(prescribed):
+        pres = np.asarray(prescribed, dtype=bool)
+        K, S = _apply_constraints(K, pres), _apply_constraints(S, pres)
+        m = np.abs(M).sum() / n                                                            # apply!(M, ...) on the diagonal matrix
+        M = np.where(pres, m, M)
+    return K, M, S
+
+
+def shallow_water_operators(K, M, S, prescribed, kappa_matern: float, tau: float, dt: float):
+    """The operators `discretize` builds from K, M, S (/root/reference/src/spdes/shallow_water.jl:170-217) for one time
+    step dt: M~ (prescribed diagonal 1e-2, :170-174), K_matern = kappa^2 M~ + G with G = S, prescribed diagonal 1
+    (:172,:178), the square root of the initial precision J = sqrt(ratio) M~^-1/2 K_matern (Q_matern = J'J, :187-189,
+    ratio = Gamma(nu) / (Gamma(nu + 1) 4 pi kappa^(2 nu)), nu = 2, :180-184), the noise scalings beta(dt) = sqrt(dt) tau
+    (1e-2 on prescribed dofs, :198-211) and the step matrix G(dt) = M~ + dt K with the constraints applied (:212-217)."""
+    from math import gamma, pi, sqrt
+    n = K.shape[0]
+    pres = np.zeros(n, dtype=bool) if prescribed is None else np.asarray(prescribed, dtype=bool)
+    Mt = np.where(pres, 1e-2, M)                                   # :172-174
+    G = sp.lil_matrix(S)
+    for d in np.flatnonzero(pres):
+        G[d, d] = 1.0                                              # :173
+    G = sp.csr_matrix(G)
+    K_matern = (kappa_matern ** 2 * sp.diags(Mt) + G).tocsr()      # :178
+    nu = 2
+    ratio = gamma(nu) / (gamma(nu + 1) * (4 * pi) * kappa_matern ** (2 * nu))          # :180-184 (sigma^2_goal = 1)
+    J = (sqrt(ratio) * sp.diags(np.sqrt(1.0 / Mt)) @ K_matern).tocsr()                # Q_matern_sqrt' (:188-189)
+    J.sort_indices()
+    noise = np.where(pres, 1e-2, tau)                              # :198, :204
+    beta, beta_inv = sqrt(dt) * noise, (1.0 / sqrt(dt)) / noise    # :210-211
+    Gdt = _apply_constraints(sp.diags(Mt) + dt * K, pres)          # :212-217
+    return {"M_tilde": Mt, "K_matern": K_matern, "J": J, "ratio": ratio, "beta": beta, "beta_inv": beta_inv, "G_dt": Gdt}

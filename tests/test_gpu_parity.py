@@ -1332,3 +1332,82 @@ def test_packed_transport_image_between_handles(pkg):
     F3.adopt_commit(False)
     with pytest.raises(pkg.GmrfError):
         F3.logdet()
+
+
+def test_shallow_water_element_kernels_on_device(pkg):
+    """SURVEY 8f rank 4, third piece: `assemble_system!` (/root/reference/src/spdes/shallow_water.jl:17-122) and the per-step
+    operators of `discretize` (:170-217) on the device, entry by entry against the oracle's line-by-line restatement (fixed
+    summation order: 1e-14 of the largest entry), with and without prescribed dofs, host and device-resident operands; then
+    the initial precision Q_matern = J'J through the posterior assembler and the block-tridiagonal factor of it."""
+    import torch
+    for (nx, ny, kk, ff, gg, with_pres) in ((9, 7, 0.3, 0.7, 9.81, False), (40, 24, 0.0, 1e-4, 9.81, True), (96, 96, 0.05, 0.2, 1.0, True)):
+        sw = pkg.ShallowWaterP1(nx, ny)
+        qp = sw.qpoints
+        H = 1.0 + 0.5 * np.sin(3.0 * qp[:, :, 0]) * np.cos(2.0 * qp[:, :, 1]) + 0.2 * qp[:, :, 0]
+        nn = nx * ny
+        pres = None
+        if with_pres:                          # u and v prescribed on the boundary nodes (a wall), h free
+            ixn, iyn = np.arange(nn) % nx, np.arange(nn) // nx
+            bnd = (ixn == 0) | (iyn == 0) | (ixn == nx - 1) | (iyn == ny - 1)
+            pres = np.zeros(3 * nn, dtype=bool); pres[1::3] = bnd; pres[2::3] = bnd
+        Ko, Mo, So = O.assemble_shallow_water_system(nx, ny, H, kk, ff, gg, prescribed=pres)
+        kv, ml, sv = sw.assemble(H, k=kk, f=ff, g=gg, prescribed=pres)
+        assert np.max(np.abs(kv - Ko.data)) < 1e-14 * np.max(np.abs(Ko.data))
+        assert np.max(np.abs(sv - So.data)) < 1e-14 * np.max(np.abs(So.data))
+        assert np.max(np.abs(ml - Mo)) < 1e-14 * np.max(np.abs(Mo))
+        # device-resident operands give the same bits
+        Hd = torch.from_numpy(H).cuda()
+        pd = None if pres is None else torch.from_numpy(pres.astype(np.uint8)).cuda()
+        kd, md, sd = sw.assemble(Hd, k=kk, f=ff, g=gg, prescribed=pd)
+        assert kd.is_cuda and np.array_equal(kd.cpu().numpy(), kv) and np.array_equal(md.cpu().numpy(), ml) and np.array_equal(sd.cpu().numpy(), sv)
+        oo = O.shallow_water_operators(Ko, Mo, So, pres, kappa_matern=3.0, tau=0.7, dt=0.05)
+        od = sw.operators(kd, md, sd, prescribed=pd, kappa_matern=3.0, tau=0.7, dt=0.05)
+        assert np.max(np.abs(od["G_dt"].cpu().numpy() - oo["G_dt"].data)) < 1e-14 * np.max(np.abs(oo["G_dt"].data))
+        assert np.max(np.abs(od["J"].cpu().numpy() - oo["J"].data)) < 1e-13 * np.max(np.abs(oo["J"].data))
+        assert np.max(np.abs(od["M_tilde"].cpu().numpy() - oo["M_tilde"])) < 1e-15
+        assert np.max(np.abs(od["beta"].cpu().numpy() - oo["beta"])) < 1e-15
+    # the initial precision of the space-time model, Q_0 = J'J (:187), assembled on the device from J's values and factored
+    # by the block-tridiagonal path (96 x 96 nodes x 3 fields, node-major: 4 node rows per block -> 24 blocks of 1152)
+    J = sw.pattern_S.copy(); J.data = od["J"].cpu().numpy()
+    Z = sp.csc_matrix((3 * nn, 3 * nn))
+    asm = pkg.PosteriorAssembler(Z, J)
+    q0 = asm.precision(np.zeros(0), J.data, 1.0)
+    Q0 = asm.pattern.copy(); Q0.data = np.asarray(q0)
+    assert abs(Q0 - (oo["J"].T @ oo["J"])).max() < 1e-12 * abs(Q0).max()
+    N = ny // 4
+    F = pkg.tridiagonal_cholesky(Q0, N)
+    b = np.random.default_rng(5).standard_normal(3 * nn)
+    x = pkg.ldiv(F, b)
+    qn = abs(Q0).sum(axis=1).max()
+    assert np.linalg.norm(Q0 @ x - b) / (qn * np.linalg.norm(x) + np.linalg.norm(b)) < 1e-14
+    assert rel(x, O.ldiv(O.tridiagonal_cholesky(Q0, N), b)) < 1e-9
+
+
+def test_burgers_p2_tangent_on_device(pkg):
+    """The Burgers residual and tangent on the QUADRATIC periodic line (the reference's element, src/utils.jl:42-49) on the
+    device, entry by entry against the oracle's line-by-line restatement at three sizes, host and device-resident operands;
+    then one Gauss-Newton style system Q + noise J'J assembled and factored (time-major: one block per time slice)."""
+    import torch
+    for ns, nt in ((12, 4), (64, 9), (512, 16)):
+        dt, nu = 1.0 / (nt - 1), 0.01 / np.pi
+        w = np.random.default_rng(ns).standard_normal(ns * nt)
+        fo, Jo = O.burgers_f_and_J(ns, nt, dt, nu, w, order=2)
+        b = pkg.BurgersP1Tangent(ns, nt, dt, nu, order=2)
+        vals, f = b.tangent(w)
+        assert np.array_equal(b.pattern.indices, Jo.indices)
+        assert np.max(np.abs(vals - Jo.data)) < 1e-14 * np.max(np.abs(Jo.data))
+        assert np.max(np.abs(f - fo)) < 1e-13 * np.max(np.abs(fo))
+        vd, fd = b.tangent(torch.from_numpy(w).cuda())
+        assert vd.is_cuda and np.array_equal(vd.cpu().numpy(), vals) and np.array_equal(fd.cpu().numpy(), f)
+    # Q + noise J'J on the device and its block-tridiagonal factor (the coupling reaches one time slice)
+    n = ns * nt
+    Q = sp.identity(n, format="csc") * 1e-2
+    asm = pkg.PosteriorAssembler(Q, b.pattern)
+    a = asm.precision(Q.data, vals, 1e4)
+    A = asm.pattern.copy(); A.data = np.asarray(a)
+    Ao = (Q + 1e4 * (Jo.T @ Jo)).tocsc()
+    assert abs(A - Ao).max() < 1e-13 * abs(Ao).max()
+    F = pkg.tridiagonal_cholesky(A, nt)
+    rhs = np.random.default_rng(1).standard_normal(n)
+    x = pkg.ldiv(F, rhs)
+    assert np.linalg.norm(A @ x - rhs) / (abs(A).sum(axis=1).max() * np.linalg.norm(x) + np.linalg.norm(rhs)) < 1e-14

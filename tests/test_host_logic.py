@@ -230,3 +230,77 @@ def test_burgers_p1_pattern_and_oracle_tangent_without_gpu(pkg):
     with pytest.raises(pkg.GmrfError) as e:
         b.tangent(w)
     assert e.value.status == pkg._cabi.ERR_NO_DEVICE
+
+
+def test_burgers_p2_line_pattern_and_oracle_without_gpu(pkg):
+    """The quadratic periodic line of the reference's Burgers scripts (src/utils.jl:42-49): the library's J pattern (device = -1)
+    equals the oracle's (vertex rows 10 entries, midpoint rows 6); the P2 restatement is pinned by what it computes: its
+    matrix is the derivative of its residual, constants have zero residual, the P2 element mass matrix has its closed form
+    h / 30 [4 -1 2; -1 4 2; 2 2 16], the stiffness annihilates constants and reproduces int (x^2)' phi_i' exactly."""
+    from oracle import bt_oracle as O
+    ns, nt, dt, nu = 12, 4, 0.05, 0.01 / np.pi
+    rng = np.random.default_rng(2)
+    w = rng.standard_normal(ns * nt)
+    f, J = O.burgers_f_and_J(ns, nt, dt, nu, w, order=2)
+    b = pkg.BurgersP1Tangent(ns, nt, dt, nu, device=-1, order=2)
+    assert b.pattern.shape == J.shape and b.nnz == J.nnz == 8 * (nt - 1) * ns
+    assert np.array_equal(b.pattern.indptr, J.indptr) and np.array_equal(b.pattern.indices, J.indices)
+    h = 2.0 / ns
+    M, G = O.assemble_burgers_mass_diffusion_matrices(ns, 2)
+    assert abs(M[2, 2] - 8 * h / 30) < 1e-16 and abs(M[3, 3] - 16 * h / 30) < 1e-16 and abs(M[2, 3] - 2 * h / 30) < 1e-16
+    assert abs(M[2, 4] + h / 30) < 1e-16 and abs(M[0, ns - 2] + h / 30) < 1e-16 and abs(M.sum() - 1.0) < 1e-14
+    assert abs(G @ np.ones(ns)).max() < 1e-12
+    u = w[:ns]
+    Gt, vt = O.assemble_burgers_advection_matrix(ns, u, 2)
+    num = np.zeros((ns, ns))
+    for j in range(ns):
+        e = np.zeros(ns); e[j] = 1e-6
+        num[:, j] = (O.assemble_burgers_advection_matrix(ns, u + e, 2)[1] - O.assemble_burgers_advection_matrix(ns, u - e, 2)[1]) / 2e-6
+    assert np.max(np.abs(Gt.toarray() - num)) < 1e-8
+    assert np.max(np.abs(O.assemble_burgers_advection_matrix(ns, np.full(ns, 0.7), 2)[1])) < 1e-15
+    f0, _ = O.burgers_f_and_J(ns, nt, dt, nu, np.full(ns * nt, -0.3), order=2)
+    assert np.max(np.abs(f0)) < 1e-15
+    with pytest.raises(pkg.GmrfError):
+        pkg.BurgersP1Tangent(7, nt, dt, nu, device=-1, order=2)            # the quadratic line has two dofs per cell
+
+
+def test_shallow_water_p1_patterns_and_oracle_without_gpu(pkg):
+    """The shallow-water restatement (oracle/bt_oracle.py, /root/reference/src/spdes/shallow_water.jl:17-122, :170-217) is
+    unpinned against Ferrite (absent); it is pinned by what the operators are: lumped mass integrates 1 per field, the
+    stiffness annihilates constants, the h-u / h-v coupling is minus the weak gradient weighted by H (exact for linear
+    fields on P1), u-u = k times the consistent mass, u-v = -f mass, K's u-h block = -g (weak gradient)'; the library's
+    patterns (device = -1: no GPU) are the oracle's, its quadrature points the oracle's; Q_matern = J'J is symmetric
+    positive definite and equals ratio K_m' M~^-1 K_m."""
+    from oracle import bt_oracle as O
+    nx, ny = 7, 6
+    sw = pkg.ShallowWaterP1(nx, ny, device=-1)
+    qp = O.shallow_water_qpoints(nx, ny)
+    assert np.max(np.abs(sw.qpoints - qp)) < 1e-16
+    H = 2.0 + 0.5 * qp[:, :, 0] - 0.25 * qp[:, :, 1]
+    kk, ff, gg = 0.3, 0.7, 9.81
+    K, M, S = O.assemble_shallow_water_system(nx, ny, H, kk, ff, gg)
+    assert np.array_equal(sw.pattern_K.indptr, K.indptr) and np.array_equal(sw.pattern_K.indices, K.indices)
+    assert np.array_equal(sw.pattern_S.indptr, S.indptr) and np.array_equal(sw.pattern_S.indices, S.indices)
+    nn = nx * ny
+    one = lambda fld: np.where(np.arange(3 * nn) % 3 == fld, 1.0, 0.0)
+    assert abs(M.sum() - 3.0) < 1e-13 and abs(S @ np.ones(3 * nn)).max() < 1e-12
+    # a constant velocity field is divergence free in the weak sense up to the boundary term: sum_i of (K e_u)[h_i] = -int H dx(sum phi_i) = 0
+    assert abs((K @ one(1))[0::3].sum()) < 1e-12 and abs((K @ one(2))[0::3].sum()) < 1e-12
+    assert np.max(np.abs((K @ one(1))[1::3] - kk * M[1::3])) < 1e-14          # u-u rows: k * mass (row sums of the consistent mass)
+    assert np.max(np.abs((K @ one(2))[1::3] + ff * M[1::3])) < 1e-14          # u-v: -f * mass
+    assert np.max(np.abs((K @ one(1))[2::3] - ff * M[2::3])) < 1e-14          # v-u: +f * mass
+    # u-h block: -g int dx(phi_i) phi_j; applied to the nodal values of x it gives -g int dx(phi_i) x: summed over i zero again,
+    # and for H = 1 the h-u block is (1 / g) times the u-h block
+    K1, _, _ = O.assemble_shallow_water_system(nx, ny, np.ones_like(H), kk, ff, gg)
+    Kd = K1.toarray()
+    assert np.max(np.abs(Kd[0::3, 1::3] - Kd[1::3, 0::3] / gg)) < 1e-13
+    # constraints: apply! zeroes rows and columns and puts meandiag on the diagonal
+    pres = np.zeros(3 * nn, dtype=bool); pres[[1, 2, 3 * nn - 1, 40]] = True
+    Kc, Mc, Sc = O.assemble_shallow_water_system(nx, ny, H, kk, ff, gg, prescribed=pres)
+    assert np.all(Sc[pres].toarray()[:, ~pres] == 0) and np.allclose(Sc.diagonal()[pres], np.abs(S.diagonal()).sum() / (3 * nn))
+    ops = O.shallow_water_operators(Kc, Mc, Sc, pres, kappa_matern=2.0, tau=0.5, dt=0.1)
+    Q = (ops["J"].T @ ops["J"]).toarray()
+    Km = ops["K_matern"].toarray()
+    assert np.max(np.abs(Q - ops["ratio"] * Km.T @ np.diag(1.0 / ops["M_tilde"]) @ Km)) < 1e-12 * np.max(np.abs(Q))
+    assert np.min(np.linalg.eigvalsh(0.5 * (Q + Q.T))) > 0
+    assert np.allclose(ops["beta"][pres], np.sqrt(0.1) * 1e-2) and np.allclose(ops["beta"][~pres], np.sqrt(0.1) * 0.5)

@@ -3,7 +3,7 @@
 OUT=gpurun_out/${1:-ab_dma}; mkdir -p $OUT
 for cfg in "0 2" "1 2" "1 3" "3 2" "1 2" "0 2"; do
   set -- $cfg
-  GMRF_GEMM_DMA=$1 GMRF_GEMM_DMA_STAGES=$2 timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-spmm --no-single-problem 2>/dev/null | python3 -c "
+  GMRF_GEMM_DMA=$1 GMRF_GEMM_DMA_STAGES=$2 timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-spmm --no-single-problem --no-full-loop 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']

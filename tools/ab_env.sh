@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; cd $R
 VAR=$1
 for v in $2; do
   echo "== $VAR=$v"
-  env $VAR=$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-spmm --no-single-problem 2>/dev/null | python3 -c "
+  env $VAR=$v timeout -k 10 300 python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-spmm --no-single-problem --no-full-loop 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('1x32 value', round(d['value']), 'factor_ms', round(d['phases_ms']['factor'],2), 'gemm tw', round(d['roofline']['gemm_f64_mfma_both_symbols_time_weighted']['achieved'],1))

@@ -2,7 +2,7 @@
 # A/B of set_eager flag sets on the bench job within ONE gpurun call:  tools/ab_flags.sh <outdir> "<flags> <flags> ..."
 OUT=gpurun_out/${1:-ab_flags}; mkdir -p $OUT
 for fl in $2; do
-  timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-spmm --no-single-problem --eager-flags $fl 2>$OUT/err_$fl.log | python3 -c "
+  timeout -k 10 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-spmm --no-single-problem --no-full-loop --eager-flags $fl 2>$OUT/err_$fl.log | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']

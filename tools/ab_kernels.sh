@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; cd $R
 for fl in $1; do
   echo "== flags=$fl"
-  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-spmm --no-single-problem --eager-flags $fl 2>/dev/null | python3 -c "
+  timeout -k 10 300 python bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-spmm --no-single-problem --no-full-loop --eager-flags $fl 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('value', round(d['value']), 'factor_ms', round(d['phases_ms']['factor'],2))

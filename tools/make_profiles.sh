@@ -4,12 +4,12 @@ set -o pipefail
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/profiles; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. the default bench command (4 streams x batch 32: kernels of different streams overlap)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-spmm > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-spmm --no-full-loop > $OUT/bench_under_rocprof.json 2> $OUT/trace.err || exit 1
 # 2. one stream (no overlap: launch durations comparable with bench.py's instrumented roofline step)
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm > $OUT/bench_1stream_under_rocprof.json 2> $OUT/trace1.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -- python3 $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm --no-full-loop > $OUT/bench_1stream_under_rocprof.json 2> $OUT/trace1.err || exit 1
 # 3. HBM traffic counters, one pass each
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm > /dev/null 2> $OUT/pmc_fetch.err || exit 1
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm > /dev/null 2> $OUT/pmc_write.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm --no-full-loop > /dev/null 2> $OUT/pmc_fetch.err || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm --no-full-loop > /dev/null 2> $OUT/pmc_write.err || exit 1
 python3 $R/tools/trace_summary.py $(ls $OUT/trace/*/*kernel_trace.csv | head -1) 1 45 > $OUT/trace_by_grid.txt
 python3 $R/tools/trace_summary.py $(ls $OUT/trace1/*/*kernel_trace.csv | head -1) 1 45 > $OUT/trace1_by_grid.txt
 python3 $R/tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/hbm_traffic.json > $OUT/pmc_table.md

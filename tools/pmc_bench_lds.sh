@@ -15,7 +15,7 @@ else
 fi
 for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '+')
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm > /dev/null 2> $OUT/$tag.err || { echo "failed $tag"; tail -3 $OUT/$tag.err; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/$tag -- python3 $R/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-single-problem --no-spmm --no-full-loop > /dev/null 2> $OUT/$tag.err || { echo "failed $tag"; tail -3 $OUT/$tag.err; exit 1; }
   cp $(ls $OUT/$tag/*/*counter_collection.csv | head -1) $OUT/$tag.csv
   rm -rf $OUT/$tag
 done
