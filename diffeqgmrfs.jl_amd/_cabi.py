@@ -40,7 +40,7 @@ EXPORTS = [
     "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
     "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
-    "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench",
+    "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench", "gmrf_test_symbolic_csc",
 ]
 
 
@@ -176,6 +176,7 @@ def load() -> C.CDLL:
         "gmrf_test_mfma_f64_rate": [i32, P(dbl)],
         "gmrf_test_hbm_rate": [i32, i64, P(dbl)],
         "gmrf_test_microbench": [i32, vp, i32],
+        "gmrf_test_symbolic_csc": [i64, i64, vp, vp, i32, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

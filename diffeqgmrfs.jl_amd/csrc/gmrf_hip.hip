@@ -450,26 +450,43 @@ static gmrf_status ensure_stage(gmrf_handle* h, int64_t elems) {
 // ------------------------------------------------------------------------------------ symbolic
 struct HostEntry { uint64_t key; int64_t src; };
 
-static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<HostEntry>>& dg,
-                                  const std::vector<std::vector<HostEntry>>& lo, int64_t nnz_in) {
-    const int64_t N = h->N;
-    h->diag_first.assign(N, 0); h->diag_count.assign(N, 0);
-    h->low_first.assign(N, 0); h->low_count.assign(N, 0);
+// Everything the symbolic phase derives on the HOST from the blocks' entry lists (no HIP call: the sanitizer build of the
+// host side reaches it without a GPU through gmrf_test_symbolic_csc): the flat key / source arrays in block order (lower
+// blocks row by row), the zero structure shared by all lower blocks (first non-zero column, last non-zero row, per 64-row
+// tile the first non-zero column: the staircase), the row pointers into the lower blocks' entry lists, and the tile plan
+// of the sparse C = B X^T (spmm_bxt_tiles: per lower block and 64-row tile the distinct columns, per entry its index).
+struct SymbolicPlan {
+    std::vector<int64_t> diag_first, diag_count, low_first, low_count;
     std::vector<uint64_t> keys;
     std::vector<int64_t> src;
+    int64_t cmin = 0, rmax = 0;
+    std::vector<int64_t> first;            // per 64-row tile of the window: first non-zero column (absolute)
+    std::vector<int> rowptr;               // [N][bsp + 1]
+    int64_t max_row = 0;
+    bool sparse_b = false, bxt_ok = false;
+    std::vector<int> uptr, ucols;
+    std::vector<uint16_t> lidx;
+    int ecap = 0, nrt = 0;
+};
+
+static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector<HostEntry>>& dg,
+                           const std::vector<std::vector<HostEntry>>& lo, bool no_staircase, SymbolicPlan& sp) {
+    sp.diag_first.assign((size_t)N, 0); sp.diag_count.assign((size_t)N, 0);
+    sp.low_first.assign((size_t)N, 0); sp.low_count.assign((size_t)N, 0);
+    auto& keys = sp.keys; auto& src = sp.src;
+    keys.clear(); src.clear();
     for (int64_t i = 0; i < N; ++i) {
-        h->diag_first[i] = (int64_t)keys.size(); h->diag_count[i] = (int64_t)dg[i].size();
+        sp.diag_first[i] = (int64_t)keys.size(); sp.diag_count[i] = (int64_t)dg[i].size();
         for (auto& e : dg[i]) { keys.push_back(e.key); src.push_back(e.src); }
-        h->low_first[i] = (int64_t)keys.size(); h->low_count[i] = (int64_t)lo[i].size();
+        sp.low_first[i] = (int64_t)keys.size(); sp.low_count[i] = (int64_t)lo[i].size();
         std::vector<HostEntry> byrow(lo[i]);           // row by row (key = row << 32 | col): spmm_bxt walks rows
         std::stable_sort(byrow.begin(), byrow.end(), [](const HostEntry& x, const HostEntry& y) { return x.key < y.key; });
         for (auto& e : byrow) { keys.push_back(e.key); src.push_back(e.src); }
     }
-    // zero structure shared by all lower blocks: first non-zero column, last non-zero row, and per
-    // 64-row tile the first non-zero column (the staircase; set_layout takes its monotone envelope)
+    // zero structure shared by all lower blocks (set_layout takes the monotone envelope of `first`)
     {
-        int64_t cmin = h->bsp, rmax = 0;
-        std::vector<int64_t> first((size_t)(h->bsp / 64), h->bsp);
+        int64_t cmin = bsp, rmax = 0;
+        std::vector<int64_t> first((size_t)(bsp / 64), bsp);
         for (int64_t i = 1; i < N; ++i)
             for (auto& e : lo[i]) {
                 const int64_t r = (int64_t)(e.key >> 32), c = (int64_t)(e.key & 0xffffffffu);
@@ -478,11 +495,68 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
             }
         if (rmax == 0) { cmin = 0; rmax = 64; first[0] = 0; }
         cmin = (cmin / 64) * 64;
-        rmax = std::min<int64_t>(h->bsp, (rmax + 63) / 64 * 64);
+        rmax = std::min<int64_t>(bsp, (rmax + 63) / 64 * 64);
         first.resize((size_t)(rmax / 64));
-        if (h->no_staircase) std::fill(first.begin(), first.end(), cmin);
-        GCHK(set_layout(h, cmin, rmax, first));
+        if (no_staircase) std::fill(first.begin(), first.end(), cmin);
+        sp.cmin = cmin; sp.rmax = rmax; sp.first = first;
     }
+    // row pointers into the lower blocks' entry lists for the sparse C = B X^T (spmm_bxt)
+    sp.rowptr.assign((size_t)(N * (bsp + 1)), 0);
+    int64_t max_row = 0;
+    for (int64_t i = 1; i < N; ++i) {
+        int* rp = sp.rowptr.data() + i * (bsp + 1);
+        const int64_t first = sp.low_first[i], cnt = sp.low_count[i];
+        for (int64_t k = 0; k < cnt; ++k) rp[(keys[first + k] >> 32) + 1]++;
+        for (int64_t r = 0; r < bsp; ++r) max_row = std::max<int64_t>(max_row, rp[r + 1]);
+        rp[0] = (int)first;
+        for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
+    }
+    // dense GEMM: 2 bs^3 flop at ~50 TF/s; sparse: one pass over C.  Rows of up to 32 entries go the sparse way,
+    // anything denser keeps the GEMM.
+    sp.max_row = max_row;
+    sp.sparse_b = keys.size() < ((size_t)1 << 31) && max_row <= 32 && bsp >= 64;
+    // tile plan for spmm_bxt_tiles (rows of the lower blocks are sorted by (row, column): a 64-row tile is a contiguous
+    // range of entries)
+    sp.bxt_ok = false; sp.uptr.clear(); sp.ucols.clear(); sp.lidx.clear();
+    if (sp.sparse_b && N > 1) {
+        const int nrt = (int)(sp.rmax / 64);
+        sp.uptr.assign((size_t)(N * (nrt + 1)), 0);
+        sp.lidx.assign(std::max<size_t>(keys.size(), 1), 0);
+        std::vector<int> tmp;
+        bool ok = true;
+        int64_t pmax = 0;
+        for (int64_t i = 1; i < N && ok; ++i) {
+            const int* rp = sp.rowptr.data() + i * (bsp + 1);
+            for (int rt = 0; rt < nrt && ok; ++rt) {
+                const int ea = rp[rt * 64], eb = rp[rt * 64 + 64];
+                tmp.clear();
+                for (int e = ea; e < eb; ++e) tmp.push_back((int)(keys[(size_t)e] & 0xffffffffu));
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                if ((int)tmp.size() > BXT_UCAP) { ok = false; break; }
+                for (int e = ea; e < eb; ++e)
+                    sp.lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), (int)(keys[(size_t)e] & 0xffffffffu)) - tmp.begin());
+                sp.uptr[(size_t)(i * (nrt + 1) + rt)] = (int)sp.ucols.size();
+                sp.ucols.insert(sp.ucols.end(), tmp.begin(), tmp.end());
+                int64_t padded = 0;
+                for (int r = rt * 64; r < rt * 64 + 64; ++r) padded += (rp[r + 1] - rp[r] + 7) / 8 * 8;
+                pmax = std::max(pmax, padded);
+            }
+            sp.uptr[(size_t)(i * (nrt + 1) + nrt)] = (int)sp.ucols.size();
+        }
+        const int ecap = (int)std::max<int64_t>(64, (pmax + 63) / 64 * 64);
+        if (ok && bxt_tile_lds_bytes(ecap) <= 53 * 1024) { sp.bxt_ok = true; sp.ecap = ecap; sp.nrt = nrt; }
+    }
+}
+
+static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<HostEntry>>& dg,
+                                  const std::vector<std::vector<HostEntry>>& lo, int64_t nnz_in) {
+    const int64_t N = h->N;
+    SymbolicPlan sp;
+    build_symbolic(N, h->bsp, dg, lo, h->no_staircase, sp);
+    h->diag_first = sp.diag_first; h->diag_count = sp.diag_count; h->low_first = sp.low_first; h->low_count = sp.low_count;
+    const auto& keys = sp.keys; const auto& src = sp.src;
+    GCHK(set_layout(h, sp.cmin, sp.rmax, sp.first));
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     h->d_keys = nullptr; h->d_vals = nullptr; h->d_src = nullptr; h->d_nz_stage = nullptr;
     h->n_entries = (int64_t)keys.size();
@@ -500,85 +574,38 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
         HIPCHK(hipMemcpyAsync(h->d_src, src.data(), src.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
-    // row pointers into the lower blocks' entry lists for the sparse C = B X^T (spmm_bxt)
     free_dev(h->d_lo_rowptr);
     h->d_lo_rowptr = nullptr;
-    {
-        const int64_t bsp = h->bsp;
-        std::vector<int> rowptr((size_t)(N * (bsp + 1)), 0);
-        int64_t max_row = 0;
-        for (int64_t i = 1; i < N; ++i) {
-            int* rp = rowptr.data() + i * (bsp + 1);
-            const int64_t first = h->low_first[i], cnt = h->low_count[i];
-            for (int64_t k = 0; k < cnt; ++k) rp[(keys[first + k] >> 32) + 1]++;
-            for (int64_t r = 0; r < bsp; ++r) max_row = std::max<int64_t>(max_row, rp[r + 1]);
-            rp[0] = (int)first;
-            for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
-        }
-        HIPCHK(hipMalloc(&h->d_lo_rowptr, rowptr.size() * sizeof(int)));
-        HIPCHK(hipMemcpyAsync(h->d_lo_rowptr, rowptr.data(), rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMalloc(&h->d_lo_rowptr, sp.rowptr.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(h->d_lo_rowptr, sp.rowptr.data(), sp.rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->lo_row_max = sp.max_row;
+    h->sparse_b = sp.sparse_b;
+    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
+    h->d_bxt_uptr = nullptr; h->d_bxt_ucols = nullptr; h->d_bxt_lidx = nullptr; h->bxt_plan_ok = false;
+    if (sp.bxt_ok) {
+        HIPCHK(hipMalloc(&h->d_bxt_uptr, sp.uptr.size() * sizeof(int)));
+        HIPCHK(hipMalloc(&h->d_bxt_ucols, std::max<size_t>(sp.ucols.size(), 1) * sizeof(int)));
+        HIPCHK(hipMalloc(&h->d_bxt_lidx, sp.lidx.size() * sizeof(uint16_t)));
+        HIPCHK(hipMemcpyAsync(h->d_bxt_uptr, sp.uptr.data(), sp.uptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        if (!sp.ucols.empty()) HIPCHK(hipMemcpyAsync(h->d_bxt_ucols, sp.ucols.data(), sp.ucols.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(h->d_bxt_lidx, sp.lidx.data(), sp.lidx.size() * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
-        // dense GEMM: 2 bs^3 flop at ~50 TF/s; sparse: one pass over C.  Rows of up to 32 entries go
-        // the sparse way, anything denser keeps the GEMM.
-        h->lo_row_max = max_row;
-        h->sparse_b = keys.size() < ((size_t)1 << 31) && max_row <= 32 && h->bsp >= 64;
-        // tile plan for spmm_bxt_tiles (rows of the lower blocks are sorted by (row, column): a 64-row tile is a
-        // contiguous range of entries)
-        free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
-        h->d_bxt_uptr = nullptr; h->d_bxt_ucols = nullptr; h->d_bxt_lidx = nullptr; h->bxt_plan_ok = false;
-        if (h->sparse_b && N > 1) {
-            const int nrt = (int)(h->rmax / 64);
-            std::vector<int> uptr((size_t)(N * (nrt + 1)), 0), ucols;
-            std::vector<uint16_t> lidx(std::max<size_t>(keys.size(), 1), 0);
-            std::vector<int> tmp;
-            bool ok = true;
-            int64_t pmax = 0;
-            for (int64_t i = 1; i < N && ok; ++i) {
-                const int* rp = rowptr.data() + i * (bsp + 1);
-                for (int rt = 0; rt < nrt && ok; ++rt) {
-                    const int ea = rp[rt * 64], eb = rp[rt * 64 + 64];
-                    tmp.clear();
-                    for (int e = ea; e < eb; ++e) tmp.push_back((int)(keys[(size_t)e] & 0xffffffffu));
-                    std::sort(tmp.begin(), tmp.end());
-                    tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                    if ((int)tmp.size() > BXT_UCAP) { ok = false; break; }
-                    for (int e = ea; e < eb; ++e)
-                        lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), (int)(keys[(size_t)e] & 0xffffffffu)) - tmp.begin());
-                    uptr[(size_t)(i * (nrt + 1) + rt)] = (int)ucols.size();
-                    ucols.insert(ucols.end(), tmp.begin(), tmp.end());
-                    int64_t padded = 0;
-                    for (int r = rt * 64; r < rt * 64 + 64; ++r) padded += (rp[r + 1] - rp[r] + 7) / 8 * 8;
-                    pmax = std::max(pmax, padded);
-                }
-                uptr[(size_t)(i * (nrt + 1) + nrt)] = (int)ucols.size();
-            }
-            const int ecap = (int)std::max<int64_t>(64, (pmax + 63) / 64 * 64);
-            if (ok && bxt_tile_lds_bytes(ecap) <= 53 * 1024) {
-                HIPCHK(hipMalloc(&h->d_bxt_uptr, uptr.size() * sizeof(int)));
-                HIPCHK(hipMalloc(&h->d_bxt_ucols, std::max<size_t>(ucols.size(), 1) * sizeof(int)));
-                HIPCHK(hipMalloc(&h->d_bxt_lidx, lidx.size() * sizeof(uint16_t)));
-                HIPCHK(hipMemcpyAsync(h->d_bxt_uptr, uptr.data(), uptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-                if (!ucols.empty()) HIPCHK(hipMemcpyAsync(h->d_bxt_ucols, ucols.data(), ucols.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-                HIPCHK(hipMemcpyAsync(h->d_bxt_lidx, lidx.data(), lidx.size() * sizeof(uint16_t), hipMemcpyHostToDevice, h->stream));
-                HIPCHK(hipStreamSynchronize(h->stream));
-                h->bxt_ecap = ecap; h->bxt_nrt = nrt; h->bxt_plan_ok = true;
-            }
-        }
+        h->bxt_ecap = sp.ecap; h->bxt_nrt = sp.nrt; h->bxt_plan_ok = true;
     }
     h->analyzed = true;
     h->factored = false;
     return GMRF_OK;
 }
 
-static gmrf_status analyze_csc(gmrf_handle* h, int64_t n, int64_t N, const int64_t* colptr,
-                               const int64_t* rowval, int32_t base) {
-    if (!colptr || !rowval) return bad_shape("null CSC arrays");
-    GCHK(set_shape(h, n, N));
-    const int64_t bs = h->bs;
-    std::vector<std::vector<HostEntry>> dg(N), lo(N);
-    const int64_t nnz = colptr[n] - base;
+// The CSC walk of the symbolic phase (host only): which stored entries belong to which block; band check.
+static gmrf_status split_csc(int64_t n, int64_t N, int64_t bs, const int64_t* colptr, const int64_t* rowval, int32_t base,
+                             std::vector<std::vector<HostEntry>>& dg, std::vector<std::vector<HostEntry>>& lo) {
+    dg.assign((size_t)N, {}); lo.assign((size_t)N, {});
+    if (colptr[0] != base) return bad_shape("colptr must start at the index base");
     for (int64_t c = 0; c < n; ++c) {
         const int64_t bj = c / bs;
+        if (colptr[c + 1] < colptr[c]) return bad_shape("colptr must be non-decreasing");
         for (int64_t p = colptr[c] - base; p < colptr[c + 1] - base; ++p) {
             const int64_t r = rowval[p] - base;
             if (r < 0 || r >= n) return bad_shape("row index out of range");
@@ -595,7 +622,16 @@ static gmrf_status analyze_csc(gmrf_handle* h, int64_t n, int64_t N, const int64
             }
         }
     }
-    return upload_entries(h, dg, lo, nnz);
+    return GMRF_OK;
+}
+
+static gmrf_status analyze_csc(gmrf_handle* h, int64_t n, int64_t N, const int64_t* colptr,
+                               const int64_t* rowval, int32_t base) {
+    if (!colptr || !rowval) return bad_shape("null CSC arrays");
+    GCHK(set_shape(h, n, N));
+    std::vector<std::vector<HostEntry>> dg, lo;
+    GCHK(split_csc(n, N, h->bs, colptr, rowval, base, dg, lo));
+    return upload_entries(h, dg, lo, colptr[n] - base);
 }
 
 // blockIdx.y = problem: nzval of problem p starts at nz + p * nnz
@@ -3553,6 +3589,33 @@ gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops) {
 
 
 // Micro-benchmark battery; fills out[0..n) (see tools/microbench.py for the meaning).
+// The host-only part of the symbolic phase of gmrf_bt_factor_csc (block split + band check, zero structure of the coupling
+// blocks, row pointers, tile plan of the sparse C = B X^T) without a device: what the sanitizer build of the host side
+// (make libgmrf_hip_asan.so, tests/test_host_logic.py) drives.  out[8] = {cmin, rmax, entries, most entries in a row of a
+// lower block, sparse route?, tile plan?, LDS entry capacity of the plan, checksum of the plan's arrays}.
+gmrf_status gmrf_test_symbolic_csc(int64_t n, int64_t n_blocks, const int64_t* colptr, const int64_t* rowval, int32_t index_base,
+                                   int64_t* out8) {
+    if (!colptr || !rowval || !out8) return bad_shape("null pointer");
+    if (n <= 0 || n_blocks <= 0 || n % n_blocks != 0) return bad_shape("n must be a positive multiple of N_blocks");
+    const int64_t bs = n / n_blocks, bsp = 64 * next_pow2((bs + 63) / 64);
+    std::vector<std::vector<HostEntry>> dg, lo;
+    GCHK(split_csc(n, n_blocks, bs, colptr, rowval, index_base, dg, lo));
+    SymbolicPlan sp;
+    build_symbolic(n_blocks, bsp, dg, lo, false, sp);
+    uint64_t sum = 1469598103934665603ull;
+    auto mix = [&sum](uint64_t v) { sum = (sum ^ v) * 1099511628211ull; };
+    for (uint64_t k : sp.keys) mix(k);
+    for (int64_t v : sp.src) mix((uint64_t)v);
+    for (int v : sp.rowptr) mix((uint64_t)(uint32_t)v);
+    for (int v : sp.uptr) mix((uint64_t)(uint32_t)v);
+    for (int v : sp.ucols) mix((uint64_t)(uint32_t)v);
+    for (uint16_t v : sp.lidx) mix(v);
+    for (int64_t v : sp.first) mix((uint64_t)v);
+    out8[0] = sp.cmin; out8[1] = sp.rmax; out8[2] = (int64_t)sp.keys.size(); out8[3] = sp.max_row; out8[4] = sp.sparse_b;
+    out8[5] = sp.bxt_ok; out8[6] = sp.ecap; out8[7] = (int64_t)(sum >> 1);
+    return GMRF_OK;
+}
+
 gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n) {
     if (!out || n < 16) return bad_shape("need 16 outputs");
     HIPCHK(hipSetDevice(device));

@@ -451,6 +451,10 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/ou
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
 gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps);
 gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n);
+/* Host-only part of the symbolic phase of gmrf_bt_factor_csc (needs no device): driven by the sanitizer build of the host
+ * side.  out8 = {cmin, rmax, entries, longest lower-block row, sparse route?, tile plan?, plan capacity, checksum}. */
+gmrf_status gmrf_test_symbolic_csc(int64_t n, int64_t n_blocks, const int64_t* colptr, const int64_t* rowval,
+                                   int32_t index_base, int64_t* out8);
 
 #ifdef __cplusplus
 }

@@ -304,3 +304,21 @@ def test_shallow_water_p1_patterns_and_oracle_without_gpu(pkg):
     assert np.max(np.abs(Q - ops["ratio"] * Km.T @ np.diag(1.0 / ops["M_tilde"]) @ Km)) < 1e-12 * np.max(np.abs(Q))
     assert np.min(np.linalg.eigvalsh(0.5 * (Q + Q.T))) > 0
     assert np.allclose(ops["beta"][pres], np.sqrt(0.1) * 1e-2) and np.allclose(ops["beta"][~pres], np.sqrt(0.1) * 0.5)
+
+
+def test_host_side_under_address_sanitizer(pkg, tmp_path):
+    """SURVEY section 5 ("Race detection / sanitizers"): the host side of the library -- symbolic phase of the factor (block
+    split, band check, staircase, tile plans), posterior-assembler symbolic phase, FEM patterns, argument validation -- is
+    compiled with -fsanitize=address,undefined (device code as usual) and driven through the entry points that need no GPU,
+    in a child process with the sanitizer runtime preloaded.  A report aborts the child."""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "diffeqgmrfs.jl_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "libgmrf_hip_asan.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    rt = subprocess.run(["make", "-s", "-C", csrc, "asan-runtime"], capture_output=True, text=True).stdout.strip().splitlines()[-1]
+    assert os.path.exists(rt), rt
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=77", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py"), os.path.join(csrc, "libgmrf_hip_asan.so")],
+                       capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "asan driver ok" in p.stdout and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, \
+        (p.returncode, p.stdout[-500:], p.stderr[-3000:])
