@@ -62,11 +62,41 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
 
 
 def git_head():
+    """Commit of the tree: from git, or (on a GPU box, whose snapshot has no .git) from .build_head, which
+    __graft_entry__.build() / the profile scripts write beside the built library."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True,
-                              timeout=5).stdout.strip() or None
+        h = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if h:
+            return h
     except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".build_head")).read().strip() or None
+    except OSError:
         return None
+
+
+def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
+    """HBM bytes per launch of kernel symbols from the committed rocprofv3 --pmc snapshot profiles/<round>_<file_stem>.json
+    (newest round present; FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py).  A snapshot, not a live counter read: the
+    source string names the commit it was taken at.  Returns ({symbol: bytes}, source) or (None, None)."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")
+        try:
+            prof = json.load(open(path))
+        except Exception:
+            continue
+        if batch is not None and prof.get("batch", batch) != batch:
+            continue
+        got = {}
+        for pre in symbol_prefixes:
+            key = next((k for k in prof["kernels"] if k.replace(" ", "").startswith(pre.replace(" ", ""))), None)
+            if key:
+                got[key] = prof["kernels"][key]["read_bytes_per_launch"] + prof["kernels"][key]["write_bytes_per_launch"]
+        if got:
+            return got, (f"snapshot: profiles/{rnd}_{file_stem}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes, taken at "
+                         f"commit {prof.get('head', '?')}; this run is {git_head()})")
+    return None, None
 
 
 def cpu_sparse_direct(w, k_samples: int):
@@ -365,8 +395,12 @@ def spmm_roofline(pkg, torch):
             e1.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / reps
             b = w.Q.nnz * ((4 if f32 else 8) + 4) + 8 * (w.n + 1) + 16 * w.n * k
-            out["cases"][f"{'fp32' if f32 else 'fp64'}_k{k}"] = {"us": us, "achieved": b / us / 1e3, "frac": b / us / 1e3 / PEAK_HBM_GBPS,
-                                                                  "algorithmic_bytes": b}
+            rec = {"us": us, "achieved": b / us / 1e3, "frac": b / us / 1e3 / PEAK_HBM_GBPS, "algorithmic_bytes": b}
+            if not f32:
+                got, src = pmc_traffic("spmm_hbm_traffic", ["csr_spmv_tiles<double" if k == 1 else "csr_spmm_tiles_pad<double"])
+                if got:
+                    rec["traffic"], rec["traffic_source"] = next(iter(got.values())), src
+            out["cases"][f"{'fp32' if f32 else 'fp64'}_k{k}"] = rec
         del S
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.default_stream())
@@ -675,6 +709,7 @@ def main():
             job.step(10_000)
         torch.cuda.synchronize()
         st = eng.F.stats()
+        shapes = eng.F.gemm_shapes()
         eng.F.set_profiling(0)
         ms, work, cnt = st["kernel_ms"], st["kernel_work"], st["kernel_launches"]
         # dominant kernel = the class with the largest time in one instrumented step of one handle (HIP events on the
@@ -686,15 +721,13 @@ def main():
         else:
             achieved, peak, unit = work[dom] / (ms[dom] * 1e-3) / 1e9, PEAK_HBM_GBPS, "GB/s"
         traffic, traffic_src = None, None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")))
-            key = next((k for k in prof["kernels"] if k.replace(" ", "").startswith(name.replace(" ", "").rstrip(">"))), None)
-            if key and w.name == "darcy256" and eng.batch == prof.get("batch", 32):
-                traffic = prof["kernels"][key]["read_bytes_per_launch"] + prof["kernels"][key]["write_bytes_per_launch"]
-                traffic_src = (f"snapshot: profiles/r02_hbm_traffic.json ({key}; rocprofv3 --pmc passes taken at commit "
-                               f"{prof.get('head', '?')}, this run is {git_head()})")
-        except Exception:
-            pass
+        if w.name == "darcy256":
+            # kernel symbol of the class as a rocprofv3 trace spells it
+            sym = {14: "gemm_f64_dma<64,64,false", 15: "gemm_f64_dma<64,64,true", 0: "gemm_f64_mfma<false,false", 11: "gemm_f64_mfma<false,true",
+                   16: "potrf_diag128", 10: "spmm_bxt_tiles", 13: "gemm_f64_ll"}.get(dom, name)
+            got, traffic_src = pmc_traffic("hbm_traffic", [sym], batch=eng.batch)
+            if got:
+                traffic = next(iter(got.values()))
         gemm_cls = [c for c in (0, 11, 12, 13, 14, 15, 6, 7) if ms[c] > 0]
         tw = sum(work[c] for c in gemm_cls) / max(sum(ms[c] for c in gemm_cls), 1e-9) / 1e9 if gemm_cls else 0.0
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
@@ -712,6 +745,14 @@ def main():
                                                   ("tflops" if KERNEL_CLASSES[c][1] == "mfma" else "gbps"):
                                                   (work[c] / (ms[c] * 1e-3) / (1e12 if KERNEL_CLASSES[c][1] == "mfma" else 1e9)) if ms[c] > 0 else 0.0}
                           for c in KERNEL_CLASSES}
+        # the GEMM launches of that step by shape (where the time-weighted figure comes from): M x N outputs per problem, K, flags
+        # (tri: triangular K range, lower: lower tiles only, kb: per-tile staircase bounds), flops as booked = executed
+        gsum = max(sum(g["ms"] for g in shapes), 1e-9)
+        out["gemm_by_shape"] = [{"kernel": KERNEL_CLASSES.get(g["class"], (str(g["class"]),))[0], "MxNxK": [g["M"], g["N"], g["K"]],
+                                 "tri": g["tri"], "lower": g["lower_only"], "kb": g["k_bounds"], "problems": g["problems"],
+                                 "launches": g["launches"], "ms": round(g["ms"], 3), "share": round(g["ms"] / gsum, 4),
+                                 "tflops": round(g["flops"] / max(g["ms"], 1e-9) / 1e9, 2)}
+                                for g in sorted(shapes, key=lambda g: -g["ms"]) if g["launches"] > 0]
         executed = sum(work[c] for c in KERNEL_CLASSES if KERNEL_CLASSES[c][1] == "mfma")
         # phase times of the un-instrumented path (whole batch of one handle)
         eng.F.refactor(eng.nz)
@@ -731,12 +772,21 @@ def main():
             # GEMV launches stream.  Beside it the same launches timed one by one in eager mode (an event pair per
             # launch adds the dispatch gap: 28.7 us against 23.9 us per launch in the rocprofv3 trace).
             g_graph = 2.0 * s1["sweep_bytes_streamed"] / (s1["solve_ms"] * 1e-3) / 1e9      # (stats: bytes of ONE sweep)
+            # PMC traffic per launch, launch-weighted over the four sweep symbols (X / C products, forward / backward)
+            sweep_traffic, sweep_traffic_src = None, None
+            if w.name == "darcy256":
+                got, sweep_traffic_src = pmc_traffic("hbm_traffic", ["sweep_gemv_n<true", "sweep_gemv_t<true", "sweep_gemv_n<false", "sweep_gemv_t<false"],
+                                                     batch=eng.batch)
+                if got:
+                    sweep_traffic = sum(got.values()) / len(got)
             g3 = work[3] / (ms[3] * 1e-3) / 1e9
             out["roofline_sweep"] = {"bound": "hbm", "achieved": g_graph, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                      "frac": g_graph / PEAK_HBM_GBPS, "kernel": "sweep_gemv_n / sweep_gemv_t",
                                      "launches_per_step": int(cnt[3]), "avg_launch_us": 1e3 * s1["solve_ms"] / max(cnt[3], 1),
                                      "timing": "graph replay of the k = 1 forward + backward sweep (events around the replay)",
                                      "bytes": "streamed: lower triangle of Linv_i, C_i inside its staircase window",
+                                     "traffic": sweep_traffic, "traffic_source": sweep_traffic_src,
+                                     "algorithmic_bytes_per_launch": 2.0 * s1["sweep_bytes_streamed"] / max(cnt[3], 1),
                                      "eager_per_launch_events": {"achieved": g3, "frac": g3 / PEAK_HBM_GBPS,
                                                                  "avg_launch_us": 1e3 * ms[3] / max(cnt[3], 1)}}
         pj.close()

@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgmrf_hip.so")
+LIB_PATH = os.environ.get("GMRF_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libgmrf_hip.so")   # (override: A/B of two builds, tools/)
 
 GMRF_OK = 0
 ERR_NOT_SPD, ERR_BAD_SHAPE, ERR_BAND, ERR_HIP, ERR_NO_FACTOR, ERR_NO_DEVICE, ERR_ALLOC, ERR_RCCL = -1, -2, -3, -4, -5, -6, -7, -8
@@ -39,7 +39,7 @@ EXPORTS = [
     "gmrf_shallow_water_p1_create", "gmrf_shallow_water_p1_destroy", "gmrf_shallow_water_p1_pattern", "gmrf_shallow_water_p1_qpoints",
     "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
-    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
+    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_gemm_shapes", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench", "gmrf_test_symbolic_csc",
 ]
 
@@ -169,6 +169,7 @@ def load() -> C.CDLL:
         "gmrf_spmm_rows_async": [vp, vp, vp, i64, i64, i64],
         "gmrf_spmm_rows": [vp, vp, vp, i64, i64, i64],
         "gmrf_test_gemm": [i32, i64, i64, i64, i32, i32, i32, i32, dbl, vp, i64, vp, i64, dbl, vp, i64],
+        "gmrf_test_gemm_shapes": [vp, P(dbl), i64, P(i64)],
         "gmrf_test_gemm_rate": [i32, i64, i64, i64, i32, i32, i32, i32, i32, i32, P(dbl)],
         "gmrf_test_potrf_tile": [i32, vp, vp, P(i32)],
         "gmrf_test_potrf_block": [i32, i64, vp, vp, P(i32)],

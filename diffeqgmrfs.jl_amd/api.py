@@ -711,6 +711,16 @@ class TridiagonalCholeskyFactor:
             out[f] = list(v) if hasattr(v, "__len__") else v
         return out
 
+    def gemm_shapes(self) -> list:
+        """GEMM launches of the profiled steps by shape (test hook gmrf_test_gemm_shapes): list of dicts."""
+        n = C.c_int64(0)
+        _cabi.check(self._lib.gmrf_test_gemm_shapes(self._h, None, 0, C.byref(n)))
+        buf = np.zeros((max(int(n.value), 1), 11))
+        _cabi.check(self._lib.gmrf_test_gemm_shapes(self._h, buf.ctypes.data_as(C.POINTER(C.c_double)), buf.shape[0], C.byref(n)))
+        names = ("class", "M", "N", "K", "tri", "lower_only", "problems", "k_bounds")
+        return [dict({k: int(r[i]) for i, k in enumerate(names)}, launches=int(r[8]), ms=float(r[9]), flops=float(r[10]))
+                for r in buf[: int(n.value)]]
+
     def set_profiling(self, level: int):
         _cabi.check(self._lib.gmrf_bt_set_profiling(self._h, level))
 

@@ -30,6 +30,9 @@
 namespace gmrf {
 
 constexpr int DMA_BK = 16;
+#ifndef GMRF_DMA_READS_FIRST
+#define GMRF_DMA_READS_FIRST 0      // 1: a K step issues its fragment reads before the next tile's LDS-DMA requests (measured: see DESIGN.md)
+#endif
 
 template <int BM, int BN>
 constexpr size_t gemm_dma_lds_bytes(int stages) { return (size_t)stages * (BM + BN) * DMA_BK * sizeof(double); }
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NA + NB)) : "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (kt + DEPTH < nkt) issue(kt + DEPTH, (kt + DEPTH) % STAGES);
+        if (!GMRF_DMA_READS_FIRST && kt + DEPTH < nkt) issue(kt + DEPTH, (kt + DEPTH) % STAGES);
         if (!idle) {
             const double* sm = gsm + (kt % STAGES) * ST;
             v2d a[BK / 8][MI], b[BK / 8][NJ];
@@ -210,6 +213,8 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                 for (int j = 0; j < NJ; ++j)
                     b[kg][j] = *reinterpret_cast<const v2d*>(sm + fb[j] + (B_N ? kg * 8 * BN : ((kg * 8) ^ sb2[j])));
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (GMRF_DMA_READS_FIRST && kt + DEPTH < nkt) issue(kt + DEPTH, (kt + DEPTH) % STAGES);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kg = 0; kg < BK / 8; ++kg)
@@ -228,7 +233,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                             acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[i][j], 0, 0, 0);
                         }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        } else if (GMRF_DMA_READS_FIRST && kt + DEPTH < nkt) issue(kt + DEPTH, (kt + DEPTH) % STAGES);
     }
     if (idle) return;
 
@@ -326,7 +331,7 @@ inline hipError_t gemm_dma_init() {
 #define GMRF_DMA_ATTR(BM, BN, BNAT, ST)                                                                          \
     if (e == hipSuccess)                                                                                          \
         e = hipFuncSetAttribute((const void*)gemm_f64_dma<BM, BN, BNAT, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)gemm_dma_lds_bytes<BM, BN>(ST));
+                                (int)gemm_dma_lds_bytes<BM, BN>(ST) + 64 * 1024);
     GMRF_DMA_ATTR(64, 64, false, 2) GMRF_DMA_ATTR(64, 64, true, 2) GMRF_DMA_ATTR(64, 64, false, 3) GMRF_DMA_ATTR(64, 64, true, 3)
     GMRF_DMA_ATTR(128, 64, false, 2) GMRF_DMA_ATTR(128, 64, true, 2) GMRF_DMA_ATTR(128, 64, false, 3) GMRF_DMA_ATTR(128, 64, true, 3)
     GMRF_DMA_ATTR(64, 128, false, 2) GMRF_DMA_ATTR(64, 128, true, 2) GMRF_DMA_ATTR(64, 128, false, 3) GMRF_DMA_ATTR(64, 128, true, 3)
@@ -349,7 +354,8 @@ inline bool gemm_try_dma(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, 
         const int64_t nx = g.N / BN, ny = g.M / BM;                                                               \
         const int64_t tiles = tri_grid ? (int64_t)(BM / BN > 0 ? BM / BN : 1) * ny * (ny + 1) / 2 : nx * ny;      \
         const dim3 grid((unsigned)(tiles * batch));                                                               \
-        const size_t lds = gemm_dma_lds_bytes<BM, BN>(stages);                                                    \
+        static const size_t lds_pad = [] { const char* e = getenv("GMRF_GEMM_DMA_LDS_PAD_KB"); return (size_t)(e ? atoi(e) : 0) * 1024; }();   /* tuning aid */ \
+        const size_t lds = gemm_dma_lds_bytes<BM, BN>(stages) + lds_pad;                                          \
         if (stages == 3) {                                                                                        \
             if (b_n) GMRF_DMA_K((gemm_f64_dma<BM, BN, true, 3>)); else GMRF_DMA_K((gemm_f64_dma<BM, BN, false, 3>)); \
         } else {                                                                                                  \

@@ -106,6 +106,13 @@ struct EvPair {
     hipEvent_t a, b;
     int kind;       // kernel class, see gmrf_stats
     double work;    // flops or bytes
+    int shape = -1; // GEMM launches: index into gmrf_handle::gemm_shapes
+};
+
+// one distinct GEMM launch shape of a profiled run (gmrf_test_gemm_shapes): the roofline table by shape
+struct GemmShapeStat {
+    int64_t key[8];     // class, M, N, K, tri, lower_only, problems, per-tile K bounds?
+    double launches = 0, ms = 0, work = 0;
 };
 
 struct gmrf_handle {
@@ -193,6 +200,7 @@ struct gmrf_handle {
     int profiling = 0;
     std::vector<EvPair> events;
     std::vector<hipEvent_t> ev_pool;
+    std::vector<GemmShapeStat> gemm_shapes;
     gmrf_stats stats;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -238,6 +246,7 @@ static void prof_collect(gmrf_handle* h) {
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, p.a, p.b);
         h->stats.kernel_ms[p.kind] += ms; h->stats.kernel_work[p.kind] += p.work; h->stats.kernel_launches[p.kind]++;
+        if (p.shape >= 0) { auto& g = h->gemm_shapes[(size_t)p.shape]; g.launches += 1; g.ms += ms; g.work += p.work; }
         h->ev_pool.push_back(p.a);
         h->ev_pool.push_back(p.b);
     }
@@ -276,6 +285,13 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
         EvPair p;
         p.kind = pclass; p.work = pwork >= 0.0 ? pwork : flops;
         p.a = ev_get(h); p.b = ev_get(h);
+        const int64_t key[8] = {pclass, M, N, K, tri, lower_only, batch * h->B, (kb_m || kb_n || ke_n) ? 1 : 0};
+        for (size_t i = 0; i < h->gemm_shapes.size() && p.shape < 0; ++i)
+            if (!memcmp(h->gemm_shapes[i].key, key, sizeof(key))) p.shape = (int)i;
+        if (p.shape < 0) {
+            GemmShapeStat st; memcpy(st.key, key, sizeof(key));
+            h->gemm_shapes.push_back(st); p.shape = (int)h->gemm_shapes.size() - 1;
+        }
         HIPCHK(launch_gemm(h->gemm_stream ? h->gemm_stream : h->stream, a_t, b_n, g, batch * (int)h->B, p.a, p.b));
         h->events.push_back(p);
         return GMRF_OK;
@@ -1395,6 +1411,7 @@ gmrf_status gmrf_bt_select_problem(gmrf_handle* h, int64_t p) {
 gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level) {
     if (!h) return bad_shape("null handle");
     h->profiling = level;
+    if (level > 0 && h->events.empty()) h->gemm_shapes.clear();
     for (int i = 0; i < GMRF_KERNEL_CLASSES; ++i) { h->stats.kernel_ms[i] = h->stats.kernel_work[i] = 0; h->stats.kernel_launches[i] = 0; }
     return GMRF_OK;
 }
@@ -3433,6 +3450,21 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
     HIPCHK(hipMemcpy(g_tile_stamps, dst, 16, hipMemcpyDeviceToHost));
     hipFree(dst);
     hipFree(dA); hipFree(dB); hipFree(dC);
+    return GMRF_OK;
+}
+
+// rows of 11 doubles per distinct GEMM launch shape seen while profiling was on: class, M, N, K, tri, lower_only, problems,
+// per-tile K bounds?, launches, ms, work (flops as booked in kernel_work).  *n_rows = rows available (may exceed cap_rows).
+gmrf_status gmrf_test_gemm_shapes(gmrf_handle* h, double* rows, int64_t cap_rows, int64_t* n_rows) {
+    if (!h || !n_rows) return bad_shape("null argument");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    prof_collect(h);
+    *n_rows = (int64_t)h->gemm_shapes.size();
+    for (int64_t i = 0; rows && i < std::min<int64_t>(cap_rows, *n_rows); ++i) {
+        const auto& g = h->gemm_shapes[(size_t)i];
+        for (int c = 0; c < 8; ++c) rows[i * 11 + c] = (double)g.key[c];
+        rows[i * 11 + 8] = g.launches; rows[i * 11 + 9] = g.ms; rows[i * 11 + 10] = g.work;
+    }
     return GMRF_OK;
 }
 

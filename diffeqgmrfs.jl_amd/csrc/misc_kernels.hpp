@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     double g[16];
     auto gather = [&](int c0) {
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc) g[cc] = (ucol >= 0) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
+        for (int cc = 0; cc < 16; ++cc)      // X = L^-1 is lower triangular: entries right of the diagonal are exact zeros, not fetched
+            g[cc] = (ucol >= 0 && ucol <= c0 + cc) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
     };
     gather(cbeg);
     for (int c0 = cbeg; c0 < cend; c0 += 16) {
@@ -328,11 +329,14 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
                 *reinterpret_cast<v2d*>(xs + t * 16 + 2 * (logical ^ swz)) = (v2d){g[2 * s2], g[2 * s2 + 1]};
             }
         }
-        __syncthreads();                                     // (first chunk: also the staged entries)
+        // (first chunk: also the staged entries.)  live = distinct columns <= c0 + 15, i.e. staged rows that are not all zero:
+        // the list is ascending and so are a row's entries, so a turn whose first index is >= live multiplies zeros only
+        const int live = __syncthreads_count(t < U && ucol <= c0 + 15);
         if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
         v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
         for (int e = pp[row]; e < pp[row + 1]; e += 8) {
             const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
+            if ((int)(q.x & 0xffffu) >= live) break;
             const double* ve = vs + e + 2 * row;
             const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
             const v2d v45 = *reinterpret_cast<const v2d*>(ve + 4), v67 = *reinterpret_cast<const v2d*>(ve + 6);

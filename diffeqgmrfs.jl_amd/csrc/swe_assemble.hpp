@@ -66,7 +66,9 @@ __global__ __launch_bounds__(256) void swe_p1_rows(SweP1Args a) {
         for (int v = 0; v < 3; ++v) { x[v] = lin_coord(nxs[v], a.nx); y[v] = lin_coord(nys[v], a.ny); }
         const double b[3] = {y[1] - y[2], y[2] - y[0], y[0] - y[1]};
         const double c[3] = {x[2] - x[1], x[0] - x[2], x[1] - x[0]};
-        const double area2 = x[0] * b[0] + x[1] * b[1] + x[2] * b[2];
+        // signed 2 |T| as the determinant of the cell Jacobian, (x1 - x0)(y2 - y0) - (x2 - x0)(y1 - y0) (what reinit! forms;
+        // sum_v x_v b_v is the same number with (n - 1)-fold cancellation: S ~ 1 / |T| would carry it)
+        const double area2 = c[2] * b[1] - c[1] * b[2];
         const double dO = 0.5 * fabs(area2) / 3.0;
         double gx[3], gy[3];
 #pragma unroll

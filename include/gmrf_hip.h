@@ -443,6 +443,9 @@ gmrf_status gmrf_test_gemm(int32_t device, int64_t M, int64_t N, int64_t K, int3
 gmrf_status gmrf_test_gemm_rate(int32_t device, int64_t M, int64_t N, int64_t K, int32_t transB,
                                 int32_t tri_flags, int32_t lower_only, int32_t batch,
                                 int32_t big, int32_t reps, double* ms_per_launch);
+/* GEMM launches of the profiled steps of a handle by shape (gmrf_bt_set_profiling on): rows of 11 doubles = class, M, N, K,
+ * tri flags, lower_only, problems, per-tile K bounds?, launches, ms (the dispatches' own time stamps), flops as booked. */
+gmrf_status gmrf_test_gemm_shapes(gmrf_handle* h, double* rows, int64_t cap_rows, int64_t* n_rows);
 gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64 /* in: SPD, out: L */,
                                  double* inv64, int32_t* info);
 gmrf_status gmrf_test_tile_timing(double* out, int32_t n);

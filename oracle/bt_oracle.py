@@ -502,7 +502,9 @@ def _p1_triangle_cells(nx: int, ny: int):
     X, Y = xs[cells % nx], ys[cells // nx]
     b = np.stack([Y[:, 1] - Y[:, 2], Y[:, 2] - Y[:, 0], Y[:, 0] - Y[:, 1]], axis=1)
     c = np.stack([X[:, 2] - X[:, 1], X[:, 0] - X[:, 2], X[:, 1] - X[:, 0]], axis=1)
-    area2 = X[:, 0] * b[:, 0] + X[:, 1] * b[:, 1] + X[:, 2] * b[:, 2]          # signed 2 |T|
+    # signed 2 |T| = det of the cell Jacobian (x1 - x0)(y2 - y0) - (x2 - x0)(y1 - y0), as reinit! forms it (the equivalent
+    # sum_v x_v b_v cancels (n - 1)-fold on this mesh, and S ~ 1 / |T| would carry that rounding)
+    area2 = c[:, 2] * b[:, 1] - c[:, 1] * b[:, 2]
     return cells, X, Y, b / area2[:, None], c / area2[:, None], 0.5 * np.abs(area2)
 
 

@@ -1352,9 +1352,23 @@ def test_shallow_water_element_kernels_on_device(pkg):
             pres = np.zeros(3 * nn, dtype=bool); pres[1::3] = bnd; pres[2::3] = bnd
         Ko, Mo, So = O.assemble_shallow_water_system(nx, ny, H, kk, ff, gg, prescribed=pres)
         kv, ml, sv = sw.assemble(H, k=kk, f=ff, g=gg, prescribed=pres)
-        assert np.max(np.abs(kv - Ko.data)) < 1e-14 * np.max(np.abs(Ko.data))
-        assert np.max(np.abs(sv - So.data)) < 1e-14 * np.max(np.abs(So.data))
-        assert np.max(np.abs(ml - Mo)) < 1e-14 * np.max(np.abs(Mo))
+        # element sums in a fixed order: 1e-14 of the largest entry (measured <= 2e-15).  The diagonal entries of prescribed
+        # dofs are meandiag, a sum over all 3 nn dofs that the device takes as a 256-way tree and NumPy pairwise: n eps at worst
+        tol_e = 1e-14
+        def close(dev, ora_data, pat):
+            err = np.abs(dev - ora_data)
+            big = np.max(np.abs(ora_data))
+            if pres is None:
+                print(f"shallow water {nx}x{ny}: max entry error {err.max() / big:.2e}")
+                return err.max() < tol_e * big
+            rows = np.repeat(np.arange(pat.shape[0]), np.diff(pat.indptr))
+            md = (rows == pat.indices) & pres[rows]
+            print(f"shallow water {nx}x{ny} constrained: entries {err[~md].max() / big:.2e}, meandiag {err[md].max() / big:.2e}")
+            return err[~md].max() < tol_e * big and err[md].max() < 3 * nn * EPS * big
+        assert close(kv, Ko.data, Ko) and close(sv, So.data, So)
+        mdm = np.zeros(3 * nn, dtype=bool) if pres is None else pres
+        assert np.max(np.abs(ml - Mo)[~mdm]) < tol_e * np.max(np.abs(Mo)) and np.max(np.abs(ml - Mo)) < 3 * nn * EPS * np.max(np.abs(Mo))
+        tol = tol_e if pres is None else 3 * nn * EPS
         # device-resident operands give the same bits
         Hd = torch.from_numpy(H).cuda()
         pd = None if pres is None else torch.from_numpy(pres.astype(np.uint8)).cuda()
@@ -1362,13 +1376,16 @@ def test_shallow_water_element_kernels_on_device(pkg):
         assert kd.is_cuda and np.array_equal(kd.cpu().numpy(), kv) and np.array_equal(md.cpu().numpy(), ml) and np.array_equal(sd.cpu().numpy(), sv)
         oo = O.shallow_water_operators(Ko, Mo, So, pres, kappa_matern=3.0, tau=0.7, dt=0.05)
         od = sw.operators(kd, md, sd, prescribed=pd, kappa_matern=3.0, tau=0.7, dt=0.05)
-        assert np.max(np.abs(od["G_dt"].cpu().numpy() - oo["G_dt"].data)) < 1e-14 * np.max(np.abs(oo["G_dt"].data))
-        assert np.max(np.abs(od["J"].cpu().numpy() - oo["J"].data)) < 1e-13 * np.max(np.abs(oo["J"].data))
+        # (SciPy's sparse sums drop the explicit zeros the patterns keep: compare as matrices)
+        Gd = sw.pattern_K.copy(); Gd.data = od["G_dt"].cpu().numpy()
+        Jd = sw.pattern_S.copy(); Jd.data = od["J"].cpu().numpy()
+        assert abs(Gd - oo["G_dt"]).max() < tol * abs(oo["G_dt"]).max()
+        assert abs(Jd - oo["J"]).max() < 1e-13 * abs(oo["J"]).max()
         assert np.max(np.abs(od["M_tilde"].cpu().numpy() - oo["M_tilde"])) < 1e-15
         assert np.max(np.abs(od["beta"].cpu().numpy() - oo["beta"])) < 1e-15
     # the initial precision of the space-time model, Q_0 = J'J (:187), assembled on the device from J's values and factored
     # by the block-tridiagonal path (96 x 96 nodes x 3 fields, node-major: 4 node rows per block -> 24 blocks of 1152)
-    J = sw.pattern_S.copy(); J.data = od["J"].cpu().numpy()
+    J = Jd
     Z = sp.csc_matrix((3 * nn, 3 * nn))
     asm = pkg.PosteriorAssembler(Z, J)
     q0 = asm.precision(np.zeros(0), J.data, 1.0)

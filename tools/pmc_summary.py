@@ -1,6 +1,6 @@
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB).
-FETCH_SIZE is doubled for the 16-byte-per-lane read streams of these kernels, as
-MI355X_MICROARCH.md (HBM section) prescribes for gfx950.  usage: pmc_summary.py fetch.csv write.csv [out.json]
+FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes for gfx950; tools/fetch_calib.hip measured the
+counter at 0.500 of the bytes read for 4-, 8- and 16-byte lanes and for a gather (profiles/r03_fetch_size_calibration.txt).  usage: pmc_summary.py fetch.csv write.csv [out.json]
 (out.json: {kernel symbol: corrected read + write bytes per launch}, read by bench.py for roofline.traffic)"""
 import csv, collections, json, sys
 
@@ -37,6 +37,11 @@ if len(sys.argv) > 3:
                               capture_output=True, text=True, timeout=5).stdout.strip() or os.environ.get("GMRF_HEAD", "?")
     except Exception:
         head = os.environ.get("GMRF_HEAD", "?")
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 for 16-byte lanes "
-                         "(MI355X_MICROARCH.md, HBM section); bench.py --steps 1 --warmup 1 --streams 1 --no-single-problem",
+    if head == "?":
+        try:
+            head = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_head")).read().strip() or "?"
+        except OSError:
+            pass
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section; "
+                         "calibrated: tools/fetch_calib.hip); bench.py --steps 1 --warmup 1 --streams 1 --no-single-problem",
                "batch": 32, "head": head, "kernels": table}, open(sys.argv[3], "w"), indent=1)

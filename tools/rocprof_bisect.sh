@@ -11,4 +11,3 @@ run() {
 run s4 --streams 4 --no-single-problem
 run s1_single --streams 1
 run s4_single --streams 4
-run s4_single_again --streams 4
