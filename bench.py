@@ -418,7 +418,8 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batched handles per GPU, each on its own HIP stream and host thread")
     ap.add_argument("--mode", choices=["auto", "problems", "shared-factor"], default="auto",
-                    help="auto: problems on one GPU, shared-factor on several")
+                    help="headline workload.  auto = problems: independent posteriors per rank at every N (the shared-factor job "
+                         "then runs as side legs at N > 1); shared-factor: rank 0 factors, broadcast, samples sharded")
     ap.add_argument("--shared-batch", type=int, default=32, help="posteriors per step whose factor is shared (N > 1)")
     ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
     ap.add_argument("--keep-l", action="store_true", help="retain the L blocks (F.chos); default: only Linv and C are stored")
@@ -480,8 +481,12 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
-    mode = args.mode if args.mode != "auto" else ("shared-factor" if world > 1 else "problems")
+    # Headline at every N: independent posteriors per rank (the BASELINE single-GPU config on every GPU, no data-path
+    # collective: ONE weak-scaling series).  The shared-factor job of north_star (rank 0 factors, the factor crosses xGMI,
+    # samples sharded) runs in the same invocation as side legs at N > 1; --mode shared-factor makes it the headline.
+    mode = args.mode if args.mode != "auto" else ("shared-factor" if args.force_shared else "problems")
     shared = mode == "shared-factor" and (world > 1 or args.force_shared)
+    shared_legs = (world > 1 or args.force_shared) and not args.no_side_legs       # the shared-factor job runs somewhere
     keep_l = bool(args.keep_l)
 
     def sync():
@@ -496,7 +501,7 @@ def main():
 
     # ------------------------------------------------------------------ transport of a shared factor
     comm, transport = None, "torch"
-    if shared:
+    if shared or shared_legs:
         want = args.transport
         if want in ("auto", "cabi") and not one_device:
             # Every rank takes part in every collective of the negotiation whatever fails where: rank 0 always
@@ -545,33 +550,40 @@ def main():
             res["receivers_max"] = {k: round(max(b[k] for b in recv), 3) for k in recv[0]}
         return res
 
-    if shared:
+    def run_shared(steps, warmup):
+        """The shared-factor job (north_star's split): per step rank 0 factors B posteriors, ranges of blocks cross xGMI as
+        packed images beside the factorisation, every rank takes the means and draws its own samples.  Returns the engine
+        (the regimes reuse it), seconds for `steps` steps (max over ranks), solves per step and what the line says about it."""
         B = max(1, args.shared_batch)
         vals = np.stack([w.Q.data * (1.0 + 0.01 * p) for p in range(B)])
         rhs = np.stack([w.rhs] * B)
-        eng, job = shared_job(w, B, args.samples, vals, rhs)
+        eng_s, job_s = shared_job(w, B, args.samples, vals, rhs)
 
         def run(first, count):
             for s in range(count):
-                job.step(first + s)
-        run(0, args.warmup)
-        eng.transport_bytes(reset=True)
-        elapsed = timed(run, sync, dist, torch, args.warmup, args.steps)
-        per_step = job.solves_per_step()
-        moved = eng.transport_bytes(reset=True) / max(args.steps, 1)
-        phases = gather_phases(job)
-        # what the N > 1 line is made of (no scaling curve has been measured on real multi-GPU hardware before the
-        # driver's SCALE run; these fields say which regime a record is in): the root factors, every range crosses xGMI
-        # as a packed image (lower-triangular tiles of Linv + the stored C windows), every rank samples.
-        extra["shared_factor"] = {
-            "bytes_broadcast_per_step": moved, "bytes_broadcast_per_posterior": moved / B,
-            "transport": transport, "phase_ms_last_step": phases,
-            "reading": "root-bound when root.factor_ms dominates ms_per_step; broadcast-bound when transfer_wait_ms does; "
-                       "the samples-per-factor regimes of side_legs.regimes show where sharing the factor pays"}
-        workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored by rank 0, "
-                    f"Linv / C ranges of {args.group} blocks broadcast (packed lower-triangular tiles) to {world} ranks beside the "
-                    f"factorisation, every rank: {B} mean(s) + {args.samples} samples per posterior")
-        sharding = f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), samples sharded by Philox sample id"
+                job_s.step(first + s)
+        run(0, warmup)
+        eng_s.transport_bytes(reset=True)
+        el = timed(run, sync, dist, torch, warmup, steps)
+        moved = eng_s.transport_bytes(reset=True) / max(steps, 1)
+        phases = gather_phases(job_s)
+        # (no scaling curve has been measured on real multi-GPU hardware before the driver's SCALE run; these fields say
+        # which regime a record is in)
+        rec = {"bytes_broadcast_per_step": moved, "bytes_broadcast_per_posterior": moved / B,
+               "transport": transport, "phase_ms_last_step": phases,
+               "reading": "root-bound when root.factor_ms dominates ms_per_step; broadcast-bound when transfer_wait_ms does; "
+                          "the samples-per-factor regimes of side_legs.regimes show where sharing the factor pays"}
+        wl = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored by rank 0, "
+              f"Linv / C ranges of {args.group} blocks broadcast (packed lower-triangular tiles) to {world} ranks beside the "
+              f"factorisation, every rank: {B} mean(s) + {args.samples} samples per posterior")
+        sh = (f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), "
+              f"samples sharded by Philox sample id")
+        return eng_s, el, job_s.solves_per_step(), rec, wl, sh
+
+    pj = None
+    if shared:
+        eng, elapsed, per_step, rec_s, workload, sharding = run_shared(args.steps, args.warmup)
+        extra["shared_factor"] = rec_s
     else:
         pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l,
                          args.eager_flags)
@@ -599,7 +611,7 @@ def main():
 
     # ------------------------------------------------------------------ N > 1: the other legs, same run
     watchdog = None
-    if shared and not args.no_side_legs:
+    if shared_legs:
         # The side legs never cost the headline: if they overrun (a rank stuck in a collective), every rank leaves
         # after --side-leg-limit seconds and rank 0 prints the line it already has.
         import threading
@@ -621,7 +633,16 @@ def main():
         watchdog = threading.Timer(args.side_leg_limit, give_up)
         watchdog.daemon = True
         watchdog.start()
-        # (a) the same job on ONE rank (no broadcast): what sharing the factor is compared with
+        if not shared:
+            # (s) north_star's split beside the headline: the shared-factor job at the headline's samples per posterior
+            leg["name"] = "shared_factor"
+            pj.close()                    # the headline's posteriors (streams x batch of them) leave the HBM first
+            pj = None
+            steps_s = max(2, args.steps // 4)
+            eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1)
+            if rank == 0:
+                side["shared_factor"] = dict({"value": per_s * steps_s / el_s, "unit": "solves/s", "ms_per_step": 1e3 * el_s / steps_s,
+                                              "steps": steps_s, "workload": wl_s, "sharding": sh_s}, **rec_s)
         # (r) the same shared-factor job at more samples per factor and rank: the factor (and its broadcast) is paid once
         # per posterior, the sample sweeps scale with the ranks -- which regime reaches what multiple of one rank
         leg["name"] = "regimes"
@@ -659,7 +680,7 @@ def main():
                        "note": f"rank 0 alone: factor + mean + {kr} samples per posterior, no broadcast"}
                 if kr == args.samples:
                     side["one_rank_same_job"] = rec
-                    rec["n_rank_over_one_rank"] = out["value"] / rec["value"]
+                    rec["n_rank_over_one_rank"] = (out["value"] if shared else side["shared_factor"]["value"]) / rec["value"]
                 else:
                     reg[str(kr)]["one_rank"] = rec
                     reg[str(kr)]["n_rank_over_one_rank"] = reg[str(kr)]["value"] / rec["value"]
@@ -688,19 +709,25 @@ def main():
             if rank == 0:
                 side["c4_elliptic512"] = {"error": repr(e)[:300]}
         sync()
-        # (c) independent problems per rank (the N = 1 line's mode): no data-path collective
-        leg["name"] = "problems_mode"
-        pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
-        pj.run(0, 1)
-        steps_p = max(2, args.steps // 4)
-        elp = timed(pj.run, sync, dist, torch, 1, steps_p)
+        if shared:
+            # (c) independent problems per rank (the default headline's mode): no data-path collective
+            leg["name"] = "problems_mode"
+            pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
+            pj.run(0, 1)
+            steps_p = max(2, args.steps // 4)
+            elp = timed(pj.run, sync, dist, torch, 1, steps_p)
+            if rank == 0:
+                side["problems_mode"] = {"value": world * pj.solves_per_step() * steps_p / elp, "unit": "solves/s",
+                                         "ms_per_step": 1e3 * elp / steps_p, "steps": steps_p,
+                                         "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
+            pj.close()
+            pj = None
         if rank == 0:
-            side["problems_mode"] = {"value": world * pj.solves_per_step() * steps_p / elp, "unit": "solves/s",
-                                     "ms_per_step": 1e3 * elp / steps_p, "steps": steps_p,
-                                     "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
             out["side_legs"] = side
-        pj.close()
         watchdog.cancel()
+    elif pj is not None and world > 1:
+        pj.close()
+        pj = None
 
     # ------------------------------------------------------------------ N = 1: per-kernel roofline + parity + CPU baseline
     if rank == 0 and world == 1 and not shared:

@@ -462,6 +462,20 @@ class ConditionedGMRF:
     def logdet(self) -> float:
         return self.F.logdet()
 
+    def sqmahal(self, z) -> float:
+        """`sqmahal(x_cond, z)` = (z - mean)' Q_post (z - mean) (scripts/burgers/solve_burgers_gmrf-collocation.jl:262):
+        one CSR SpMV of the posterior precision (K6) and a dot product."""
+        if self._csr is None:
+            self._csr = CsrMatrix(self.precision_matrix())
+        d = np.ascontiguousarray(np.asarray(z, dtype=np.float64) - np.asarray(self.mean()))
+        return float(d @ np.asarray(self._csr @ d))
+
+    def nll(self, z) -> float:
+        """Negative log-likelihood of z under the conditioned GMRF, `nll_soln` of the same script (:213-215):
+        0.5 (n log 2 pi + sqmahal + logdet Sigma), logdet Sigma = -logdet Q_post = -2 sum log diag L (:208-211)."""
+        n = self.asm.n
+        return 0.5 * (n * np.log(2.0 * np.pi) + self.sqmahal(z) - self.logdet())
+
 
 def condition_on_observations(Q, mu, A, q_eps: float, y, n_blocks: int, device: int = 0) -> ConditionedGMRF:
     """Python twin of the reference's `condition_on_observations(x, A, Q_eps, y)` for a GMRF

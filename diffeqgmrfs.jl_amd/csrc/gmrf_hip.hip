@@ -1038,6 +1038,8 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                     ta.uptr = h->d_bxt_uptr + i * (h->bxt_nrt + 1); ta.ucols = h->d_bxt_ucols;
                     ta.X = Xp; ta.C = C; ta.ld = ld; ta.ldc = ldc; ta.pX = pX; ta.pC = pC; ta.kst = h->d_kst;
                     ta.cm = cm; ta.rm = rm; ta.bsp = bsp; ta.ecap = h->bxt_ecap;
+                    static const bool live_skip = [] { const char* e = getenv("GMRF_BXT_LIVE"); return e && atoi(e) != 0; }();   // tuning aid (measured: 4.1 vs 3.9 ms per step, off)
+                    ta.skip_dead = live_skip ? 1 : 0;
                     const int chunks = W / 16, nrt = rm / 64;
                     ta.nch = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)chunks * nrt * nb / 512));
                     const int ncg = (chunks + ta.nch - 1) / ta.nch;

@@ -245,6 +245,7 @@ struct BxtTileArgs {
     int cm, rm, bsp;
     int nch;                  // 16-column chunks per workgroup
     int ecap;                 // padded entries per tile (LDS capacity, multiple of 8)
+    int skip_dead;            // leave a row's multiply loop at the first turn that only meets zero rows of the staged image
 };
 
 constexpr int BXT_UCAP = 256;             // distinct columns per tile (one per thread)
@@ -331,7 +332,9 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         }
         // (first chunk: also the staged entries.)  live = distinct columns <= c0 + 15, i.e. staged rows that are not all zero:
         // the list is ascending and so are a row's entries, so a turn whose first index is >= live multiplies zeros only
-        const int live = __syncthreads_count(t < U && ucol <= c0 + 15);
+        int live = 1 << 30;
+        if (a.skip_dead) live = __syncthreads_count(t < U && ucol <= c0 + 15);
+        else __syncthreads();
         if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
         v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
         for (int e = pp[row]; e < pp[row + 1]; e += 8) {

@@ -34,7 +34,7 @@ import GaussianMarkovRandomFields: AbstractSolver, AbstractSolverBlueprint, cons
                                    construct_conditional_solver, compute_mean, compute_variance, compute_rand!,
                                    gmrf_precision, to_matrix
 
-export BlockTridiagonalSolverBlueprint, BlockTridiagonalSolver, gn_step!
+export BlockTridiagonalSolverBlueprint, BlockTridiagonalSolver, gn_step!, sqmahal, nll
 
 """
     BlockTridiagonalSolverBlueprint(N_blocks; var_strategy = :exact, n_var_samples = 50, seed = 0x5EED, device = 0, keep_l = false)
@@ -131,6 +131,17 @@ end
 
 "log det of the precision: 2 sum log diag(L_i) (scripts/burgers/solve_burgers_gmrf-collocation.jl:208-211)."
 LinearAlgebra.logdet(s::BlockTridiagonalSolverState) = logdet(_live(s).precision_chol)
+
+"`sqmahal(x, z)` = (z - mean)' Q (z - mean) (scripts/burgers/solve_burgers_gmrf-collocation.jl:262): one CSR SpMV on the device (K6) and a dot product."
+function sqmahal(s::BlockTridiagonalSolverState, z::AbstractVector)
+    _live(s)
+    s.csr === nothing && (s.csr = HIP.GmrfCsr(s.precision; device = s.bp.device))
+    d = Vector{Float64}(z) .- s.mean
+    return dot(d, s.csr * d)
+end
+
+"Negative log-likelihood of z, `nll_soln` of the same script (:213-215): 0.5 (n log 2pi + sqmahal + logdet Sigma), logdet Sigma = -logdet Q."
+nll(s::BlockTridiagonalSolverState, z::AbstractVector) = 0.5 * (length(z) * log(2pi) + sqmahal(s, z) - logdet(s))
 
 """
     gn_step!(s, Q, Qx_prior, J, x, obs_diff, noise)  ->  new iterate

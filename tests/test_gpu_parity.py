@@ -718,6 +718,13 @@ def test_condition_on_observations_problem_loop(pkg):
     X = x.rand(8, seed=5)
     Z = x.F.normals(8, seed=5)
     assert rel(X, O.sample(Fo, mu_o, Z)) < solve_tol(w)
+    # sqmahal / nll of a field under the conditioned GMRF (scripts/burgers/solve_burgers_gmrf-collocation.jl:208-215, :262)
+    zt = mu_o + 0.1 * np.random.default_rng(9).standard_normal(mu_o.size)
+    dz = zt - mu_o
+    sq_o = float(dz @ (Qp @ dz))
+    assert abs(x.sqmahal(zt) - sq_o) < 1e-9 * sq_o          # (the device mean differs from the oracle's by solve_tol)
+    nll_o = 0.5 * (mu_o.size * np.log(2.0 * np.pi) + sq_o - O.logdet(Fo))
+    assert abs(x.nll(zt) - nll_o) < 1e-9 * abs(nll_o)
     # next problem: new coefficient field, same pattern -> values only
     x.update(A2.data, y2)
     Qp2, Fo2, mu2 = O.condition_on_observations(Q0, None, A2, 1e8, y2, N)

@@ -322,3 +322,16 @@ def test_host_side_under_address_sanitizer(pkg, tmp_path):
                        capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
     assert p.returncode == 0 and "asan driver ok" in p.stdout and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, \
         (p.returncode, p.stdout[-500:], p.stderr[-3000:])
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_the_launcher():
+    """bench.py under a launcher (WORLD_SIZE set): --gpus that differs from it is a configuration error, exit code 2,
+    before anything touches a GPU; so is a launcher-less environment asking for ranks it is not given (no WORLD_SIZE
+    and --gpus 1 is the plain single-GPU run and is not exercised here: it needs the GPU)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr and p.stdout.strip() == ""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 2          # default --gpus 1 under a 2-rank launcher
