@@ -770,7 +770,7 @@ class TridiagonalCholeskyFactor:
         self._set_shape(n, n_blocks)
 
     def get_layout(self) -> np.ndarray:
-        """Layout record of the stored coupling blocks: [cmin, rmax, n_row_tiles, kst...] (int64)."""
+        """Layout record of the stored factor: [cmin, rmax, n_row_tiles, kst..., split p of the block inverses (0: full)] (int64)."""
         cnt = C.c_int64(0)
         _cabi.check(self._lib.gmrf_bt_get_layout(self._h, None, 0, C.byref(cnt)))
         out = np.zeros(cnt.value, dtype=np.int64)

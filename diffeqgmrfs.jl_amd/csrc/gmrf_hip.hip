@@ -182,6 +182,13 @@ struct gmrf_handle {
     bool no_staircase = false;         // treat the coupling window as dense (comparison; takes effect at the next analysis)
     bool left_looking = false;         // batches: left-looking in-panel steps (tile + potrf_panel_ll) instead of tile, panel, update
     bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
+    // Split representation of the block inverses (batches whose coupling blocks are zero left of column cmin >= 256):
+    // with p = xsplit, a = [0, p), b = [p, bsp), the storage of Linv_i holds X_aa, X_bb and -- in the place of
+    // X_ba = -X_bb L_ba X_aa -- the factor's own L_ba.  C_i = B_i Linv_{i-1}^T reads X_bb only; the sweeps apply
+    // y_a = X_aa t_a, y_b = X_bb (t_b - L_ba y_a) (and the transposed order backward).  0: the full inverse.
+    int xsplit = 0;                    // state of the stored factor
+    int adopt_xsplit = 0;              // what the layout record of an adopted factor said (committed by gmrf_bt_adopt_commit)
+    bool no_xsplit = false;            // set_eager bit 12: always assemble the full inverse (comparison)
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
     bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
     bool panels128 = false;            // batches: rows below a diagonal block meet the 128 x 128 inverses one by one (K = 128 products; comparison)
@@ -683,13 +690,26 @@ static gmrf_status load_values(gmrf_handle* h, const double* nzval) {
 // ------------------------------------------------------------------------------------ numeric factor
 // Recursive doubling  X21 = -X22 (L21 X11)  over pairs of hh-wide diagonal blocks, levels hh = lo .. hi.
 // half: -1 all pairs, 0 / 1 only the pairs inside the first / second half of the block.
-static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double* T, int lo, int hi, int half) {
+static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double* T, int lo, int hi, int half, int split = 0) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
     const int64_t pL = stride_pL(h), pX = stride_pX(h), pW = (int64_t)bsp * bsp;
     for (int hh = lo; hh <= hi && hh < bsp; hh *= 2) {
         int pairs = bsp / (2 * hh), first = 0;
         if (half >= 0) { pairs /= 2; first = half * pairs; }
+        if (split > 0 && hh >= split) {
+            // split representation (split = p, a power of two): the first block column [0, p) of the rows >= p is not
+            // assembled.  Level p: the first pair IS that part; above: the first pair keeps its columns [p, hh) --
+            // T[:, p:hh] = L21[:, p:hh] X11[p:hh, p:hh],  X21[:, p:hh] = -X22 T[:, p:hh]
+            if (hh > split) {
+                const int q = split, w = hh - q;
+                GCHK(gemm(h, false, true, hh, w, w, TRI_B_LOWER, 0, 1.0, L + (int64_t)hh * ld + q, ld, X + (int64_t)q * ld + q, ld, 0.0,
+                          T + (int64_t)hh * ld + q, ld, pL, pX, pW));
+                GCHK(gemm(h, false, true, hh, w, hh, TRI_A_LOWER, 0, -1.0, X + (int64_t)hh * ld + hh, ld, T + (int64_t)hh * ld + q, ld, 0.0,
+                          X + (int64_t)hh * ld + q, ld, pX, pW, pX));
+            }
+            first = 1; pairs -= 1;
+        }
         if (pairs <= 0) continue;
         const int64_t st = (int64_t)2 * hh * ld + 2 * hh, o = first * st;
         // T21 = L21 * X11
@@ -726,6 +746,19 @@ static gmrf_status fork_event(gmrf_handle* h, hipEvent_t* out) {
     return GMRF_OK;
 }
 
+// The split the next factorisation of this handle will use (0: none): only the 256-column panel route of batches
+// assembles the inverse level by level, and only a coupling window that starts at cmin >= 256 leaves a first block
+// column nobody multiplies with.  p = the largest power of two <= cmin (the doubling tree splits at powers of two).
+static int planned_xsplit(const gmrf_handle* h) {
+    const int bsp = (int)h->bsp, nt = bsp / 64;
+    if (h->no_xsplit || h->N <= 0 || nt < 8 || nt % 4 != 0) return 0;
+    const bool lone_fused = (h->B == 1 && !h->split_step);
+    if (lone_fused || h->left_looking || h->rank64_panels || h->panels128 || h->fork_graph) return 0;
+    int p = 256;
+    while (2 * p <= (int)h->cmin) p *= 2;
+    return (h->cmin >= 256 && p < bsp) ? p : 0;
+}
+
 static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, double* T, int blk_id) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
@@ -737,6 +770,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // one-launch step (43 ms against 48 ms on darcy256); beyond that the fused step's redundant
     // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
     const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
+    if (h->xsplit > 0 && (h->B == 1 && !h->split_step)) return bad_shape("internal: split inverse planned for the one-problem route");
     static const int pw_env = [] { const char* e = getenv("GMRF_PANEL_TILES"); return e ? atoi(e) : 4; }();   // tuning aid
     const int pw = (!fused && nt >= 8) ? ((pw_env == 2 || pw_env == 8) ? pw_env : 4) : nt;           // panel width in tiles
     // a lone problem with larger blocks: two-level, with the fused kernel restricted to the panel's
@@ -859,8 +893,15 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             GCHK(gemm(h, false, false, m3 * 64, m3 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + oc * ld + oc, ld, sa.pL, sa.pL, sa.pS,
                       1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m3 * (m3 + 1) / 2) * nb));
         }
-        // X = L^-1 by recursive doubling over the 256-wide diagonal inverses
-        GCHK(doubling_levels(h, L, X, T, 256, bsp / 2, -1));
+        // X = L^-1 by recursive doubling over the 256-wide diagonal inverses -- or, split representation, everything
+        // but its first block column below row p, whose place L[p:, 0:p] takes (see gmrf_handle::xsplit)
+        const int p = h->xsplit;
+        GCHK(doubling_levels(h, L, X, T, 256, bsp / 2, -1, p));
+        if (p > 0) {
+            hipLaunchKernelGGL(copy_rect, dim3((unsigned)((bsp - p) / 4), (unsigned)h->B), dim3(256), 0, h->stream,
+                               L + (int64_t)p * ld, ld, sa.pL, X + (int64_t)p * ld, ld, sa.pX, bsp - p, p);
+            HIPCHK(hipGetLastError());
+        }
         return GMRF_OK;
     }
     for (int j = 0; j < nt; ++j) {
@@ -982,6 +1023,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
 
 static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     const int bsp = (int)h->bsp;
+    h->xsplit = planned_xsplit(h);                     // representation of the inverses this factorisation leaves
     const int64_t ld = bsp;
     const size_t blk_bytes = (size_t)bsp * bsp * sizeof(double) * (size_t)h->B;
     const int64_t bstride = (int64_t)bsp * bsp;
@@ -1083,6 +1125,23 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
     return GMRF_OK;
 }
 
+// Split representation -> full inverse, in place, every block and problem: X_ba = -X_bb (L_ba X_aa) takes L_ba's place.
+// Needed by whoever reads Linv_i as a matrix (selected inversion, gmrf_bt_get_block / export); the sweeps and the
+// coupling products never are.  The factor stays full until the next factorisation.
+static gmrf_status ensure_full_inverse(gmrf_handle* h) {
+    if (h->xsplit <= 0) return GMRF_OK;
+    const int bsp = (int)h->bsp, p = h->xsplit, q = bsp - p;
+    const int64_t ld = bsp, bstride = (int64_t)bsp * bsp, pX = stride_pX(h), pW = bstride;
+    for (int64_t i = 0; i < h->N; ++i) {
+        double* X = h->d_Linv + i * bstride;
+        double* T = h->d_T + (int64_t)p * ld;
+        GCHK(gemm(h, false, true, q, p, p, TRI_B_LOWER, 0, 1.0, X + (int64_t)p * ld, ld, X, ld, 0.0, T, ld, pX, pX, pW));
+        GCHK(gemm(h, false, true, q, p, q, TRI_A_LOWER, 0, -1.0, X + (int64_t)p * ld + p, ld, T, ld, 0.0, X + (int64_t)p * ld, ld, pX, pW, pX));
+    }
+    h->xsplit = 0;
+    return GMRF_OK;
+}
+
 // Stream captures of different handles (host threads) are taken one at a time: capture + instantiate is a
 // once-per-shape set-up step, and concurrent captures are the one place where handles would meet inside the runtime.
 static std::mutex g_capture_mu;
@@ -1104,6 +1163,7 @@ static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
         (void)hipGraphDestroy(graph);
         h->factor_graph_i0 = i0; h->factor_graph_i1 = i1;
     }
+    h->xsplit = planned_xsplit(h);                     // (what the captured launches produce)
     HIPCHK(hipGraphLaunch(h->factor_graph, h->stream));
     return GMRF_OK;
 }
@@ -1266,7 +1326,37 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
         // y_i = Linv_i T   /   x_i = Linv_i^T T
         const double* X = h->d_Linv + i * bstride;
         double* yout = Yout + i * bsp;
-        if (via_gemm) {
+        if (h->xsplit > 0) {
+            // split representation: [X_aa 0; L_ba X_bb] in the block's storage.  forward: y_a = X_aa t_a, t_b -= L_ba y_a,
+            // y_b = X_bb t_b;  backward: x_b = X_bb^T t_b, t_a -= L_ba^T x_b, x_a = X_aa^T t_a.  Same bytes, same flops.
+            const int p = h->xsplit, q = bsp - p;
+            const double* Xbb = X + (int64_t)p * ld + p;
+            const double* Lba = X + (int64_t)p * ld;
+            for (int part = 0; part < 3; ++part) {
+                const int which = backward ? 2 - part : part;          // 0: aa, 1: ba, 2: bb
+                if (via_gemm) {
+                    if (which == 0)
+                        GCHK(gemm(h, false, backward, kp, p, p, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs, npad, X, ld, 0.0, yout, npad,
+                                  pPanel, pX, pPanel));
+                    else if (which == 2)
+                        GCHK(gemm(h, false, backward, kp, q, q, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs + p, npad, Xbb, ld, 0.0,
+                                  yout + p, npad, pPanel, pX, pPanel));
+                    else if (!backward)
+                        GCHK(gemm(h, false, false, kp, q, p, 0, 0, -1.0, yout, npad, Lba, ld, 1.0, rhs + p, npad, pPanel, pX, pPanel));
+                    else
+                        GCHK(gemm(h, false, true, kp, p, q, 0, 0, -1.0, yout + p, npad, Lba, ld, 1.0, rhs, npad, pPanel, pX, pPanel));
+                } else {
+                    s.ld = ld; s.ldx = npad; s.ldo = npad; s.pMat = pX; s.pXin = pPanel; s.pOut = pPanel; s.kst = nullptr; s.mend = nullptr;
+                    if (which == 0) { s.Mat = X; s.Xin = rhs; s.Bin = nullptr; s.ldb = 0; s.Out = yout; s.rows = p; s.kdim = p; s.sub = 0; s.pBin = 0; }
+                    else if (which == 2) { s.Mat = Xbb; s.Xin = rhs + p; s.Bin = nullptr; s.ldb = 0; s.Out = yout + p; s.rows = q; s.kdim = q; s.sub = 0; s.pBin = 0; }
+                    else if (!backward) { s.Mat = Lba; s.Xin = yout; s.Bin = rhs + p; s.ldb = npad; s.Out = rhs + p; s.rows = q; s.kdim = p; s.sub = 1; s.pBin = pPanel; }
+                    else { s.Mat = Lba; s.Xin = yout + p; s.Bin = rhs; s.ldb = npad; s.Out = rhs; s.rows = p; s.kdim = q; s.sub = 1; s.pBin = pPanel; }
+                    const double frac = which == 0 ? (double)p * (p + 1) : (which == 2 ? (double)q * (q + 1) : 2.0 * p * q);
+                    ProfScope ps(h, pclass, blk_work_t * frac / ((double)bsp * (bsp + 1)));
+                    HIPCHK(launch_sweep(h->stream, backward, which != 1, kp, s, nprob));
+                }
+            }
+        } else if (via_gemm) {
             // forward: Linv stored [m][k], zero for k > m; backward: Linv^T, stored [k][m], zero for k < m
             GCHK(gemm(h, false, backward, kp, bsp, bsp, backward ? TRI_B_LOWER : TRI_B_UPPER, 0, 1.0, rhs, npad, X, ld, 0.0,
                       yout, npad, pPanel, pX, pPanel, 1, 0, 0, 0, nullptr, 0, 0, 0, -1.0));
@@ -1291,7 +1381,7 @@ static gmrf_status run_sweeps(gmrf_handle* h, int mode, int kp) {
         return sweep_launches(h, true, kp, h->d_Y, h->d_P);
     };
     if (h->eager || h->profiling) return body();
-    const int64_t key = (int64_t)mode * 4096 + kp;
+    const int64_t key = ((int64_t)h->xsplit << 32) | ((int64_t)mode * 4096 + kp);       // (the representation decides the launches)
     auto it = h->sweep_graphs.find(key);
     if (it == h->sweep_graphs.end()) {
         std::lock_guard<std::mutex> capture_lock(g_capture_mu);
@@ -1431,6 +1521,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 512) != 0) != h->update_via_gemm) { destroy_graphs(h); h->update_via_gemm = (eager & 512) != 0; }
     if (((eager & 1024) != 0) != h->rank64_panels) { destroy_graphs(h); h->rank64_panels = (eager & 1024) != 0; }
     if (((eager & 2048) != 0) != h->panels128) { destroy_graphs(h); h->panels128 = (eager & 2048) != 0; }
+    if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -1589,11 +1680,13 @@ gmrf_status gmrf_bt_get_layout(gmrf_handle* h, int64_t* out, int64_t cap, int64_
     if (!h || !count) return bad_shape("null pointer");
     if (h->N <= 0 || h->kst.empty()) { g_last_error = "no shape"; return GMRF_ERR_NO_FACTOR; }
     const int64_t nrt = h->rmax / 64;
-    *count = 3 + nrt;
+    *count = 4 + nrt;
     if (!out) return GMRF_OK;
-    if (cap < 3 + nrt) return bad_shape("layout buffer too small");
+    if (cap < 4 + nrt) return bad_shape("layout buffer too small");
     out[0] = h->cmin; out[1] = h->rmax; out[2] = nrt;
     for (int64_t t = 0; t < nrt; ++t) out[3 + t] = h->kst[(size_t)t];
+    // representation of the block inverses (gmrf_handle::xsplit): of the stored factor, or what the next factorisation will leave
+    out[3 + nrt] = h->factored ? h->xsplit : planned_xsplit(h);
     return GMRF_OK;
 }
 
@@ -1609,8 +1702,15 @@ gmrf_status gmrf_bt_adopt_layout(gmrf_handle* h, int64_t n, int64_t n_blocks, co
         std::vector<int64_t> first((size_t)layout[2]);
         for (int64_t t = 0; t < layout[2]; ++t) first[(size_t)t] = layout[0] + layout[3 + t];
         GCHK(set_layout(h, layout[0], layout[1], first));
+        h->adopt_xsplit = 0;
+        if (count >= 4 + layout[2]) {
+            const int64_t xs = layout[3 + layout[2]];
+            if (xs < 0 || xs >= h->bsp || xs % 64) return bad_shape("bad layout record (split)");
+            h->adopt_xsplit = (int)xs;
+        }
     } else {
         GCHK(set_layout_dense(h));
+        h->adopt_xsplit = 0;
     }
     GCHK(alloc_factor(h));
     if (h->c_dirty) {
@@ -1631,6 +1731,7 @@ gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
 gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid) {
     if (!h || !h->d_Linv) return bad_shape("no factor storage");
     h->factored = true;
+    h->xsplit = h->adopt_xsplit;
     h->l_valid = l_blocks_valid != 0 && h->keep_l;
     // the log-determinant parts travel inside the packed transport image (gmrf_bt_unpack_blocks_async): valid once
     // every block of this factor came that way; a factor moved as raw buffers has none (logdet then needs the L blocks)
@@ -1760,6 +1861,7 @@ gmrf_status gmrf_bt_get_block(gmrf_handle* h, int32_t kind, int64_t i, double* o
         src = h->d_L + h->sel * stride_pL(h) + i * blk_elems(h);
     } else if (kind == GMRF_BLOCK_LINV) {
         if (i < 0 || i >= h->N) return bad_shape("block index");
+        GCHK(ensure_full_inverse(h));
         src = h->d_Linv + h->sel * stride_pX(h) + i * blk_elems(h);
     } else if (kind == GMRF_BLOCK_C) {
         if (i < 0 || i >= h->N - 1) return bad_shape("block index");
@@ -1868,6 +1970,7 @@ gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes
     in += (N - 1) * be;
     for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_Linv + h->sel * stride_pX(h) + i * blk_elems(h), true));
     h->factored = true; h->l_valid = true;
+    h->xsplit = 0;                                     // the image holds the full inverses
     return GMRF_OK;
 }
 
@@ -3228,6 +3331,7 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp;
     const int64_t pX = stride_pX(h), pCm = stride_pC(h), pW = bstride;
     const int cm = (int)h->cmin, rm = (int)h->rmax, wc = bsp - cm;
+    GCHK(ensure_full_inverse(h));
     double* Sg = h->d_S;     // current Sigma_{i+1,i+1}
     double* G = h->d_B;
     double* Hm = h->d_T;

@@ -367,6 +367,16 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     }
 }
 
+// rows x cols rectangle of doubles (cols a multiple of 2, 16-byte aligned rows), one wave per row, blockIdx.y = problem
+__global__ __launch_bounds__(256) void copy_rect(const double* __restrict__ src, int64_t lds, int64_t ps, double* __restrict__ dst,
+                                                 int64_t ldd, int64_t pd, int rows, int cols) {
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6), lane = (int)threadIdx.x & 63;
+    if (row >= rows) return;
+    const double* s = src + (int64_t)blockIdx.y * ps + (int64_t)row * lds;
+    double* d = dst + (int64_t)blockIdx.y * pd + (int64_t)row * ldd;
+    for (int c = 2 * lane; c < cols; c += 128) *reinterpret_cast<v2d*>(d + c) = *reinterpret_cast<const v2d*>(s + c);
+}
+
 // ------------------------------------------------------------------------------- K6
 // CSR SpMV/SpMM  Y = S X, X and Y stored one right-hand side after the other (strides
 // ldx/ldy).  Replaces SparseArrays' `Q * x` (scripts/solve_burger.jl:157-158,166,177 and the

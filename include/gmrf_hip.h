@@ -187,10 +187,16 @@ gmrf_status gmrf_bt_export_factor(gmrf_handle* h, void* host_buf, int64_t bytes)
 gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* host_buf, int64_t bytes);
 
 /* Storage of the factor on the device (all fp64, row-major blocks padded to bsp = 64 * 2^p):
- *   LINV  [batch][N][bsp][bsp]      Linv_i = inv(chos[i].L), lower triangular -- what the sweeps stream
+ *   LINV  [batch][N][bsp][bsp]      Linv_i = inv(chos[i].L), lower triangular -- what the sweeps stream.
+ *         SPLIT representation (batches whose coupling window starts at cmin >= 256; p = the largest power of two
+ *         <= cmin): with a = [0, p), b = [p, bsp) the block holds X_aa, X_bb and, where X_ba = -X_bb L_ba X_aa would
+ *         be, the factor's own L_ba -- nobody multiplies with X_ba (C_i = B_i Linv_{i-1}^T reads X_bb only), and the
+ *         sweeps apply X_aa, L_ba, X_bb in turn (same bytes, same flops).  gmrf_bt_get_block(LINV), export and the
+ *         exact variances convert the factor to the full inverse in place; the last entry of the layout record says
+ *         which form a factor is in (0: full).
  *   C     [batch][N-1][rmax][bsp - cmin]   the non-zero WINDOW of Cs[i]: rows 0 .. rmax, columns cmin ..
  *         (a FEM coupling block is zero outside it; inside, row tile t is zero left of cmin + kst[t]).
- *         The layout record {cmin, rmax, n_row_tiles, kst[...]} comes from the symbolic phase
+ *         The layout record {cmin, rmax, n_row_tiles, kst[...], split p} comes from the symbolic phase
  *         (gmrf_bt_get_layout) and travels with a broadcast factor (gmrf_bt_adopt_layout).
  *   L     [batch][N][bsp][bsp]      chos[i].L -- only F.chos / export / logdet read it.  With
  *         gmrf_bt_set_keep_l(h, 0) L_i lives in a one-block work buffer (log-determinant parts are taken
@@ -306,7 +312,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain; bit 10: batches
  * factor a block by 64-column steps (tile, potrf_panel, potrf_update: the round-2 path) instead of 128-column diagonal
  * blocks with GEMM panels (comparison); bit 11: the rows below a 256-column panel meet its two 128 x 128 inverses one after the
- * other (three K = 128 products per panel) instead of the panel's 256 x 256 inverse in one K = 256 product (comparison). */
+ * other (three K = 128 products per panel) instead of the panel's 256 x 256 inverse in one K = 256 product (comparison);
+ * bit 12: batches always assemble the full block inverses (no split representation; comparison). */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 

@@ -531,7 +531,7 @@ bcast_host!(c::GmrfComm, a::Array, root::Integer = 0) =
 allreduce_sum!(c::GmrfComm, F::TridiagonalCholeskyFactor, dev_ptr::Ptr{Float64}, count::Integer) =
     check(ccall((:gmrf_comm_allreduce_sum, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Float64}, Int64), c.handle, F.handle, dev_ptr, count))
 
-"Layout record of the stored coupling blocks: [cmin, rmax, n_row_tiles, kst...]."
+"Layout record of the stored factor: [cmin, rmax, n_row_tiles, kst..., split p of the block inverses (0: full)]."
 function get_layout(F::TridiagonalCholeskyFactor)
     cnt = Ref{Int64}(0)
     check(ccall((:gmrf_bt_get_layout, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ref{Int64}), F.handle, C_NULL, 0, cnt))

@@ -861,9 +861,10 @@ def test_staircase_of_the_coupling_blocks_is_exact(pkg):
         Fd.set_eager(32)
         Fd.factor(w.Q, w.n_blocks)
         lay_s, lay_d = Fs.get_layout(), Fd.get_layout()
-        assert tuple(lay_s[:3]) == tuple(lay_d[:3]) and np.all(lay_d[3:] == 0) and np.all(np.diff(lay_s[3:]) >= 0)
+        # record = [cmin, rmax, row tiles, kst..., split of the inverses (0 here: one problem)]
+        assert tuple(lay_s[:3]) == tuple(lay_d[:3]) and np.all(lay_d[3:] == 0) and np.all(np.diff(lay_s[3:-1]) >= 0) and lay_s[-1] == 0
         if name == "darcy64":                       # 4 node rows of 64 per block, reach 3 rows: tile a starts at column 64 (a + 1)
-            assert list(lay_s) == [64, 192, 3, 0, 64, 128]
+            assert list(lay_s) == [64, 192, 3, 0, 64, 128, 0]
         for i in (0, w.n_blocks // 2, w.n_blocks - 1):
             assert np.array_equal(Fs.chos[i], Fd.chos[i])
             assert np.array_equal(Fs.get_block(pkg._cabi.BLOCK_LINV, i), Fd.get_block(pkg._cabi.BLOCK_LINV, i))
@@ -1435,3 +1436,76 @@ def test_burgers_p2_tangent_on_device(pkg):
     rhs = np.random.default_rng(1).standard_normal(n)
     x = pkg.ldiv(F, rhs)
     assert np.linalg.norm(A @ x - rhs) / (abs(A).sum(axis=1).max() * np.linalg.norm(x) + np.linalg.norm(rhs)) < 1e-14
+
+
+def test_split_inverse_representation_of_batches(pkg):
+    """Round 3: batches whose coupling blocks are zero left of column cmin >= 256 (darcy256: 256) do not assemble the
+    first block column of Linv_i below row p = 256 -- C_i = B_i Linv_{i-1}^T never multiplies with it -- and keep the
+    factor's own L[p:, 0:p] in its place; the sweeps apply X_aa, L_ba, X_bb one after the other.  Against the full
+    representation (set_eager bit 12) on the leading 8 blocks of darcy256, batch 8, and against the oracle: same factor
+    (log-determinants bitwise), means / samples / variances to rounding, fewer GEMM flops; Linv_i as a matrix
+    (gmrf_bt_get_block) converts the factor to the full form; the layout record and the packed transport image carry the
+    representation to another handle."""
+    import torch
+    w, vals_full, rhs_full = _darcy_batch(pkg, 256, 8)
+    nb = 8
+    ns = nb * w.block_size
+    Q0 = w.Q.tocsr()[:ns, :ns].tocsc(); Q0.sort_indices()
+    vals, rhs = [], []
+    for p in range(8):
+        Qp = w.Q.copy(); Qp.data = vals_full[p].copy()
+        Qp = Qp.tocsr()[:ns, :ns].tocsc(); Qp.sort_indices()
+        vals.append(Qp.data); rhs.append(rhs_full[p][:ns])
+    vals, rhs = np.stack(vals), np.stack(rhs)
+    rhs_t = torch.from_numpy(rhs[:, None, :]).cuda()
+    Fs = pkg.TridiagonalCholeskyFactor(batch=8); Fs.set_keep_l(False)
+    Ff = pkg.TridiagonalCholeskyFactor(batch=8); Ff.set_keep_l(False); Ff.set_eager(4096)
+    for F in (Fs, Ff):
+        F.set_profiling(1)
+        F.factor(Q0, nb, values=vals)
+    assert Fs.get_layout()[-1] == 256 and Ff.get_layout()[-1] == 0
+    fl = lambda F: sum(F.stats()["kernel_work"][c] for c in (13, 14, 15))
+    assert fl(Fs) < 0.9 * fl(Ff)                               # the top doubling level does half the work, level 256 one pair less
+    for F in (Fs, Ff):
+        F.set_profiling(0)
+    mu_s, mu_f = Fs.solve_batch(rhs_t)[:, 0, :], Ff.solve_batch(rhs_t)[:, 0, :]
+    assert float((mu_s - mu_f).norm() / mu_f.norm()) < 1e-12
+    Xs = Fs.sample_batch(64, mean=mu_s, seed=11, like=rhs_t)   # k = 64: the GEMM route of the sweeps
+    Xf = Ff.sample_batch(64, mean=mu_s, seed=11, like=rhs_t)
+    assert float((Xs - Xf).norm() / Xf.norm()) < 1e-12
+    X16s = Fs.sample_batch(16, mean=mu_s, seed=11, like=rhs_t)  # k = 16: sweep_mm
+    X16f = Ff.sample_batch(16, mean=mu_s, seed=11, like=rhs_t)
+    assert float((X16s - X16f).norm() / X16f.norm()) < 1e-12
+    for p in (0, 5):
+        Fs.select_problem(p); Ff.select_problem(p)
+        assert Fs.logdet() == Ff.logdet()
+    # oracle, problem 5
+    Q5 = Q0.copy(); Q5.data = vals[5].copy()
+    Fo = O.tridiagonal_cholesky(Q5, nb)
+    assert rel(mu_s[5].cpu().numpy(), O.ldiv(Fo, rhs[5])) < solve_tol(w)      # (bound of the full darcy256 posterior)
+    # the receiving side of a shared factor: layout record + packed image, representation included
+    Fr = pkg.TridiagonalCholeskyFactor(batch=8); Fr.set_keep_l(False)
+    Fr.adopt_layout(ns, nb, Fs.get_layout())
+    sz = Fs.packed_size(0, nb)
+    buf = torch.empty((8, sz), dtype=torch.float64, device="cuda")
+    Fs.pack_blocks_async(0, nb, buf); Fs.synchronize()
+    Fr.unpack_blocks_async(0, nb, buf); Fr.synchronize()
+    Fr.adopt_commit(False)
+    assert Fr.get_layout()[-1] == 256
+    assert torch.equal(Fr.solve_batch(rhs_t), Fs.solve_batch(rhs_t))
+    # exact variances need Linv_i as a matrix: the factor converts itself (and says so in its layout record)
+    vs, vf = Fs.marginal_var("exact"), Ff.marginal_var("exact")
+    assert Fs.get_layout()[-1] == 0
+    assert np.max(np.abs(vs - vf) / vf) < 1e-10
+    Fs.select_problem(5); Ff.select_problem(5)
+    Xi_s, Xi_f = Fs.get_block(pkg._cabi.BLOCK_LINV, 3), Ff.get_block(pkg._cabi.BLOCK_LINV, 3)
+    assert np.max(np.abs(Xi_s - Xi_f)) < 1e-12 * np.max(np.abs(Xi_f))
+    assert np.max(np.abs(Xi_s - np.linalg.inv(Fo.chos[3]))) < 1e-9 * np.max(np.abs(Xi_f))
+    # sweeps after the conversion use the full form again and agree
+    mu_c = Fs.solve_batch(rhs_t)[:, 0, :]
+    assert float((mu_c - mu_f).norm() / mu_f.norm()) < 1e-12
+    # re-factorisation returns to the split form
+    Fs.refactor(vals)
+    assert Fs.get_layout()[-1] == 256
+    for F in (Fs, Ff, Fr):
+        F.close()
