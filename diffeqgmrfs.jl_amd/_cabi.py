@@ -34,7 +34,7 @@ EXPORTS = [
     "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_comm_bytes", "gmrf_streams_create", "gmrf_streams_destroy",
     "gmrf_bt_packed_size", "gmrf_bt_pack_blocks_async", "gmrf_bt_unpack_blocks_async",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows", "gmrf_spmm_async", "gmrf_spmm_rows_async",
-    "gmrf_darcy_p1_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
+    "gmrf_darcy_p1_create", "gmrf_darcy_p2_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
     "gmrf_burgers_p1_create", "gmrf_burgers_p2_create", "gmrf_burgers_p1_destroy", "gmrf_burgers_p1_pattern", "gmrf_burgers_p1_tangent",
     "gmrf_shallow_water_p1_create", "gmrf_shallow_water_p1_destroy", "gmrf_shallow_water_p1_pattern", "gmrf_shallow_water_p1_qpoints",
     "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
@@ -150,6 +150,7 @@ def load() -> C.CDLL:
         "gmrf_assemble_precision": [vp, vp, vp, dbl, vp],
         "gmrf_assemble_rhs": [vp, vp, vp, vp, vp, dbl, vp],
         "gmrf_darcy_p1_create": [i32, vp, i64, i64, P(vp)],
+        "gmrf_darcy_p2_create": [i32, vp, i64, i64, P(vp)],
         "gmrf_darcy_p1_destroy": [vp],
         "gmrf_darcy_p1_pattern": [vp, P(i64), vp, vp, i32],
         "gmrf_darcy_p1_assemble": [vp, vp, i64, dbl, vp, vp],

@@ -222,13 +222,19 @@ class DarcyP1Assembler:
     (nx x ny nodes, x fastest, quads cut by the diagonal n00 - n11, one quadrature point per cell), the
     coefficient looked up by nearest grid point (src/datasets/darcy.jl:30-34), Dirichlet rows / columns
     applied.  `pattern` is the CSR matrix (values 1) whose `.data` order `assemble()` fills -- the `J`
-    of `PosteriorAssembler`.  device = -1: pattern only (no GPU needed)."""
+    of `PosteriorAssembler`.  device = -1: pattern only (no GPU needed).
+    order = 2: the reference's own element (src/utils.jl:32-33) -- Lagrange{RefTriangle,2} with the 4-point rule of degree 3
+    on the same nx x ny vertex mesh; dofs = the (2 nx - 1) x (2 ny - 1) lattice of vertices and edge midpoints."""
 
-    def __init__(self, nx: int, ny: int, device: int = 0, stream: int = 0):
-        self.nx, self.ny, self.n = int(nx), int(ny), int(nx) * int(ny)
+    def __init__(self, nx: int, ny: int, device: int = 0, stream: int = 0, order: int = 1):
+        if order not in (1, 2):
+            raise ValueError("order must be 1 (P1) or 2 (quadratic triangles)")
+        self.nx, self.ny, self.order = int(nx), int(ny), int(order)
+        self.n = int(nx) * int(ny) if order == 1 else (2 * int(nx) - 1) * (2 * int(ny) - 1)
         self._h = C.c_void_p()
         lib = _cabi.load()
-        _cabi.check(lib.gmrf_darcy_p1_create(device, C.c_void_p(stream), nx, ny, C.byref(self._h)))
+        create = lib.gmrf_darcy_p1_create if order == 1 else lib.gmrf_darcy_p2_create
+        _cabi.check(create(device, C.c_void_p(stream), nx, ny, C.byref(self._h)))
         nnz = C.c_int64(0)
         _cabi.check(lib.gmrf_darcy_p1_pattern(self._h, C.byref(nnz), None, None, 0))
         self.nnz = int(nnz.value)

@@ -29,12 +29,17 @@ struct DarcyP1Args {
     double* diag;                   // [n] raw diagonal (before the constraints), for meandiag
 };
 
-__device__ __forceinline__ double lin_coord(int i, int n) {      // numpy.linspace(0, 1, n)[i]
+// numpy.linspace(0, 1, n)[i].  The product must stay a product: fused into a following subtraction (hipcc contracts
+// a * b - c by default) the coordinate differences and the distances of the nearest-grid-point lookup round differently
+// from the host's, which decides exact ties (a quadrature point half-way between two table points) the other way.
+__device__ __forceinline__ double lin_coord(int i, int n) {
+#pragma clang fp contract(off)
     return (i == n - 1) ? 1.0 : (double)i * (1.0 / (double)(n - 1));
 }
 
 // argmin_k |grid[k] - p| with the first minimum winning (Julia argmin, src/datasets/darcy.jl:31-32)
 __device__ __forceinline__ int nearest_grid_index(double p, int ng) {
+#pragma clang fp contract(off)
     int k0 = (int)floor(p * (double)(ng - 1));
     k0 = max(0, min(k0, ng - 1));
     int best = k0;

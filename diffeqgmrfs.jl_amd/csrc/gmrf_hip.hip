@@ -32,6 +32,7 @@
 #include "potrf_step.hpp"
 #include "sweep.hpp"
 #include "swe_assemble.hpp"
+#include "fem_assemble_p2.hpp"
 
 using namespace gmrf;
 
@@ -2878,16 +2879,56 @@ struct gmrf_darcy_p1 {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int64_t nx = 0, ny = 0, n = 0, nnz = 0;
+    int order = 1;                      // 1: P1 triangles on the nx x ny nodes; 2: quadratic triangles, dofs = the (2 nx - 1) x (2 ny - 1) lattice
     std::vector<int64_t> rowptr, colidx;            // 0-based
     int64_t* d_rowptr = nullptr;
+    int32_t* d_colidx = nullptr;        // order 2: the pattern's columns and the Dirichlet mask for the generic apply! kernels
+    uint8_t* d_pres = nullptr;
     double *d_diag = nullptr, *d_mean = nullptr, *d_table = nullptr, *d_vals = nullptr, *d_f = nullptr;   // work + staging
     int64_t table_cap = 0;
 };
 
-gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out) {
-    if (!out || nx < 2 || ny < 2 || nx > 32768 || ny > 32768) return bad_shape("bad Darcy mesh size");
+// Pattern of the quadratic-triangle lattice: row (I, J) couples with every node of every cell it belongs to (the same
+// enumeration as darcy_p2_rows: 5 x 5 window of lattice offsets, touched entries in ascending column order).
+static void darcy_p2_pattern(gmrf_darcy_p1* d) {
+    const int64_t nx = d->nx, ny = d->ny, W = 2 * nx - 1, H = 2 * ny - 1;
+    d->n = W * H;
+    d->rowptr.assign((size_t)d->n + 1, 0);
+    d->colidx.reserve((size_t)d->n * 12);
+    for (int64_t J = 0; J < H; ++J)
+        for (int64_t I = 0; I < W; ++I) {
+            unsigned present = 0u;
+            int cand[6][3], nc;
+            if (!(I & 1) && !(J & 1)) { const int t[6][3] = {{-1, -1, 0}, {-1, 0, 0}, {0, 0, 0}, {-1, -1, 1}, {0, -1, 1}, {0, 0, 1}}; nc = 6; memcpy(cand, t, sizeof(t)); }
+            else if ((I & 1) && !(J & 1)) { const int t[2][3] = {{0, 0, 0}, {0, -1, 1}}; nc = 2; memcpy(cand, t, sizeof(t)); }
+            else if (!(I & 1) && (J & 1)) { const int t[2][3] = {{-1, 0, 0}, {0, 0, 1}}; nc = 2; memcpy(cand, t, sizeof(t)); }
+            else { const int t[2][3] = {{0, 0, 0}, {0, 0, 1}}; nc = 2; memcpy(cand, t, sizeof(t)); }
+            for (int e = 0; e < nc; ++e) {
+                const int64_t qx = I / 2 + cand[e][0], qy = J / 2 + cand[e][1];
+                if (qx < 0 || qy < 0 || qx >= nx - 1 || qy >= ny - 1) continue;
+                const bool upper = cand[e][2] != 0;
+                const int64_t I0 = 2 * qx, J0 = 2 * qy;
+                int64_t nI[6], nJ[6];
+                nI[0] = I0; nJ[0] = J0;
+                if (!upper) { nI[1] = I0 + 2; nJ[1] = J0; nI[2] = I0 + 2; nJ[2] = J0 + 2; }
+                else { nI[1] = I0 + 2; nJ[1] = J0 + 2; nI[2] = I0; nJ[2] = J0 + 2; }
+                nI[3] = (nI[0] + nI[1]) / 2; nJ[3] = (nJ[0] + nJ[1]) / 2;
+                nI[4] = (nI[1] + nI[2]) / 2; nJ[4] = (nJ[1] + nJ[2]) / 2;
+                nI[5] = (nI[2] + nI[0]) / 2; nJ[5] = (nJ[2] + nJ[0]) / 2;
+                for (int j = 0; j < 6; ++j) present |= 1u << (unsigned)((nJ[j] - J + 2) * 5 + (nI[j] - I + 2));
+            }
+            for (int s5 = 0; s5 < 25; ++s5)
+                if (present & (1u << s5)) d->colidx.push_back((J + s5 / 5 - 2) * W + (I + s5 % 5 - 2));
+            d->rowptr[(size_t)(J * W + I) + 1] = (int64_t)d->colidx.size();
+        }
+}
+
+static gmrf_status darcy_create(int32_t device, void* stream, int64_t nx, int64_t ny, int order, gmrf_darcy_p1** out) {
+    if (!out || nx < 2 || ny < 2 || nx > 32768 || ny > 32768 || (order == 2 && (nx > 16384 || ny > 16384))) return bad_shape("bad Darcy mesh size");
     auto* d = new gmrf_darcy_p1();
-    d->nx = nx; d->ny = ny; d->n = nx * ny;
+    d->nx = nx; d->ny = ny; d->n = nx * ny; d->order = order;
+    if (order == 2) darcy_p2_pattern(d);
+    else {
     d->rowptr.assign((size_t)d->n + 1, 0);
     d->colidx.reserve((size_t)d->n * 7);
     const int dxs[7] = {-1, 0, -1, 0, 1, 0, 1}, dys[7] = {-1, -1, 0, 0, 0, 1, 1};
@@ -2900,6 +2941,7 @@ gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64
             }
             d->rowptr[(size_t)(iy * nx + ix) + 1] = (int64_t)d->colidx.size();
         }
+    }
     d->nnz = (int64_t)d->colidx.size();
     if (device >= 0) {
         int count = 0;
@@ -2916,6 +2958,18 @@ gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64
         if (e == hipSuccess) e = hipMalloc(&d->d_diag, sizeof(double) * d->n);
         if (e == hipSuccess) e = hipMalloc(&d->d_mean, sizeof(double));
         if (e == hipSuccess) e = hipMemcpyAsync(d->d_rowptr, d->rowptr.data(), sizeof(int64_t) * (d->n + 1), hipMemcpyHostToDevice, d->stream);
+        std::vector<int32_t> col32;
+        std::vector<uint8_t> pres;
+        if (order == 2) {
+            const int64_t W = 2 * nx - 1, H = 2 * ny - 1;
+            col32.assign(d->colidx.begin(), d->colidx.end());
+            pres.resize((size_t)d->n);
+            for (int64_t r = 0; r < d->n; ++r) { const int64_t I = r % W, J = r / W; pres[(size_t)r] = (I == 0 || J == 0 || I == W - 1 || J == H - 1) ? 1 : 0; }
+            if (e == hipSuccess) e = hipMalloc(&d->d_colidx, sizeof(int32_t) * d->nnz);
+            if (e == hipSuccess) e = hipMalloc(&d->d_pres, (size_t)d->n);
+            if (e == hipSuccess) e = hipMemcpyAsync(d->d_colidx, col32.data(), sizeof(int32_t) * d->nnz, hipMemcpyHostToDevice, d->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(d->d_pres, pres.data(), (size_t)d->n, hipMemcpyHostToDevice, d->stream);
+        }
         if (e == hipSuccess) e = hipStreamSynchronize(d->stream);
         if (e != hipSuccess) {
             g_last_error = std::string("gmrf_darcy_p1_create: ") + hipGetErrorString(e);
@@ -2927,12 +2981,21 @@ gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64
     return GMRF_OK;
 }
 
+gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out) {
+    return darcy_create(device, stream, nx, ny, 1, out);
+}
+
+gmrf_status gmrf_darcy_p2_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out) {
+    return darcy_create(device, stream, nx, ny, 2, out);
+}
+
 gmrf_status gmrf_darcy_p1_destroy(gmrf_darcy_p1* d) {
     if (!d) return GMRF_OK;
     if (d->device >= 0) {
         (void)hipSetDevice(d->device);
         if (d->stream) (void)hipStreamSynchronize(d->stream);
         free_dev(d->d_rowptr); free_dev(d->d_diag); free_dev(d->d_mean); free_dev(d->d_table); free_dev(d->d_vals); free_dev(d->d_f);
+        free_dev(d->d_colidx); free_dev(d->d_pres);
         if (d->own_stream) (void)hipStreamDestroy(d->stream);
     }
     delete d;
@@ -2965,13 +3028,24 @@ gmrf_status gmrf_darcy_p1_assemble(gmrf_darcy_p1* d, const double* coeff_table, 
     const bool v_dev = is_device_ptr(vals_out), f_dev = is_device_ptr(f_out);
     if (!v_dev && !d->d_vals) HIPCHK(hipMalloc(&d->d_vals, sizeof(double) * d->nnz));
     if (!f_dev && !d->d_f) HIPCHK(hipMalloc(&d->d_f, sizeof(double) * d->n));
-    DarcyP1Args a;
-    a.nx = (int)d->nx; a.ny = (int)d->ny; a.ng = (int)ng; a.table = d_tab; a.rowptr = d->d_rowptr; a.beta = beta;
-    a.vals = v_dev ? vals_out : d->d_vals; a.f = f_dev ? f_out : d->d_f; a.diag = d->d_diag;
     const dim3 grid((unsigned)((d->n + 255) / 256));
-    hipLaunchKernelGGL(darcy_p1_rows, grid, dim3(256), 0, d->stream, a);
-    hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, d->stream, d->d_diag, d->n, d->d_mean);
-    hipLaunchKernelGGL(darcy_p1_constrain, grid, dim3(256), 0, d->stream, a, d->d_mean);
+    if (d->order == 2) {
+        DarcyP2Args a;
+        a.nx = (int)d->nx; a.ny = (int)d->ny; a.ng = (int)ng; a.table = d_tab; a.rowptr = d->d_rowptr; a.beta = beta;
+        a.vals = v_dev ? vals_out : d->d_vals; a.f = f_dev ? f_out : d->d_f; a.diag = d->d_diag;
+        hipLaunchKernelGGL(darcy_p2_rows, grid, dim3(256), 0, d->stream, a);
+        hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, d->stream, d->d_diag, d->n, d->d_mean);
+        // apply!(G, f, ch): rows and columns of the boundary lattice points, meandiag on their diagonal, f = 0 there
+        hipLaunchKernelGGL(csr_apply_constraints, grid, dim3(256), 0, d->stream, d->d_rowptr, d->d_colidx, d->d_pres, d->n, d->d_mean, a.vals);
+        hipLaunchKernelGGL(vec_set_prescribed, grid, dim3(256), 0, d->stream, d->d_pres, d->n, (const double*)nullptr, 0.0, a.f);
+    } else {
+        DarcyP1Args a;
+        a.nx = (int)d->nx; a.ny = (int)d->ny; a.ng = (int)ng; a.table = d_tab; a.rowptr = d->d_rowptr; a.beta = beta;
+        a.vals = v_dev ? vals_out : d->d_vals; a.f = f_dev ? f_out : d->d_f; a.diag = d->d_diag;
+        hipLaunchKernelGGL(darcy_p1_rows, grid, dim3(256), 0, d->stream, a);
+        hipLaunchKernelGGL(darcy_meandiag, dim3(1), dim3(256), 0, d->stream, d->d_diag, d->n, d->d_mean);
+        hipLaunchKernelGGL(darcy_p1_constrain, grid, dim3(256), 0, d->stream, a, d->d_mean);
+    }
     HIPCHK(hipGetLastError());
     if (!v_dev) HIPCHK(hipMemcpyAsync(vals_out, d->d_vals, sizeof(double) * d->nnz, hipMemcpyDeviceToHost, d->stream));
     if (!f_dev) HIPCHK(hipMemcpyAsync(f_out, d->d_f, sizeof(double) * d->n, hipMemcpyDeviceToHost, d->stream));

@@ -157,6 +157,20 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
             sum1 = fma(mv[u].y, xv[u].y, sum1);
         }
     }
+    // rows of 512 .. 1023 elements (a 768-wide coupling window, the 768-row part of a split block inverse): four loads in flight
+    for (; k + 3 * 128 < ke2; k += 4 * 128) {
+        v2d mv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
+            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sum0 = fma(mv[u].x, xv[u].x, sum0);
+            sum1 = fma(mv[u].y, xv[u].y, sum1);
+        }
+    }
     for (; k < ke2; k += 128) {
         const v2d mv = *reinterpret_cast<const v2d*>(mrow + k);
         const v2d xv = *reinterpret_cast<const v2d*>(x + k);
@@ -171,6 +185,113 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
         double v = sum;
         if (s.sub) v = s.Bin[row] - sum;
         s.Out[row] = v;
+    }
+}
+
+// One right-hand side, non-transposed, SHORT rows (kdim <= 256: the first block column of a split block inverse, see
+// gmrf_handle::xsplit): a wave owns four consecutive rows, the vector piece is loaded once, the eight 16-byte row pieces
+// are in flight together (one row per wave leaves a lane with two loads and a reduction: latency, not bandwidth).
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_n_short(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= s.rows) return;
+    const double* __restrict__ x = s.Xin;
+    const int k0 = lane * 2, k1 = lane * 2 + 128;
+    const int kd = s.kdim;
+    const v2d z = (v2d){0.0, 0.0};
+    // (TRI: row r sums k <= r; the stored zeros right of the diagonal make whole 16-byte pieces safe to read up to the
+    //  next even k, and pieces entirely right of it are skipped)
+    v2d m[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int ke = TRI ? (row0 + r + 2) & ~1 : kd;
+        const double* mrow = s.Mat + (int64_t)(row0 + r) * s.ld;
+        m[r][0] = (k0 < ke) ? *reinterpret_cast<const v2d*>(mrow + k0) : z;
+        m[r][1] = (k1 < ke) ? *reinterpret_cast<const v2d*>(mrow + k1) : z;
+    }
+    const int kx = TRI ? (row0 + 5) & ~1 : kd;
+    const v2d x0 = (k0 < kx && k0 < kd) ? *reinterpret_cast<const v2d*>(x + k0) : z;
+    const v2d x1 = (k1 < kx && k1 < kd) ? *reinterpret_cast<const v2d*>(x + k1) : z;
+    double sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // the order of sweep_gemv_n: even elements into one sum, odd into the other, ascending k, then the wave reduction
+        double a0 = fma(m[r][0].x, x0.x, 0.0), a1 = fma(m[r][0].y, x0.y, 0.0);
+        a0 = fma(m[r][1].x, x1.x, a0); a1 = fma(m[r][1].y, x1.y, a1);
+        sum[r] = a0 + a1;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], off, 64);
+    }
+    if (lane < 4) {
+        const int row = row0 + lane;
+        const double v0 = lane == 0 ? sum[0] : (lane == 1 ? sum[1] : (lane == 2 ? sum[2] : sum[3]));
+        s.Out[row] = s.sub ? s.Bin[row] - v0 : v0;
+    }
+}
+
+// One right-hand side, non-transposed, rows of moderate length (a batch's coupling window inside its staircase, the parts of
+// a split block inverse: 256 .. 768 elements): a wave owns FOUR consecutive rows (rows % 4 == 0; they share the staircase
+// start, 4 | 64), reads the vector piece once per 128 elements and keeps eight 16-byte row pieces in flight -- one row per
+// wave (sweep_gemv_n) gets there only for rows of 1024 elements and more.  Per row the summation order of sweep_gemv_n.
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_n4(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+    if (row0 >= s.rows) return;
+    const double* __restrict__ x = s.Xin;
+    const int kb = (!TRI && s.kst) ? s.kst[row0 >> 6] : 0;
+    // TRI: row r ends at r + 1; pieces are read up to the next even index (stored zeros right of the diagonal)
+    const int ke_max = TRI ? (row0 + 5) & ~1 : s.kdim & ~1;
+    const double* __restrict__ m0 = s.Mat + (int64_t)row0 * s.ld;
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    const v2d z = (v2d){0.0, 0.0};
+    int k = kb + lane * 2;
+    for (; k + 128 < ke_max; k += 256) {
+        v2d mv[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ke = TRI ? (row0 + r + 2) & ~1 : ke_max;
+            mv[r][0] = (k < ke) ? *reinterpret_cast<const v2d*>(m0 + (int64_t)r * s.ld + k) : z;
+            mv[r][1] = (k + 128 < ke) ? *reinterpret_cast<const v2d*>(m0 + (int64_t)r * s.ld + k + 128) : z;
+        }
+        const v2d x0 = *reinterpret_cast<const v2d*>(x + k), x1 = *reinterpret_cast<const v2d*>(x + k + 128);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a0[r] = fma(mv[r][0].x, x0.x, a0[r]); a1[r] = fma(mv[r][0].y, x0.y, a1[r]);
+            a0[r] = fma(mv[r][1].x, x1.x, a0[r]); a1[r] = fma(mv[r][1].y, x1.y, a1[r]);
+        }
+    }
+    for (; k < ke_max; k += 128) {
+        const v2d x0 = *reinterpret_cast<const v2d*>(x + k);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ke = TRI ? (row0 + r + 2) & ~1 : ke_max;
+            const v2d mv = (k < ke) ? *reinterpret_cast<const v2d*>(m0 + (int64_t)r * s.ld + k) : z;
+            a0[r] = fma(mv.x, x0.x, a0[r]); a1[r] = fma(mv.y, x0.y, a1[r]);
+        }
+    }
+    double sum[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sum[r] = a0[r] + a1[r];
+    if (!TRI && (s.kdim & 1) && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = fma(m0[(int64_t)r * s.ld + s.kdim - 1], x[s.kdim - 1], sum[r]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], off, 64);
+    }
+    if (lane < 4) {
+        const int row = row0 + lane;
+        const double v0 = lane == 0 ? sum[0] : (lane == 1 ? sum[1] : (lane == 2 ? sum[2] : sum[3]));
+        s.Out[row] = s.sub ? s.Bin[row] - v0 : v0;
     }
 }
 
@@ -233,13 +354,26 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
 inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s, int nprob) {
     if (kp == 1) {
         if (!trans) {
+            if (s.kdim <= 256 && s.rows % 16 == 0 && s.kdim % 2 == 0 && !s.kst) {
+                dim3 grid(s.rows / 16, 1, nprob), block(256);
+                if (tri) hipLaunchKernelGGL((sweep_gemv_n_short<true>), grid, block, 0, st, s);
+                else hipLaunchKernelGGL((sweep_gemv_n_short<false>), grid, block, 0, st, s);
+                return hipGetLastError();
+            }
+            if (nprob >= 8 && s.rows % 16 == 0 && s.kdim <= 768 && s.kdim % 2 == 0) {
+                dim3 grid(s.rows / 16, 1, nprob), block(256);
+                if (tri) hipLaunchKernelGGL((sweep_gemv_n4<true>), grid, block, 0, st, s);
+                else hipLaunchKernelGGL((sweep_gemv_n4<false>), grid, block, 0, st, s);
+                return hipGetLastError();
+            }
             dim3 grid((s.rows + 3) / 4, 1, nprob), block(256);
             if (tri) hipLaunchKernelGGL((sweep_gemv_n<true>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_n<false>), grid, block, 0, st, s);
         } else {
-            // wide column blocks (256-byte row pieces) when the batch supplies the workgroups, narrow ones for a
-            // lone problem (more workgroups on its latency-bound chain)
-            const bool wide = nprob >= 8 && s.rows % 32 == 0;
+            // wide column blocks (256-byte row pieces) when the batch supplies enough workgroups that way (two per CU),
+            // narrow ones otherwise (a lone problem's latency-bound chain; the short products of a split block inverse)
+            const int ncb32 = s.rows / 32;
+            const bool wide = nprob >= 8 && s.rows % 32 == 0 && (int64_t)(tri ? (ncb32 + 1) / 2 : ncb32) * nprob >= 512;
             const int cw = wide ? 32 : 16, ncb = s.rows / cw;
             dim3 grid(tri ? (ncb + 1) / 2 : ncb, 1, nprob), block(256);
             if (tri && wide) hipLaunchKernelGGL((sweep_gemv_t<true, 32>), grid, block, 0, st, s);

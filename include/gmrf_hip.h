@@ -379,6 +379,11 @@ gmrf_status gmrf_assemble_rhs(gmrf_assembler* as, const double* base, const doub
  * pointers; device = -1: pattern only. */
 typedef struct gmrf_darcy_p1 gmrf_darcy_p1;
 gmrf_status gmrf_darcy_p1_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out);
+/* The same assembler with the reference's own element (src/utils.jl:32-33): Lagrange{RefTriangle,2} and the 4-point rule of
+ * QuadratureRule{RefTriangle}(3) on the nx x ny vertex mesh; dofs = the (2 nx - 1) x (2 ny - 1) lattice of vertices and edge
+ * midpoints, x fastest; the coefficient is looked up at every quadrature point.  Same handle type: gmrf_darcy_p1_pattern /
+ * _assemble / _destroy serve both (n = (2 nx - 1)(2 ny - 1) rows, up to 19 entries per row). */
+gmrf_status gmrf_darcy_p2_create(int32_t device, void* stream, int64_t nx, int64_t ny, gmrf_darcy_p1** out);
 gmrf_status gmrf_darcy_p1_destroy(gmrf_darcy_p1* d);
 gmrf_status gmrf_darcy_p1_pattern(const gmrf_darcy_p1* d, int64_t* nnz_out, int64_t* rowptr, int64_t* colidx,
                                   int32_t index_base);

@@ -393,14 +393,20 @@ mutable struct DarcyP1Assembler
     pattern::SparseMatrixCSC{Float64,Int}     # TRANSPOSE of the stiffness pattern (CSC of G' = CSR of G), values 1.0
 end
 
-function DarcyP1Assembler(nx::Integer, ny::Integer; device::Integer = 0)
+"order = 2: Lagrange{RefTriangle,2} with QuadratureRule{RefTriangle}(3) (src/utils.jl:32-33); dofs = the (2nx-1) x (2ny-1) lattice of vertices and edge midpoints."
+function DarcyP1Assembler(nx::Integer, ny::Integer; device::Integer = 0, order::Integer = 1)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:gmrf_darcy_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), device, C_NULL, nx, ny, h))
+    if order == 2
+        check(ccall((:gmrf_darcy_p2_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), device, C_NULL, nx, ny, h))
+    else
+        check(ccall((:gmrf_darcy_p1_create, libgmrf), Int32, (Int32, Ptr{Cvoid}, Int64, Int64, Ref{Ptr{Cvoid}}), device, C_NULL, nx, ny, h))
+    end
+    n = order == 2 ? (2nx - 1) * (2ny - 1) : nx * ny
     nnz_out = Ref{Int64}(0)
     check(ccall((:gmrf_darcy_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, C_NULL, C_NULL, 1))
-    rowptr = Vector{Int64}(undef, nx * ny + 1); colidx = Vector{Int64}(undef, nnz_out[])
+    rowptr = Vector{Int64}(undef, n + 1); colidx = Vector{Int64}(undef, nnz_out[])
     check(ccall((:gmrf_darcy_p1_pattern, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int64}, Ptr{Int64}, Ptr{Int64}, Int32), h[], nnz_out, rowptr, colidx, 1))
-    d = DarcyP1Assembler(h[], SparseMatrixCSC(nx * ny, nx * ny, rowptr, colidx, ones(nnz_out[])))
+    d = DarcyP1Assembler(h[], SparseMatrixCSC(n, n, rowptr, colidx, ones(nnz_out[])))
     finalizer(x -> ccall((:gmrf_darcy_p1_destroy, libgmrf), Int32, (Ptr{Cvoid},), x.handle), d)
     return d
 end

@@ -339,6 +339,94 @@ def assemble_darcy_diff_matrix(nx: int, ny: int, x_coords, y_coords, coeff_mat, 
     return G, f
 
 
+# Lagrange{RefTriangle,2} in Ferrite's reference coordinates: vertex 1 at xi = (1, 0), vertex 2 at (0, 1), vertex 3 at (0, 0),
+# then the edge nodes (1-2), (2-3), (3-1).  gamma = 1 - xi_x - xi_y.
+def _p2_triangle_shape(xi_x, xi_y):
+    g = 1.0 - xi_x - xi_y
+    return np.array([xi_x * (2.0 * xi_x - 1.0), xi_y * (2.0 * xi_y - 1.0), g * (2.0 * g - 1.0), 4.0 * xi_x * xi_y, 4.0 * xi_y * g, 4.0 * xi_x * g])
+
+
+def _p2_triangle_ref_grad(xi_x, xi_y):
+    g = 1.0 - xi_x - xi_y
+    return np.array([[4.0 * xi_x - 1.0, 0.0], [0.0, 4.0 * xi_y - 1.0], [-(4.0 * g - 1.0), -(4.0 * g - 1.0)],
+                     [4.0 * xi_y, 4.0 * xi_x], [-4.0 * xi_y, 4.0 * (g - xi_y)], [4.0 * (g - xi_x), -4.0 * xi_x]])
+
+
+# QuadratureRule{RefTriangle}(3) (src/utils.jl:33: element_order + 1), taken as the 4-point Dunavant rule of degree 3
+# (weights sum to 1/2, one of them negative); the order of the points fixes the summation order on both sides.
+P2_TRI_QPOINTS = ((1.0 / 3.0, 1.0 / 3.0, -27.0 / 96.0), (0.2, 0.2, 25.0 / 96.0), (0.6, 0.2, 25.0 / 96.0), (0.2, 0.6, 25.0 / 96.0))
+
+
+def p2_lattice_cells(nx: int, ny: int):
+    """Cells of the structured quadratic mesh: the P1 triangulation of nx x ny vertices (all lower triangles
+    (n00, n10, n11) first, then all upper (n00, n11, n01)), every cell with its three edge midpoints; dofs are the points
+    of the (2 nx - 1) x (2 ny - 1) lattice, x fastest.  Returns (cells (nc, 6) dof numbers in Ferrite's local order --
+    vertices 1, 2, 3, then the nodes of the edges (1-2), (2-3), (3-1) --, X, Y (nc, 3) vertex coordinates)."""
+    W = 2 * nx - 1
+    xs, ys = np.linspace(0.0, 1.0, nx), np.linspace(0.0, 1.0, ny)
+    qx, qy = np.meshgrid(np.arange(nx - 1), np.arange(ny - 1), indexing="xy")
+    qx, qy = qx.ravel(), qy.ravel()
+    lat = lambda I, J: J * W + I
+    I0, J0 = 2 * qx, 2 * qy
+    v_lo = [(I0, J0), (I0 + 2, J0), (I0 + 2, J0 + 2)]
+    v_up = [(I0, J0), (I0 + 2, J0 + 2), (I0, J0 + 2)]
+    out, Xs, Ys = [], [], []
+    for v in (v_lo, v_up):
+        nodes = list(v) + [((v[0][0] + v[1][0]) // 2, (v[0][1] + v[1][1]) // 2), ((v[1][0] + v[2][0]) // 2, (v[1][1] + v[2][1]) // 2),
+                           ((v[2][0] + v[0][0]) // 2, (v[2][1] + v[0][1]) // 2)]
+        out.append(np.stack([lat(I, J) for I, J in nodes], axis=1))
+        Xs.append(np.stack([xs[I // 2] for I, _ in v], axis=1)); Ys.append(np.stack([ys[J // 2] for _, J in v], axis=1))
+    return np.concatenate(out, axis=0), np.concatenate(Xs, axis=0), np.concatenate(Ys, axis=0)
+
+
+def assemble_darcy_diff_matrix_p2(nx: int, ny: int, x_coords, y_coords, coeff_mat, beta: float = 1.0, constrain: bool = True):
+    """`assemble_darcy_diff_matrix` (/root/reference/src/problems/darcy.jl:5-63) with the reference's own element:
+    `Lagrange{RefTriangle,2}` and `QuadratureRule{RefTriangle}(3)` (src/utils.jl:32-33) on the structured mesh of
+    p2_lattice_cells.  Per cell and quadrature point (:27-59):
+        x_q = spatial_coordinate (straight-sided cell: xi_x x_1 + xi_y x_2 + gamma x_3)              :35
+        coeff_val = coeff_mat[get_xy_idcs(x_q, ...)]                                                 :39
+        dOmega = w_q |det J|,  grad N_i = J^-T grad_xi N_i,  J = [x_1 - x_3, x_2 - x_3]               :42
+        fe[i] += beta N_i dOmega;  Ge[i, j] += (grad N_i . coeff_val grad N_j) dOmega                :47-52
+    `assemble!` and `apply!` with homogeneous Dirichlet data on the boundary lattice points as in the P1 form.
+    Returns (G CSR over the lattice with the pattern of all cell couplings, zeros kept, f)."""
+    cells, X, Y = p2_lattice_cells(nx, ny)
+    nc = cells.shape[0]
+    W, H = 2 * nx - 1, 2 * ny - 1
+    n = W * H
+    a, b = X[:, 0] - X[:, 2], X[:, 1] - X[:, 2]            # J = [[a, b], [c, d]]
+    c, d = Y[:, 0] - Y[:, 2], Y[:, 1] - Y[:, 2]
+    det = a * d - b * c
+    Ge = np.zeros((nc, 6, 6)); fe = np.zeros((nc, 6))
+    for (xi_x, xi_y, wq) in P2_TRI_QPOINTS:
+        g = 1.0 - xi_x - xi_y
+        xq = (xi_x * X[:, 0] + xi_y * X[:, 1]) + g * X[:, 2]
+        yq = (xi_x * Y[:, 0] + xi_y * Y[:, 1]) + g * Y[:, 2]
+        xi, yi = get_xy_idcs(xq, yq, x_coords, y_coords)
+        coeff_val = np.asarray(coeff_mat)[xi, yi]
+        dO = wq * np.abs(det)
+        N = _p2_triangle_shape(xi_x, xi_y)
+        dN = _p2_triangle_ref_grad(xi_x, xi_y)
+        gx = (d[:, None] * dN[None, :, 0] - c[:, None] * dN[None, :, 1]) / det[:, None]        # J^-T grad_xi
+        gy = (-b[:, None] * dN[None, :, 0] + a[:, None] * dN[None, :, 1]) / det[:, None]
+        for i in range(6):
+            fe[:, i] += beta * N[i] * dO
+            for j in range(6):
+                Ge[:, i, j] += coeff_val * (gx[:, i] * gx[:, j] + gy[:, i] * gy[:, j]) * dO
+    rows = np.repeat(cells[:, :, None], 6, axis=2).ravel()
+    cols = np.repeat(cells[:, None, :], 6, axis=1).ravel()
+    G = sp.coo_matrix((Ge.ravel(), (rows, cols)), shape=(n, n)).tocsr()
+    G.sort_indices()
+    f = np.zeros(n)
+    np.add.at(f, cells.ravel(), fe.ravel())
+    I, J = np.arange(n) % W, np.arange(n) // W
+    if not constrain:                 # (the raw element sums, for the tests that pin this restatement by what G is)
+        return G, f
+    constrained = (I == 0) | (J == 0) | (I == W - 1) | (J == H - 1)
+    G = _apply_constraints(G, constrained)
+    f = np.where(constrained, 0.0, f)
+    return G, f
+
+
 def reconstruct(F: TridiagonalCholeskyFactor) -> np.ndarray:
     """Dense L L^T from the block factor (tests only, small n)."""
     N, bs = F.n_blocks, F.block_size

@@ -1509,3 +1509,50 @@ def test_split_inverse_representation_of_batches(pkg):
     assert Fs.get_layout()[-1] == 256
     for F in (Fs, Ff, Fr):
         F.close()
+
+
+def test_darcy_p2_triangle_stiffness_on_device(pkg):
+    """Quadratic triangles: `assemble_darcy_diff_matrix` (/root/reference/src/problems/darcy.jl:5-63) with the reference's
+    own element (Lagrange{RefTriangle,2}, QuadratureRule{RefTriangle}(3): src/utils.jl:32-33) on the device, entry by
+    entry against the oracle's restatement (fixed summation order over a lattice point's cells and the quadrature
+    points: 1e-14 of max |G|), host and device-resident operands; then the problem chain table -> G (device) ->
+    Q + Q_eps G'G (device) -> block-tridiagonal factor -> mean against the oracle on the lattice (reach of G'G: four
+    lattice rows = one block)."""
+    import torch
+    import scipy.sparse as sp
+    gq = np.linspace(0.0, 1.0, 241)
+    GX, GY = np.meshgrid(gq, gq, indexing="ij")
+    for (nx, ny, seed) in ((9, 8, 523802340), (33, 33, 11), (128, 96, 7)):
+        table = pkg.workloads.darcy_coefficient(seed)(GX.ravel(), GY.ravel()).reshape(241, 241)
+        Go, fo = O.assemble_darcy_diff_matrix_p2(nx, ny, gq, gq, table, 2.0)
+        d = pkg.DarcyP1Assembler(nx, ny, order=2)
+        assert d.n == (2 * nx - 1) * (2 * ny - 1) and np.array_equal(d.pattern.indptr, Go.indptr) and np.array_equal(d.pattern.indices, Go.indices)
+        vals, f = d.assemble(table, beta=2.0)
+        ev, ef = np.max(np.abs(vals - Go.data)) / np.max(np.abs(Go.data)), np.max(np.abs(f - fo)) / np.max(np.abs(fo))
+        print(f"darcy P2 {nx}x{ny}: entries {ev:.2e}, load {ef:.2e}")
+        # (the boundary lattice points carry meandiag, an n-term sum taken as a 256-way tree here and pairwise by NumPy)
+        W, H = 2 * nx - 1, 2 * ny - 1
+        rows = np.repeat(np.arange(d.n), np.diff(Go.indptr))
+        bnd = lambda r: (r % W == 0) | (r // W == 0) | (r % W == W - 1) | (r // W == H - 1)
+        md = (rows == Go.indices) & bnd(rows)
+        err = np.abs(vals - Go.data)
+        assert err[~md].max() < 1e-14 * np.max(np.abs(Go.data)) and err[md].max() < d.n * EPS * np.max(np.abs(Go.data))
+        assert ef < 1e-14
+        vd, fd = d.assemble(torch.from_numpy(table).cuda(), beta=2.0)
+        assert vd.is_cuda and np.array_equal(vd.cpu().numpy(), vals) and np.array_equal(fd.cpu().numpy(), f)
+    # chain: 17 x 15 lattice (nx = 9, ny = 8), 3 blocks of 5 lattice rows
+    nx, ny, N, q_eps = 9, 8, 3, 1e4
+    d = pkg.DarcyP1Assembler(nx, ny, order=2)
+    n = d.n
+    Q0 = sp.identity(n, format="csc") * 2.0
+    asm = pkg.PosteriorAssembler(Q0, d.pattern)
+    table = pkg.workloads.darcy_coefficient(5)(GX.ravel(), GY.ravel()).reshape(241, 241)
+    a_vals, y = d.assemble(torch.from_numpy(table).cuda())
+    p_vals = asm.precision(torch.from_numpy(Q0.data).cuda(), a_vals, q_eps)
+    P = asm.pattern.copy(); P.data = p_vals.cpu().numpy()
+    F = pkg.tridiagonal_cholesky(P, N)
+    rhs = asm.rhs(None, a_vals, torch.zeros(n, dtype=torch.float64, device="cuda"), y, q_eps)
+    mu = pkg.ldiv(F, rhs)
+    Go, fo = O.assemble_darcy_diff_matrix_p2(nx, ny, gq, gq, table, 1.0)
+    _, _, mu_o = O.condition_on_observations(Q0, None, Go, q_eps, fo, N)
+    assert rel(mu.cpu().numpy(), mu_o) < 1e-10

@@ -335,3 +335,40 @@ def test_bench_refuses_a_rank_count_that_differs_from_the_launcher():
     assert p.returncode == 2 and "WORLD_SIZE=2" in p.stderr and p.stdout.strip() == ""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, env=env, timeout=120)
     assert p.returncode == 2          # default --gpus 1 under a 2-rank launcher
+
+
+def test_darcy_p2_triangle_pattern_and_oracle_without_gpu(pkg):
+    """Quadratic triangles (the reference's own element, src/utils.jl:32-33): the restatement
+    oracle/bt_oracle.py `assemble_darcy_diff_matrix_p2` of /root/reference/src/problems/darcy.jl:5-63 is unpinned against
+    Ferrite (absent) and pinned by what G is: symmetric, constants in its null space, u' G u = int a |grad u|^2 exactly for
+    quadratic u and piecewise-constant a that the quadrature points resolve (the degree-3 rule integrates the degree-2
+    integrand), f = beta int N_i (vertex functions integrate to 0, edge functions to |T| / 3); the library's pattern
+    (device = -1: no GPU) is the oracle's; `apply!` semantics on the boundary lattice points."""
+    from oracle import bt_oracle as O
+    nx, ny = 6, 5
+    W, H = 2 * nx - 1, 2 * ny - 1
+    ng = 11
+    xc = np.linspace(0.0, 1.0, ng)
+    G, f = O.assemble_darcy_diff_matrix_p2(nx, ny, xc, xc, np.ones((ng, ng)), beta=2.0, constrain=False)
+    d = pkg.DarcyP1Assembler(nx, ny, device=-1, order=2)
+    assert d.n == W * H and np.array_equal(d.pattern.indptr, G.indptr) and np.array_equal(d.pattern.indices, G.indices)
+    assert abs(G - G.T).max() < 1e-14 and abs(G @ np.ones(W * H)).max() < 1e-13
+    I, J = np.arange(W * H) % W, np.arange(W * H) // W
+    x, y = I / (W - 1), J / (H - 1)
+    for u, energy in ((x, 1.0), (y, 1.0), (x * x, 4.0 / 3.0), (x * y, 2.0 / 3.0), (x * x - 2.0 * y * y + x * y, 19.0 / 3.0)):
+        assert abs(u @ (G @ u) - energy) < 1e-12
+    assert abs(f.sum() - 2.0) < 1e-13
+    vertex = (I % 2 == 0) & (J % 2 == 0)
+    assert np.max(np.abs(f[vertex])) < 1e-15                       # int N_vertex = 0 on every cell for the quadratic Lagrange basis
+    # a coefficient that is 3 on the left half and 12 on the right (the reference's two-phase medium): energy of u = x
+    # (table fine enough that the nearest-grid-point lookup of no quadrature point crosses x = 1/2: they keep 0.05 from it)
+    xf = np.linspace(0.0, 1.0, 41)
+    tab = np.where(xf[:, None] < 0.5, 3.0, 12.0) * np.ones((1, 41))
+    Ga, _ = O.assemble_darcy_diff_matrix_p2(5, 5, xf, xf, tab, constrain=False)       # cell edges at multiples of 1/4: x = 1/2 is a cell boundary
+    Ia = np.arange(81) % 9
+    assert abs((Ia / 8.0) @ (Ga @ (Ia / 8.0)) - 7.5) < 1e-12
+    # constraints: boundary lattice points
+    Gc, fc = O.assemble_darcy_diff_matrix_p2(nx, ny, xc, xc, np.ones((ng, ng)), beta=2.0)
+    bnd = (I == 0) | (J == 0) | (I == W - 1) | (J == H - 1)
+    assert np.all(fc[bnd] == 0) and np.all(Gc[bnd].toarray()[:, ~bnd] == 0)
+    assert np.allclose(Gc.diagonal()[bnd], np.abs(G.diagonal()).sum() / (W * H))
