@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
 // workgroup gathers X[c0 .. c0+15][distinct columns] ONCE per 16-column chunk (thread u = distinct column u: 16
 // independent 8-byte loads, coalesced along u, issued while the previous chunk is being multiplied), writes them as
 // swizzled 128-byte LDS rows [u][16] and then runs the multiply phase of csr_spmm_tiles_pad: lane (row, kq) owns the
-// columns 4 kq .. 4 kq + 3 of the chunk, entries padded to multiples of 8 per row (aligned 16-byte index / value
+// columns 4 kq .. 4 kq + 3 of the chunk, entries padded to multiples of 4 per row (aligned 8-byte index / 16-byte value
 // reads), fixed CSR summation order -- the results are bitwise those of spmm_bxt.  C leaves as 128-byte lines.
 struct BxtTileArgs {
     const int* rowptr;        // this block's [bsp + 1] row pointers (absolute entry indices)
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     const int e0 = a.rowptr[r0];
     if (t < 64) {                                            // padded row starts: one wave scans
         const int ea = a.rowptr[r0 + t] - e0, eb = a.rowptr[r0 + t + 1] - e0;
-        int x = (eb - ea + 7) & ~7;
+        int x = (eb - ea + 3) & ~3;                          // rows padded to turns of 4 entries (FEM coupling rows are short: 9 / 4 / 1 entries on the darcy mesh)
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int y = __shfl_up(x, d, 64);
@@ -337,25 +337,23 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         else __syncthreads();
         if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
         v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
-        for (int e = pp[row]; e < pp[row + 1]; e += 8) {
-            const uint4 q = *reinterpret_cast<const uint4*>(ls + e);
+        for (int e = pp[row]; e < pp[row + 1]; e += 4) {
+            const uint2 q = *reinterpret_cast<const uint2*>(ls + e);
             if ((int)(q.x & 0xffffu) >= live) break;
             const double* ve = vs + e + 2 * row;
             const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
-            const v2d v45 = *reinterpret_cast<const v2d*>(ve + 4), v67 = *reinterpret_cast<const v2d*>(ve + 6);
-            const int ii[8] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16),
-                               (int)(q.z & 0xffffu), (int)(q.z >> 16), (int)(q.w & 0xffffu), (int)(q.w >> 16)};
-            const double vv[8] = {v01.x, v01.y, v23.x, v23.y, v45.x, v45.y, v67.x, v67.y};
-            v2d xa[8], xb[8];
+            const int ii[4] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16)};
+            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+            v2d xa[4], xb[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 const int swz = (((ii[u] >> 1) & 1) << 2) ^ ((ii[u] >> 2) & 3);
                 const int o = (ii[u] << 4) + 2 * (kq ^ swz);                 // in doubles: row * 16 + 2 * slot(kq, half 0)
                 xa[u] = *reinterpret_cast<const v2d*>(xs + o);
                 xb[u] = *reinterpret_cast<const v2d*>(xs + (o ^ 8));
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 4; ++u) {
                 a01.x = fma(vv[u], xa[u].x, a01.x); a01.y = fma(vv[u], xa[u].y, a01.y);
                 a23.x = fma(vv[u], xb[u].x, a23.x); a23.y = fma(vv[u], xb[u].y, a23.y);
             }
