@@ -743,8 +743,13 @@ inline bool gemm_uses_ll(const GemmArgs& g, int batch) {
     if (gemm_ll_policy() == 2 || g.K % 32 || (g.tri & ~15) || g.stamps) return false;
     const int64_t sx = g.N / GEMM_BN, sy = g.M / GEMM_BM;
     const int64_t tiles = ((g.lower_only && g.M == g.N) ? sx * (sx + 1) / 2 : sx * sy) * batch;
-    static const int64_t ll_max = [] { const char* e = getenv("GMRF_GEMM_LL_MAX_TILES"); return (int64_t)(e ? atoi(e) : 128); }();   // tuning aid
-    return tiles <= ll_max;
+    static const int64_t ll_env = [] { const char* e = getenv("GMRF_GEMM_LL_MAX_TILES"); return (int64_t)(e ? atoi(e) : -1); }();   // tuning aid
+    if (ll_env >= 0) return tiles <= ll_env;
+    // The 32 x 32-tile kernel is for the latency of ONE problem's small products (or a handful of problems).  A launch of a
+    // real batch is better served by 64 x 64 tiles even when they fill few CUs: with several handles in flight what counts is
+    // what a launch takes from the chip, not how soon it ends (darcy256, 4 x 32: the 128-tile launches on gemm_f64_dma are
+    // slower one by one -- 1-stream GEMM time 46.9 -> 48.9 ms -- and the job is faster, 43.7 k -> 44.2 k solves/s).
+    return tiles <= 128 && batch < 8;
 }
 
 // The LDS-DMA kernels (gemm_f64_dma.hpp) take the launches that qualify; defined there.
