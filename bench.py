@@ -780,6 +780,19 @@ def main():
                                  "launches": g["launches"], "ms": round(g["ms"], 3), "share": round(g["ms"] / gsum, 4),
                                  "tflops": round(g["flops"] / max(g["ms"], 1e-9) / 1e9, 2)}
                                 for g in sorted(shapes, key=lambda g: -g["ms"]) if g["launches"] > 0]
+        # the same symbols restricted to the launches that fill the chip (>= 1024 workgroups of 64 x 64 outputs = every
+        # workgroup slot of the 256 CUs): what the kernel does when the launch is not the limit
+        def wgs(g):
+            tm, tn = g["M"] // 64, g["N"] // 64
+            return (tm * (tm + 1) // 2 if g["lower_only"] and g["M"] == g["N"] else tm * tn) * g["problems"]
+        big = [g for g in shapes if g["launches"] > 0 and wgs(g) >= 1024 and g["class"] in (0, 11, 14, 15)]
+        if big:
+            bms, bfl = sum(g["ms"] for g in big), sum(g["flops"] for g in big)
+            out["roofline"]["chip_filling_launches"] = {"achieved": bfl / bms / 1e9, "frac": bfl / bms / 1e9 / PEAK_FP64_MFMA_TFLOPS,
+                                                        "ms_per_step": bms, "share_of_gemm_time": bms / gsum,
+                                                        "launches_per_step": sum(g["launches"] for g in big),
+                                                        "note": "GEMM launches of >= 1024 workgroups; the symbol-level figures above also average "
+                                                                "over the short products of the diagonal chain and the 64-row sweep panels"}
         executed = sum(work[c] for c in KERNEL_CLASSES if KERNEL_CLASSES[c][1] == "mfma")
         # phase times of the un-instrumented path (whole batch of one handle)
         eng.F.refactor(eng.nz)
