@@ -610,13 +610,15 @@ def main():
         out.update(extra)
 
     # ------------------------------------------------------------------ N > 1: the other legs, same run
+    leg_state = {}
     watchdog = None
     if shared_legs:
         # The side legs never cost the headline: if they overrun (a rank stuck in a collective), every rank leaves
         # after --side-leg-limit seconds and rank 0 prints the line it already has.
         import threading
 
-        leg = {"name": "set-up"}
+        leg = leg_state
+        leg["name"] = "set-up"
 
         def give_up():
             # a rank that is still in a side leg after the limit is stuck (a collective that never completes = a GPU
@@ -633,95 +635,102 @@ def main():
         watchdog = threading.Timer(args.side_leg_limit, give_up)
         watchdog.daemon = True
         watchdog.start()
-        if not shared:
-            # (s) north_star's split beside the headline: the shared-factor job at the headline's samples per posterior
-            leg["name"] = "shared_factor"
-            pj.close()                    # the headline's posteriors (streams x batch of them) leave the HBM first
-            pj = None
-            steps_s = max(2, args.steps // 4)
-            eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1)
-            if rank == 0:
-                side["shared_factor"] = dict({"value": per_s * steps_s / el_s, "unit": "solves/s", "ms_per_step": 1e3 * el_s / steps_s,
-                                              "steps": steps_s, "workload": wl_s, "sharding": sh_s}, **rec_s)
-        # (r) the same shared-factor job at more samples per factor and rank: the factor (and its broadcast) is paid once
-        # per posterior, the sample sweeps scale with the ranks -- which regime reaches what multiple of one rank
-        leg["name"] = "regimes"
-        regimes = [int(x) for x in args.regimes.split(",") if x.strip()]
-        reg = {}
-        for kr in regimes:
-            jr = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=kr, group=args.group,
-                                       force_shared=args.force_shared, keep_samples=False, timing=True)
-            jr.step(1 << 21)
-
-            def run_r(first, count, jr=jr):
-                for s in range(count):
-                    jr.step(first + s)
-            el = timed(run_r, sync, dist, torch, 0, 3)
-            ph = gather_phases(jr)
-            if rank == 0:
-                reg[str(kr)] = {"value": jr.solves_per_step() * 3 / el, "unit": "solves/s", "ms_per_step": 1e3 * el / 3,
-                                "samples_per_posterior_and_rank": kr, "phase_ms_last_step": ph}
-        # (a) the same jobs on ONE rank (no broadcast): what sharing the factor is compared with
-        leg["name"] = "one_rank_same_job"
-        if rank == 0:
-            e1 = post.HipEngine(pkg, w, device_index=local, batch=eng.batch, values=eng.values_host, rhs=eng.rhs[:, 0, :].cpu().numpy(), keep_l=keep_l)
-            for kr in [args.samples] + regimes:
-                j1 = post.ShardedPosterior(e1, k_samples=kr, replicate_factor=True, keep_samples=False)
-                if kr == args.samples:
-                    j1.prepare()
-                j1.step(0)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for s in range(3):
-                    j1.step(1 + s)
-                torch.cuda.synchronize()
-                t1 = (time.perf_counter() - t0) / 3
-                rec = {"ms_per_step": 1e3 * t1, "value": e1.batch * (1 + kr) / t1,
-                       "note": f"rank 0 alone: factor + mean + {kr} samples per posterior, no broadcast"}
-                if kr == args.samples:
-                    side["one_rank_same_job"] = rec
-                    rec["n_rank_over_one_rank"] = (out["value"] if shared else side["shared_factor"]["value"]) / rec["value"]
-                else:
-                    reg[str(kr)]["one_rank"] = rec
-                    reg[str(kr)]["n_rank_over_one_rank"] = reg[str(kr)]["value"] / rec["value"]
-            side["regimes"] = reg
-            e1.F.close()
-        eng.F.close()
-        sync()
-        # (b) C4: elliptic 512^2, 256 samples sharded over the ranks, one shared factor
-        leg["name"] = "c4_elliptic512"
         try:
-            w4 = pkg.workloads.make("elliptic512")
-            k4 = max(1, 256 // world)
-            e4, j4 = shared_job(w4, 1, k4)
+            if not shared:
+                # (s) north_star's split beside the headline: the shared-factor job at the headline's samples per posterior
+                leg["name"] = "shared_factor"
+                pj.close()                    # the headline's posteriors (streams x batch of them) leave the HBM first
+                pj = None
+                steps_s = max(2, args.steps // 4)
+                eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1)
+                if rank == 0:
+                    side["shared_factor"] = dict({"value": per_s * steps_s / el_s, "unit": "solves/s", "ms_per_step": 1e3 * el_s / steps_s,
+                                                  "steps": steps_s, "workload": wl_s, "sharding": sh_s}, **rec_s)
+            # (r) the same shared-factor job at more samples per factor and rank: the factor (and its broadcast) is paid once
+            # per posterior, the sample sweeps scale with the ranks -- which regime reaches what multiple of one rank
+            leg["name"] = "regimes"
+            regimes = [int(x) for x in args.regimes.split(",") if x.strip()]
+            reg = {}
+            for kr in regimes:
+                jr = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=kr, group=args.group,
+                                           force_shared=args.force_shared, keep_samples=False, timing=True)
+                jr.step(1 << 21)
 
-            def run4(first, count):
-                for s in range(count):
-                    j4.step(first + s)
-            run4(0, 1)
-            el4 = timed(run4, sync, dist, torch, 1, 3)
+                def run_r(first, count, jr=jr):
+                    for s in range(count):
+                        jr.step(first + s)
+                el = timed(run_r, sync, dist, torch, 0, 3)
+                ph = gather_phases(jr)
+                if rank == 0:
+                    reg[str(kr)] = {"value": jr.solves_per_step() * 3 / el, "unit": "solves/s", "ms_per_step": 1e3 * el / 3,
+                                    "samples_per_posterior_and_rank": kr, "phase_ms_last_step": ph}
+            # (a) the same jobs on ONE rank (no broadcast): what sharing the factor is compared with
+            leg["name"] = "one_rank_same_job"
             if rank == 0:
-                side["c4_elliptic512"] = {"ms_per_job": 1e3 * el4 / 3, "value": (1 + k4 * world) * 3 / el4, "unit": "solves/s",
-                                          "samples_total": k4 * world, "samples_per_rank": k4,
-                                          "workload": f"{w4.name}: n={w4.n}, {w4.n_blocks} blocks x {w4.block_size}"}
-            e4.F.close()
+                e1 = post.HipEngine(pkg, w, device_index=local, batch=eng.batch, values=eng.values_host, rhs=eng.rhs[:, 0, :].cpu().numpy(), keep_l=keep_l)
+                for kr in [args.samples] + regimes:
+                    j1 = post.ShardedPosterior(e1, k_samples=kr, replicate_factor=True, keep_samples=False)
+                    if kr == args.samples:
+                        j1.prepare()
+                    j1.step(0)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for s in range(3):
+                        j1.step(1 + s)
+                    torch.cuda.synchronize()
+                    t1 = (time.perf_counter() - t0) / 3
+                    rec = {"ms_per_step": 1e3 * t1, "value": e1.batch * (1 + kr) / t1,
+                           "note": f"rank 0 alone: factor + mean + {kr} samples per posterior, no broadcast"}
+                    if kr == args.samples:
+                        side["one_rank_same_job"] = rec
+                        rec["n_rank_over_one_rank"] = (out["value"] if shared else side["shared_factor"]["value"]) / rec["value"]
+                    else:
+                        reg[str(kr)]["one_rank"] = rec
+                        reg[str(kr)]["n_rank_over_one_rank"] = reg[str(kr)]["value"] / rec["value"]
+                side["regimes"] = reg
+                e1.F.close()
+            eng.F.close()
+            sync()
+            # (b) C4: elliptic 512^2, 256 samples sharded over the ranks, one shared factor
+            leg["name"] = "c4_elliptic512"
+            try:
+                w4 = pkg.workloads.make("elliptic512")
+                k4 = max(1, 256 // world)
+                e4, j4 = shared_job(w4, 1, k4)
+
+                def run4(first, count):
+                    for s in range(count):
+                        j4.step(first + s)
+                run4(0, 1)
+                el4 = timed(run4, sync, dist, torch, 1, 3)
+                if rank == 0:
+                    side["c4_elliptic512"] = {"ms_per_job": 1e3 * el4 / 3, "value": (1 + k4 * world) * 3 / el4, "unit": "solves/s",
+                                              "samples_total": k4 * world, "samples_per_rank": k4,
+                                              "workload": f"{w4.name}: n={w4.n}, {w4.n_blocks} blocks x {w4.block_size}"}
+                e4.F.close()
+            except Exception as e:      # noqa: BLE001
+                if rank == 0:
+                    side["c4_elliptic512"] = {"error": repr(e)[:300]}
+            sync()
+            if shared:
+                # (c) independent problems per rank (the default headline's mode): no data-path collective
+                leg["name"] = "problems_mode"
+                pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
+                pj.run(0, 1)
+                steps_p = max(2, args.steps // 4)
+                elp = timed(pj.run, sync, dist, torch, 1, steps_p)
+                if rank == 0:
+                    side["problems_mode"] = {"value": world * pj.solves_per_step() * steps_p / elp, "unit": "solves/s",
+                                             "ms_per_step": 1e3 * elp / steps_p, "steps": steps_p,
+                                             "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
+                pj.close()
+                pj = None
         except Exception as e:      # noqa: BLE001
-            if rank == 0:
-                side["c4_elliptic512"] = {"error": repr(e)[:300]}
-        sync()
-        if shared:
-            # (c) independent problems per rank (the default headline's mode): no data-path collective
-            leg["name"] = "problems_mode"
-            pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l)
-            pj.run(0, 1)
-            steps_p = max(2, args.steps // 4)
-            elp = timed(pj.run, sync, dist, torch, 1, steps_p)
-            if rank == 0:
-                side["problems_mode"] = {"value": world * pj.solves_per_step() * steps_p / elp, "unit": "solves/s",
-                                         "ms_per_step": 1e3 * elp / steps_p, "steps": steps_p,
-                                         "note": f"{pj.n_streams} streams x batch {pj.batch} independent posteriors per rank, no data-path collective"}
-            pj.close()
-            pj = None
+            # a leg that fails the same way on every rank (an API error, memory) must not cost the headline: record it and go on
+            # to the end; a failure on ONE rank leaves the others in a collective, which the watchdog above ends
+            side["error"] = f"leg '{leg['name']}' raised on rank {rank}: {repr(e)[:300]}; exit code 4"
+            sys.stderr.write(f"bench.py rank {rank}: {side['error']}\n")
+            leg["failed"] = True
         if rank == 0:
             out["side_legs"] = side
         watchdog.cancel()
@@ -893,6 +902,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if leg_state.get("failed"):
+        sys.exit(4)             # the line is out; a side leg raised on this rank
 
 
 if __name__ == "__main__":
