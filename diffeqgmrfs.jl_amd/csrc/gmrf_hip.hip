@@ -886,19 +886,23 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                       sa.pX, pW, sa.pX));
             const int m3 = nt - j - 4;                             // row tiles below the panel
             if (m3 <= 0) continue;
+            // Split representation with p = the panel width and no L blocks kept: L[p:, 0:p] is read by this panel's own
+            // update only, so it is formed directly in the place it takes in Linv's storage (see gmrf_handle::xsplit)
+            const bool in_slot = (j == 0 && h->xsplit == 256 && !h->keep_l);
+            double* Lb = in_slot ? X + oc * ld + oa : L + oc * ld + oa;
+            const int64_t pLb = in_slot ? sa.pX : sa.pL;
             // L[below, P] = S[below, P] X_P^T: b(k, n) = X_P[n][k], zero for k > n (tile-K units: 1 + 2 + 3 + 4 of 16)
-            GCHK(gemm(h, false, false, 64 * m3, 256, 256, TRI_B_UPPER, 0, 1.0, S + oc * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + oc * ld + oa, ld,
-                      sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 10.0 * m3 * nb));
+            GCHK(gemm(h, false, false, 64 * m3, 256, 256, TRI_B_UPPER, 0, 1.0, S + oc * ld + oa, ld, X + oa * ld + oa, ld, 0.0, Lb, ld,
+                      sa.pS, sa.pX, pLb, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 10.0 * m3 * nb));
             // S[r,c] -= L[r,P] L[c,P]^T for the tiles right of / below the panel
-            const double* Lp = L + oc * ld + oa;
-            GCHK(gemm(h, false, false, m3 * 64, m3 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + oc * ld + oc, ld, sa.pL, sa.pL, sa.pS,
+            GCHK(gemm(h, false, false, m3 * 64, m3 * 64, 256, 0, 1, -1.0, Lb, ld, Lb, ld, 1.0, S + oc * ld + oc, ld, pLb, pLb, sa.pS,
                       1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m3 * (m3 + 1) / 2) * nb));
         }
         // X = L^-1 by recursive doubling over the 256-wide diagonal inverses -- or, split representation, everything
         // but its first block column below row p, whose place L[p:, 0:p] takes (see gmrf_handle::xsplit)
         const int p = h->xsplit;
         GCHK(doubling_levels(h, L, X, T, 256, bsp / 2, -1, p));
-        if (p > 0) {
+        if (p > 0 && !(p == 256 && !h->keep_l)) {
             hipLaunchKernelGGL(copy_rect, dim3((unsigned)((bsp - p) / 4), (unsigned)h->B), dim3(256), 0, h->stream,
                                L + (int64_t)p * ld, ld, sa.pL, X + (int64_t)p * ld, ld, sa.pX, bsp - p, p);
             HIPCHK(hipGetLastError());
