@@ -414,7 +414,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="darcy256")
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=32, help="independent problems per handle and step")
+    ap.add_argument("--batch", type=int, default=64, help="independent problems per handle and step (4 x 64 darcy256 posteriors = 260 GB of the 288 GB)")
     ap.add_argument("--streams", type=int, default=4,
                     help="independent batched handles per GPU, each on its own HIP stream and host thread")
     ap.add_argument("--mode", choices=["auto", "problems", "shared-factor"], default="auto",

@@ -1237,7 +1237,7 @@ def _darcy_batch(pkg, n_xy, B, n_distinct=8):
 
 
 def test_measured_path_darcy256_batch_against_oracle(pkg):
-    """The code path the headline number is measured on -- darcy256, a batch of 32 problems (8 distinct coefficient
+    """The code path the headline number is measured on -- darcy256, a batch of 64 problems (bench.py's default; 8 distinct coefficient
     fields, as bench.py cycles them: every launch has the grid and the kernel symbol of the timed job),
     keep_l = 0, on a StreamSet stream, HipEngine / ShardedPosterior.step with the second step replayed from the
     captured graphs (128-column diagonal blocks + GEMM panels + rank-256 GEMM updates on the LDS-DMA kernel, doubling
@@ -1248,10 +1248,10 @@ def test_measured_path_darcy256_batch_against_oracle(pkg):
     from importlib import import_module
     from tests import measured_path as MP
     post = import_module(pkg.__name__ + ".posterior")
-    w, vals, rhs = _darcy_batch(pkg, 256, 32)
+    w, vals, rhs = _darcy_batch(pkg, 256, 64)
     w.meta.setdefault("cond", 3.4e9)
     tol = solve_tol(w)
-    res = MP.run(pkg, post, O, w.Q, w.n_blocks, vals, rhs, k_samples=64, check=(1, 30), last_blocks=8, rbmc_k=50,
+    res = MP.run(pkg, post, O, w.Q, w.n_blocks, vals, rhs, k_samples=64, check=(1, 62), last_blocks=8, rbmc_k=50,
                  true_var_samples=24)
     print("measured path:", res)
     route = res["route"]
@@ -1262,7 +1262,7 @@ def test_measured_path_darcy256_batch_against_oracle(pkg):
         assert route.get(cls, 0) > 0, (cls, route)
     for cls in (1, 2, 8, 9):
         assert route.get(cls, 0) == 0, (cls, route)
-    for p in (1, 30):
+    for p in (1, 62):
         r = res[p]
         assert r["mean_rel_l2"] < tol and r["samples_rel_l2"] < tol, r
         assert r["logdet_rel"] < 1e-10, r

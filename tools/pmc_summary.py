@@ -43,5 +43,5 @@ if len(sys.argv) > 3:
         except OSError:
             pass
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 (MI355X_MICROARCH.md, HBM section; "
-                         "calibrated: tools/fetch_calib.hip); bench.py --steps 1 --warmup 1 --streams 1 --no-single-problem",
-               "batch": 32, "head": head, "kernels": table}, open(sys.argv[3], "w"), indent=1)
+                         "calibrated: tools/fetch_calib.hip); bench.py --steps 1 --warmup 1 --streams 1 --no-single-problem (default batch)",
+               "batch": int(os.environ.get("GMRF_PROFILE_BATCH", "64")), "head": head, "kernels": table}, open(sys.argv[3], "w"), indent=1)
