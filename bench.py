@@ -99,6 +99,25 @@ def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
     return None, None
 
 
+def pmc_traffic_weighted(file_stem: str, prefix: str, batch=None):
+    """Launch-weighted HBM bytes per launch over every kernel symbol that starts with `prefix` in the newest committed
+    snapshot (see pmc_traffic).  Returns (bytes, source) or (None, None)."""
+    for rnd in ("r03", "r02"):
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")))
+        except Exception:
+            continue
+        if batch is not None and prof.get("batch", batch) != batch:
+            continue
+        rows = [v for k, v in prof["kernels"].items() if k.startswith(prefix)]
+        n = sum(r["launches"] for r in rows)
+        if n:
+            tot = sum(r["launches"] * (r["read_bytes_per_launch"] + r["write_bytes_per_launch"]) for r in rows)
+            return tot / n, (f"snapshot: profiles/{rnd}_{file_stem}.json ({len(rows)} symbols {prefix}*, launch-weighted; rocprofv3 --pmc FETCH_SIZE x2 + "
+                             f"WRITE_SIZE, separate passes, taken at commit {prof.get('head', '?')}; this run is {git_head()})")
+    return None, None
+
+
 def cpu_sparse_direct(w, k_samples: int):
     """Secondary CPU comparator: a general sparse direct solver on the same posterior
     precision -- what the reference's scripts really call (CHOLMOD there; SuperLU via SciPy here,
@@ -821,13 +840,11 @@ def main():
             # GEMV launches stream.  Beside it the same launches timed one by one in eager mode (an event pair per
             # launch adds the dispatch gap: 28.7 us against 23.9 us per launch in the rocprofv3 trace).
             g_graph = 2.0 * s1["sweep_bytes_streamed"] / (s1["solve_ms"] * 1e-3) / 1e9      # (stats: bytes of ONE sweep)
-            # PMC traffic per launch, launch-weighted over the four sweep symbols (X / C products, forward / backward)
+            # PMC traffic per launch, launch-weighted over every sweep_gemv* symbol of the profiled step (coupling window, X_aa /
+            # L_ba / X_bb parts, forward / backward)
             sweep_traffic, sweep_traffic_src = None, None
             if w.name == "darcy256":
-                got, sweep_traffic_src = pmc_traffic("hbm_traffic", ["sweep_gemv_n<true", "sweep_gemv_t<true", "sweep_gemv_n<false", "sweep_gemv_t<false"],
-                                                     batch=eng.batch)
-                if got:
-                    sweep_traffic = sum(got.values()) / len(got)
+                sweep_traffic, sweep_traffic_src = pmc_traffic_weighted("hbm_traffic", "sweep_gemv", batch=eng.batch)
             g3 = work[3] / (ms[3] * 1e-3) / 1e9
             out["roofline_sweep"] = {"bound": "hbm", "achieved": g_graph, "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                                      "frac": g_graph / PEAK_HBM_GBPS, "kernel": "sweep_gemv_n / sweep_gemv_t",
