@@ -754,7 +754,7 @@ static int planned_xsplit(const gmrf_handle* h) {
     const int bsp = (int)h->bsp, nt = bsp / 64;
     if (h->no_xsplit || h->N <= 0 || nt < 8 || nt % 4 != 0) return 0;
     const bool lone_fused = (h->B == 1 && !h->split_step);
-    if (lone_fused || h->left_looking || h->rank64_panels || h->fork_graph) return 0;
+    if (lone_fused || h->left_looking || h->rank64_panels || h->panels128 || h->fork_graph) return 0;
     int p = 256;
     while (2 * p <= (int)h->cmin) p *= 2;
     return (h->cmin >= 256 && p < bsp) ? p : 0;
@@ -867,13 +867,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                               sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m2 * (m2 + 1) / 2) * nb));
                 }
             }
-            GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1, h->xsplit));
-            if (h->xsplit > 0) {
-                const int p = h->xsplit;
-                hipLaunchKernelGGL(copy_rect, dim3((unsigned)((bsp - p) / 4), (unsigned)h->B), dim3(256), 0, h->stream,
-                                   L + (int64_t)p * ld, ld, sa.pL, X + (int64_t)p * ld, ld, sa.pX, bsp - p, p);
-                HIPCHK(hipGetLastError());
-            }
+            GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
             return GMRF_OK;
         }
         for (int j = 0; j < nt; j += 4) {
