@@ -848,6 +848,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             return GMRF_OK;
         };
         if (h->panels128) {
+            if (h->xsplit > 0) return bad_shape("internal: split inverse planned for the 128-column panel variant");
             for (int j = 0; j < nt; j += 2) {
                 GCHK(diag128(j));
                 const int m2 = nt - j - 2;                         // row tiles below the diagonal block
@@ -909,6 +910,8 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         }
         return GMRF_OK;
     }
+    // (only the 256-column panel route above leaves the split form: planned_xsplit mirrors its conditions)
+    if (h->xsplit > 0) return bad_shape("internal: split inverse planned off the 256-column panel route");
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.j = j; sa.nt = nt;
