@@ -302,6 +302,23 @@ def full_loop(pkg, torch, n_xy: int, batch: int, local: int, with_cpu: bool, sam
 
 
 
+def fit_batch(torch, w, local, batch, n_streams, samples, keep_l):
+    """Largest batch <= `batch` (a multiple of 8) whose T x B posteriors fit the free HBM: per posterior the block inverses,
+    the coupling blocks (dense bound), five work blocks, three right-hand-side panels, the sample output (darcy256: 1.03 GB per posterior estimated, 1.01 measured).
+    The default (4 x 64 darcy256 = 260 GB) is sized for the 288 GB of an MI355X; a card with less free memory gets a
+    smaller batch instead of an out-of-memory error, and the line says so."""
+    free_b, _ = torch.cuda.mem_get_info(local)
+    bsp = 64
+    while bsp < w.block_size:
+        bsp *= 2
+    N = w.n_blocks
+    per = 8.0 * bsp * bsp * (N * (2 if keep_l else 1) + 0.6 * max(N - 1, 0) + 5) + 8.0 * N * bsp * (3 * max(samples, 16) + samples + 4)
+    b = batch
+    while b > 8 and n_streams * b * per * 1.01 > free_b:
+        b -= 8
+    return b
+
+
 class ProblemsJob:
     """T handles x batch B of independent posteriors on T streams / host threads (no collective)."""
 
@@ -604,6 +621,14 @@ def main():
         eng, elapsed, per_step, rec_s, workload, sharding = run_shared(args.steps, args.warmup)
         extra["shared_factor"] = rec_s
     else:
+        fit = fit_batch(torch, w, local, args.batch, max(1, args.streams), args.samples, keep_l)
+        if dist is not None:            # every rank runs the same batch
+            box = [None] * world
+            dist.all_gather_object(box, fit)
+            fit = min(box)
+        if fit != args.batch:
+            extra["batch_reduced"] = {"from": args.batch, "to": fit, "why": "free HBM on the card"}
+            args.batch = fit
         pj = ProblemsJob(pkg, post, w, torch, local, args.config, args.batch, max(1, args.streams), args.samples, rank, keep_l,
                          args.eager_flags)
         eng, job = pj.eng, pj.job
