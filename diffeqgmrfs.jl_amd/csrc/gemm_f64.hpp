@@ -716,6 +716,8 @@ inline double gemm_estimate_us(bool big, const GemmArgs& g, int batch) {
     return makespan;
 }
 
+inline bool gemm_uses_dma(bool a_t, const GemmArgs& g, int batch);      // (gemm_f64_dma.hpp)
+
 // Which kernel a launch takes (also used for the per-kernel statistics).
 inline bool gemm_uses_big(bool a_t, const GemmArgs& g, int batch) {
     if (a_t || g.M % GEMM_BIG || g.N % GEMM_BIG || g.K % GEMM_BIG_BK || (g.tri & ~15) || g.stamps) return false;
@@ -723,6 +725,11 @@ inline bool gemm_uses_big(bool a_t, const GemmArgs& g, int batch) {
     const int policy = gemm_big_policy();
     if (policy == 1) return true;
     if (policy == 2) return false;
+    // The makespan model below was calibrated against the register-staged 64 x 64 kernel; a launch that the LDS-DMA kernel
+    // takes is faster there than the model thinks, and the 82 KB of LDS of a 128 x 128 workgroup cost the other streams more
+    // than they save (found at batches of 40 / 48 / 56 problems, which the model sent here: 4 x 48 41.3 k solves/s against
+    // 44.8 k at 4 x 32 and 47.5 k at 4 x 56)
+    if (gemm_uses_dma(a_t, g, batch)) return false;
     if ((int64_t)(g.M / GEMM_BIG) * (g.N / GEMM_BIG) * batch < 64) return false;
     // the choice depends on the shape only: remember it (launchers run on several host threads)
     static std::mutex mu;
