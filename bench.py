@@ -314,9 +314,12 @@ def fit_batch(torch, w, local, batch, n_streams, samples, keep_l):
     N = w.n_blocks
     per = 8.0 * bsp * bsp * (N * (2 if keep_l else 1) + 0.6 * max(N - 1, 0) + 5) + 8.0 * N * bsp * (3 * max(samples, 16) + samples + 4)
     b = batch
-    while b > 8 and n_streams * b * per * 1.01 > free_b:
-        b -= 8
-    return b
+    fits = lambda x: n_streams * x * per * 1.01 <= free_b
+    while b > 1 and not fits(b):
+        b = b - 8 if b > 8 else b - 1            # multiples of 8 first (XCD grouping), then one by one
+        if b > 8:
+            b -= b % 8
+    return b                                     # (b == 1 may still not fit: the handles' allocation then reports it)
 
 
 class ProblemsJob:

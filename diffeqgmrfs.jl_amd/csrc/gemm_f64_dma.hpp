@@ -306,6 +306,10 @@ inline int gemm_dma_shape(bool a_t, const GemmArgs& g, int batch) {
     const int policy = gemm_dma_force() ? 2 : gemm_dma_policy();
     if (policy == 0 || a_t || g.stamps || (g.tri & ~15) || g.K % DMA_BK || g.M % 64 || g.N % 64) return 0;
     if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((g.strideA | g.strideB | g.pA | g.pB) & 1)) return 0;
+    // the B [k][n] epilogue loads the addend and stores the result as 16-byte pieces
+    if (((uintptr_t)g.C & 15) || (g.ldc & 1) || ((g.strideC | g.pC) & 1)) return 0;
+    if (g.D && (((uintptr_t)g.D & 15) || (g.ldd & 1) || (g.pD & 1))) return 0;
+    if ((int64_t)g.M * g.ldc * 8 >= ((int64_t)1 << 32) || (g.D && (int64_t)g.M * g.ldd * 8 >= ((int64_t)1 << 32))) return 0;
     // 32-bit byte offsets inside a problem's operand
     if ((int64_t)g.M * g.lda * 8 >= ((int64_t)1 << 32) || (int64_t)std::max(g.N, g.K) * g.ldb * 8 >= ((int64_t)1 << 32)) return 0;
     const int force = gemm_dma_force();

@@ -30,6 +30,7 @@
 #include "microbench.hpp"
 #include "misc_kernels.hpp"
 #include "potrf_step.hpp"
+#include "potrf_persist.hpp"
 #include "sweep.hpp"
 #include "swe_assemble.hpp"
 #include "fem_assemble_p2.hpp"
@@ -39,6 +40,7 @@ using namespace gmrf;
 static thread_local std::string g_last_error;
 static double g_tile_us = 0.0;
 static unsigned long long g_tile_stamps[32];
+static unsigned long long g_persist_stamps[128];    // chain workgroup of the last gmrf_test_potrf_block (potrf_persist.hpp)
 
 #define HIPCHK(expr)                                                                        \
     do {                                                                                    \
@@ -193,6 +195,14 @@ struct gmrf_handle {
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
     bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
     bool panels128 = false;            // batches: rows below a diagonal block meet the 128 x 128 inverses one by one (K = 128 products; comparison)
+    // One problem: the in-block Cholesky as ONE persistent launch per block / per 256-column panel (potrf_persist.hpp) instead of a
+    // launch per 64-column step.  Needs every workgroup resident (1 + tiles <= CUs); a wait that gives up sets d_info[1], and
+    // factor_finish then repeats the factorisation with the launch-per-step form and keeps it for this handle.
+    bool no_persist = false;           // set_eager bit 13, or a persistent launch gave up
+    int persist_aborts = 0;
+    int cu_count = 0;
+    unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zeroed by a memset node ahead of each)
+    int64_t pflags_words = 0;
     bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
@@ -413,6 +423,14 @@ static gmrf_status alloc_work(gmrf_handle* h) {
     HIPCHK(hipMalloc(&h->d_T, blk));
     HIPCHK(hipMalloc(&h->d_W, blk));
     HIPCHK(hipMalloc(&h->d_logdet, sizeof(double) * h->N * h->B));
+    {   // flag words of the persistent in-block launches (potrf_persist.hpp), one set per problem
+        const int64_t words = (int64_t)persist_flag_words((int)(h->bsp / 64)) * h->B;
+        if (!h->d_pflags || h->pflags_words < words) {
+            free_dev(h->d_pflags); h->d_pflags = nullptr; h->pflags_words = 0;
+            HIPCHK(hipMalloc(&h->d_pflags, sizeof(unsigned) * (size_t)words));
+            h->pflags_words = words;
+        }
+    }
     h->alloc_N = h->N; h->alloc_bsp = h->bsp; h->alloc_B = h->B;
     h->stats.factor_bytes = (int64_t)(blk * ((h->keep_l ? 2 : 1) * h->N) + (size_t)stride_pC(h) * sizeof(double) * (size_t)h->B);
     return GMRF_OK;
@@ -695,6 +713,7 @@ static gmrf_status doubling_levels(gmrf_handle* h, double* L, double* X, double*
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
     const int64_t pL = stride_pL(h), pX = stride_pX(h), pW = (int64_t)bsp * bsp;
+    if (split > 0 && half >= 0) return bad_shape("internal: the split inverse is not assembled half by half");
     for (int hh = lo; hh <= hi && hh < bsp; hh *= 2) {
         int pairs = bsp / (2 * hh), first = 0;
         if (half >= 0) { pairs /= 2; first = half * pairs; }
@@ -760,6 +779,36 @@ static int planned_xsplit(const gmrf_handle* h) {
     return (h->cmin >= 256 && p < bsp) ? p : 0;
 }
 
+// One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles: the flag words are zeroed by
+// a memset node ahead of it (re-initialised on every graph replay).  false: this shape does not fit the chip (every workgroup
+// must be resident: 140 KB of LDS = one per CU) or the form is switched off.
+static bool persist_fits(const gmrf_handle* h, int nt, int j0, int j1, int xrows) {
+    if (h->no_persist || h->B != 1 || h->cu_count <= 0) return false;
+    static const int margin = [] { const char* e = getenv("GMRF_PERSIST_CU_MARGIN"); return e ? atoi(e) : 0; }();   // tuning aid
+    return 1 + persist_tiles(nt, j0, j1, xrows) + margin <= h->cu_count;
+}
+
+static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* X, int nt, int j0, int j1, int xrows, int blk_id,
+                                  double flops) {
+    const int words = persist_flag_words(nt);
+    if (!h->d_pflags || h->pflags_words < (int64_t)words * h->B) return bad_shape("internal: flag words of the persistent launches not allocated");
+    HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)words * (size_t)h->B, h->stream));
+    PersistArgs pa;
+    pa.S = S; pa.L = L; pa.X = X; pa.ld = h->bsp; pa.nt = nt; pa.j0 = j0; pa.j1 = j1; pa.xrows = xrows;
+    pa.info = h->d_info; pa.blk = blk_id;
+    pa.pS = h->bsp * h->bsp; pa.pL = stride_pL(h); pa.pX = stride_pX(h); pa.blk_per_problem = (int)h->N;
+    pa.flags = h->d_pflags; pa.flag_stride = words;
+    pa.abort_word = reinterpret_cast<unsigned*>(h->d_info + 1);
+    static const unsigned limit = [] { const char* e = getenv("GMRF_PERSIST_SPIN_MS"); return (unsigned)(e ? atoi(e) : 2000) * 100000u; }();   // 100 MHz ticks
+    pa.spin_limit = limit;
+    pa.stamps = h->dbg_stamps;
+    ProfScope ps(h, 1, flops);
+    hipLaunchKernelGGL(potrf_persist<false>, dim3(1 + persist_tiles(nt, j0, j1, xrows), (unsigned)h->B), dim3(256), POTRF_PERSIST_LDS,
+                       h->stream, pa);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
 static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, double* T, int blk_id) {
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp;
@@ -787,6 +836,17 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     if (overlap && !h->aux) HIPCHK(hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (overlap) { GCHK(fork_event(h, &ev_fork)); GCHK(fork_event(h, &ev_join)); }
+    if (fused && !h->no_lookahead && !h->doubling_x && !overlap && nt >= 2 && persist_fits(h, nt, 0, nt, 1)) {
+        // One problem, ONE launch per block: the look-ahead chain below with flags in place of its launch boundaries
+        // (potrf_persist.hpp; same arithmetic, bitwise the same factor and inverse)
+        const double t3 = 64.0 * 64.0 * 64.0;
+        double fl = t3 / 3.0 * nt;
+        for (int j = 0; j + 1 < nt; ++j) {
+            const int m = nt - j - 1;
+            fl += (double)m * t3 + 2.0 * t3 * (m * (m + 1) / 2) + 2.0 * t3 * (0.5 * (double)(j + 1) * (j + 2) + 0.625 * (j + 1));
+        }
+        return launch_persist(h, S, L, X, nt, 0, nt, 1, blk_id, fl);
+    }
     if (fused && !h->no_lookahead && !h->doubling_x && !overlap && nt >= 2) {
         // One problem, look-ahead chain (potrf_step, `lookahead`): tile 0 alone, then per step j ONE launch in which
         // workgroup 0 forms L[j+1,j], updates tile (j+1,j+1) in LDS and factors it for the next launch while the other
@@ -925,7 +985,26 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const double rem = 64.0 * m, nb = (double)h->B;
         const double f_tile = 64.0 * 64.0 * 64.0 / 3.0 * nb, f_panel = rem * 64.0 * 64.0 * nb;
         const double f_upd = 2.0 * 64.0 * 64.0 * 64.0 * utiles * nb;
-        if (fused || m == 0) {
+        if (fused_in_panel && !h->no_lookahead && !overlap && j % pw == 0 && cend - j >= 2 && persist_fits(h, nt, j, cend, 0)) {
+            // One problem, larger blocks: the panel's column tiles [j, cend) as ONE persistent launch (potrf_persist.hpp): the
+            // look-ahead chain over the panel's own columns; the last column's rows below (potrf_panel) and the rank-256
+            // update of the rest of the block (GEMM) follow as before
+            const int npc = cend - j;
+            double fl = 64.0 * 64.0 * 64.0 / 3.0 * npc;
+            for (int jj = j; jj + 1 < cend; ++jj) {
+                int ut = 0;
+                for (int c = jj + 1; c < cend; ++c) ut += nt - c;
+                fl += 64.0 * (nt - jj - 1) * 64.0 * 64.0 + 2.0 * 64.0 * 64.0 * 64.0 * ut;
+            }
+            GCHK(launch_persist(h, S, L, X, nt, j, cend, 0, blk_id, fl));
+            j = cend - 1;                                     // the loop continues with the panel's last column
+            sa.j = j;
+            const int ml = nt - j - 1;
+            if (ml > 0) {
+                ProfScope ps(h, 8, 64.0 * ml * 64.0 * 64.0);
+                hipLaunchKernelGGL(potrf_panel, dim3(ml, 1), dim3(256), 0, h->stream, sa);
+            }
+        } else if (fused || m == 0) {
             // one problem, fused steps: the tiles of row j - 1 of the inverse ride in the launch of step j (4 workgroups
             // per tile on CUs the step leaves idle; see xrow_strip), the last row gets a launch of its own below
             const bool xrows = fused && !h->doubling_x && !overlap && j >= 2;
@@ -1177,9 +1256,20 @@ static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
 }
 
 static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
-    int hinfo = 0;
-    HIPCHK(hipMemcpyAsync(&hinfo, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    int hinfo2[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(hinfo2, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (hinfo2[1] != 0) {
+        // a wait inside a persistent launch gave up (its workgroups were not all resident, or starved): every such launch
+        // has drained; repeat the numeric phase with the launch-per-step form, which this handle keeps from now on
+        h->no_persist = true; h->persist_aborts++;
+        destroy_graphs(h);
+        HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
+        GCHK(factor_blocks_range(h, 0, h->N));
+        HIPCHK(hipMemcpyAsync(hinfo2, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    int hinfo = hinfo2[0];
     if (info) *info = hinfo;
     if (hinfo != 0) {
         h->factored = false;
@@ -1203,7 +1293,7 @@ static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* 
     }
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     GCHK(load_values(h, nzval));
-    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
     GCHK(run_factor(h, 0, h->N));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     gmrf_status s = factor_finish(h, info);
@@ -1449,13 +1539,16 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     h->device = device;
     if (stream) { h->stream = (hipStream_t)stream; h->own_stream = false; }
     else { HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
-    HIPCHK(hipMalloc(&h->d_info, sizeof(int)));
-    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    HIPCHK(hipMalloc(&h->d_info, 4 * sizeof(int)));           // [0] info, [1] abort word of the persistent kernel
+    HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_PERSIST_LDS));
+    HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
+    { const char* e = getenv("GMRF_PERSIST"); if (e && atoi(e) == 0) h->no_persist = true; }      // tuning aid
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128_slim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(gemm_init());
     HIPCHK(gemm_dma_init());
@@ -1474,7 +1567,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
-    free_dev(h->d_info); free_dev(h->d_logdet);
+    free_dev(h->d_info); free_dev(h->d_logdet); free_dev(h->d_pflags);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
     free_dev(h->d_stage); free_dev(h->d_mean); free_dev(h->d_acc);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -1530,6 +1623,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 1024) != 0) != h->rank64_panels) { destroy_graphs(h); h->rank64_panels = (eager & 1024) != 0; }
     if (((eager & 2048) != 0) != h->panels128) { destroy_graphs(h); h->panels128 = (eager & 2048) != 0; }
     if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
+    if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -1568,7 +1662,7 @@ gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks
         h->c_dirty = false;
     }
     GCHK(load_values(h, nzval));
-    HIPCHK(hipMemsetAsync(h->d_info, 0, sizeof(int), h->stream));
+    HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
     h->factored = false;
     return GMRF_OK;
 }
@@ -1738,8 +1832,19 @@ gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks) {
 // l_blocks_valid != 0: the caller also filled the L buffer (gmrf_bt_factor_buffer kind L), so F.chos / logdet work
 gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid) {
     if (!h || !h->d_Linv) return bad_shape("no factor storage");
+    HIPCHK(hipSetDevice(h->device));
+    // Representation of the block inverses: a packed image says which form ITS sender was in when it packed (the layout record
+    // may be older than that: the sender converts to the full form for get_block / export / exact variances and goes back to the
+    // split form at its next factorisation); raw buffer transfers carry no tag and follow the record.
+    int seen = 0;
+    HIPCHK(hipMemcpyAsync(&seen, h->d_info + 2, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (seen != 0) HIPCHK(hipMemsetAsync(h->d_info + 2, 0, sizeof(int), h->stream));
+    if (seen < 0) { g_last_error = "the packed ranges of this factor carry different (or no) representation tags"; return GMRF_ERR_BAD_SHAPE; }
+    const int xs = seen > 0 ? seen - 1 : h->adopt_xsplit;
+    if (xs < 0 || xs >= h->bsp || xs % 64) { g_last_error = "bad representation tag in the packed image"; return GMRF_ERR_BAD_SHAPE; }
     h->factored = true;
-    h->xsplit = h->adopt_xsplit;
+    h->xsplit = xs;
     h->l_valid = l_blocks_valid != 0 && h->keep_l;
     // the log-determinant parts travel inside the packed transport image (gmrf_bt_unpack_blocks_async): valid once
     // every block of this factor came that way; a factor moved as raw buffers has none (logdet then needs the L blocks)
@@ -1784,6 +1889,7 @@ gmrf_status gmrf_bt_block_range(gmrf_handle* h, int32_t kind, int64_t i0, int64_
 // Packed transport image of the blocks [i0, i1) of every problem of the batch: per problem one segment of
 //   (i1 - i0) * ntri * 4096   lower-triangular 64 x 64 tiles of Linv_i0 .. Linv_{i1-1} (linv_tiles_copy),
 //   (c1 - c0) * c_blk          stored windows of the coupling blocks C_{i0-1} .. C_{i1-2},
+//   2                          representation tag {xsplit of the sender, magic} (pack_tag_write: the receiver's commit follows it)
 //   (i1 - i0) rounded to even  log-determinant parts of the blocks
 // doubles: darcy256 0.56 GB per posterior instead of the 0.83 GB of the raw Linv / C buffers.
 static void packed_counts(const gmrf_handle* h, int64_t i0, int64_t i1, int64_t* x_elems, int64_t* c_elems, int64_t* ld_elems,
@@ -1792,7 +1898,7 @@ static void packed_counts(const gmrf_handle* h, int64_t i0, int64_t i1, int64_t*
     const int64_t c0 = std::max<int64_t>(i0 - 1, 0), c1 = std::max<int64_t>(i1 - 1, 0);
     *x_elems = (i1 - i0) * ntri * 4096;
     *c_elems = (c1 - c0) * c_blk(h);
-    *ld_elems = ((i1 - i0) + 1) / 2 * 2;
+    *ld_elems = 2 + ((i1 - i0) + 1) / 2 * 2;
     if (c0_out) *c0_out = c0;
 }
 
@@ -1831,10 +1937,16 @@ static gmrf_status pack_blocks_on(gmrf_handle* h, hipStream_t st, int64_t i0, in
                            blk_elems(h), h->bsp, (int)h->bs, h->d_logdet + i0, stride_pL(h), h->N);
         HIPCHK(hipGetLastError());
     }
-    if (pack) HIPCHK(hipMemcpy2DAsync(buf + xe + ce, seg * sizeof(double), h->d_logdet + i0, h->N * sizeof(double),
-                                      (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
-    else {
-        HIPCHK(hipMemcpy2DAsync(h->d_logdet + i0, h->N * sizeof(double), buf + xe + ce, seg * sizeof(double),
+    if (pack) {
+        if (h->B > 1024) return bad_shape("batch too large for the transport tag");
+        hipLaunchKernelGGL(pack_tag_write, dim3(1), dim3((unsigned)h->B), 0, st, buf + xe + ce, seg, (double)h->xsplit);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy2DAsync(buf + xe + ce + 2, seg * sizeof(double), h->d_logdet + i0, h->N * sizeof(double),
+                                (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(pack_tag_read, dim3(1), dim3(1), 0, st, buf + xe + ce, h->d_info + 2);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpy2DAsync(h->d_logdet + i0, h->N * sizeof(double), buf + xe + ce + 2, seg * sizeof(double),
                                 (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
         if (h->got_block.size() != (size_t)h->N) h->got_block.assign((size_t)h->N, 0);
         for (int64_t i = i0; i < i1; ++i) h->got_block[(size_t)i] = 1;
@@ -2339,15 +2451,14 @@ gmrf_status gmrf_bt_logdet(gmrf_handle* h, double* out) {
     if (!h || !out) return bad_shape("null pointer");
     if (!h->factored) { g_last_error = "logdet before factor"; return GMRF_ERR_NO_FACTOR; }
     HIPCHK(hipSetDevice(h->device));
-    if (h->keep_l) {
-        if (!h->l_valid) { g_last_error = "the L blocks of this factor are not resident"; return GMRF_ERR_NO_FACTOR; }
+    if (h->keep_l && h->l_valid) {
         hipLaunchKernelGGL(logdet_blocks, dim3((unsigned)h->N, 1), dim3(256), 0, h->stream,
                            h->d_L + h->sel * stride_pL(h), blk_elems(h), h->bsp, (int)h->bs, h->d_logdet + h->sel * h->N,
                            (int64_t)0, (int64_t)0);
         HIPCHK(hipGetLastError());
     } else if (!h->logdet_valid) {
-        // (a factor adopted as raw buffers: nothing ever filled d_logdet)
-        g_last_error = "the log-determinant parts of this factor are not resident (adopted without the packed transport image and without L)";
+        // (a factor adopted as raw buffers without its L blocks: nothing ever filled d_logdet)
+        g_last_error = "neither the L blocks nor the log-determinant parts of this factor are resident (adopted as raw buffers without L)";
         return GMRF_ERR_NO_FACTOR;
     }   // else: the factorisation (or the transport image) left every block's part in d_logdet
     std::vector<double> part((size_t)h->N);
@@ -3755,6 +3866,14 @@ gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
     return GMRF_OK;
 }
 
+// s_memtime stamps of the chain workgroup of the last gmrf_test_potrf_block that ran the persistent form: out[0] = after tile 0,
+// then per step j four stamps (flags seen, operands in LDS, tile updated, tile j + 1 published), relative to the first, in cycles
+gmrf_status gmrf_test_persist_stamps(double* out, int32_t n) {
+    if (!out || n < 1 || n > 128) return bad_shape("1 .. 128 outputs");
+    for (int i = 0; i < n; ++i) out[i] = g_persist_stamps[i] ? (double)(g_persist_stamps[i] - g_persist_stamps[0]) : -1.0;
+    return GMRF_OK;
+}
+
 gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double* Linv, int32_t* info) {
     if (bs % 64 || next_pow2(bs / 64) != bs / 64) return bad_shape("bs must be 64 * 2^p");
     gmrf_handle* h = nullptr;
@@ -3763,8 +3882,8 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
     gmrf_status s = set_layout_dense(h);
     if (s == GMRF_OK) s = alloc_factor(h);
     unsigned long long* dst = nullptr;
-    if (s == GMRF_OK && hipMalloc(&dst, 8 * sizeof(unsigned long long)) == hipSuccess) {
-        (void)hipMemset(dst, 0, 8 * sizeof(unsigned long long));
+    if (s == GMRF_OK && hipMalloc(&dst, 128 * sizeof(unsigned long long)) == hipSuccess) {
+        (void)hipMemset(dst, 0, 128 * sizeof(unsigned long long));
         h->dbg_stamps = dst;
     }
     if (s == GMRF_OK) {
@@ -3778,6 +3897,7 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
             if (hipStreamSynchronize(h->stream) != hipSuccess) s = GMRF_ERR_HIP;
             if (info) *info = hi;
             if (dst) (void)hipMemcpy(g_tile_stamps + 24, dst, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+            if (dst) (void)hipMemcpy(g_persist_stamps, dst, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
         }
     }
     if (dst) (void)hipFree(dst);

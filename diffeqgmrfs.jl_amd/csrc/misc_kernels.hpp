@@ -62,6 +62,22 @@ __global__ __launch_bounds__(256) void linv_tiles_copy(double* __restrict__ X, i
     }
 }
 
+// Representation tag of a packed transport image (gmrf_handle::xsplit of the SENDER when it packed): two doubles per problem
+// segment, {xsplit, 0x474d5246}.  The receiver's unpack leaves xsplit + 1 (or -1 if the ranges of one factor disagree / the tag is
+// not one) in a device word that gmrf_bt_adopt_commit reads: the layout record can be stale, the image cannot.
+constexpr double PACK_TAG_MAGIC = 1196249670.0;     // "GMRF"
+__global__ void pack_tag_write(double* __restrict__ buf, int64_t pbuf, double xsplit) {
+    double* q = buf + (int64_t)threadIdx.x * pbuf;
+    q[0] = xsplit; q[1] = PACK_TAG_MAGIC;
+}
+__global__ void pack_tag_read(const double* __restrict__ buf, int* __restrict__ seen) {
+    const double v = buf[0];
+    int code = (buf[1] == PACK_TAG_MAGIC && v >= 0.0 && v < 1.0e6 && v == (double)(int)v) ? (int)v + 1 : -1;
+    const int old = *seen;
+    if (old != 0 && old != code) code = -1;
+    *seen = code;
+}
+
 // ------------------------------------------------------------------------------- panels
 // user matrix (column-major n x k, leading dimension ld) <-> padded panel P[rhs][n_pad]
 // blockIdx.y = problem p: columns [p*k, (p+1)*k) of the user matrix <-> panel p (kp * n_pad doubles)

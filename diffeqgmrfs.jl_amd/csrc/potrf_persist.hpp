@@ -1,0 +1,400 @@
+// One problem (or a few): the dense Cholesky of a bs x bs Schur block (dpotrf of D_i - C C^T,
+// /root/reference/src/tridiagonal_cholesky.jl:67,77) as ONE persistent launch per block (blocks of up to 16 tiles) or per
+// 256-column panel (larger blocks) instead of one launch per 64-column step.  Round 4.
+//
+// The arithmetic is the look-ahead chain of potrf_step.hpp (`lookahead`), operation for operation -- the factor and the
+// inverse come out bitwise equal to the launch-per-step form -- but the launch boundary between two steps is gone:
+//
+//   workgroup 0 ("chain")   for j = j0 .. j1-1:  tile (j, j) -> L_jj, X_jj = L_jj^-1 (tile_potrf_inv), published; then
+//                           L[j+1, j] = S'[j+1, j] X_jj^T, tile (j+1, j+1) -= L[j+1, j] L[j+1, j]^T in LDS, and on to j + 1.
+//                           X_jj stays in LDS between the two (the launch-per-step form stored and re-loaded it).
+//   workgroup of tile (r,c) keeps its tile of the trailing block in REGISTERS (MFMA C/D layout) over all its steps
+//                           j = j0 .. c-1:  Lr = S'[r, j] X_jj^T,  Lc = S'[c, j] X_jj^T,  tile -= Lr Lc^T;  stores the tile once,
+//                           when it is final (it is then the panel tile of step c for everybody else), and -- blocks of up
+//                           to 16 tiles -- goes on to assemble tile (r, c) of the block inverse,
+//                           X[r, c] = -X_rr sum_{p = c}^{r-1} L[r, p] X[p, c]   (the sums in the order of xrow_strip).
+//
+// Hand-offs between workgroups follow the guide's write-through form (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement
+// & inter-workgroup visibility", first row of the table of measured hand-offs): every handed-off byte is stored `sc1` (write
+// through), every storing wave drains `vmcnt(0)`, the workgroup meets at a barrier, ONE lane stores the flag (agent scope,
+// relaxed); the consumer's lane 0 polls that word relaxed, the workgroup meets at a barrier, and EVERY load of handed-off bytes
+// is an `sc1` buffer load (L1 bypassed; per-XCD L2s are not coherent).  Nothing depends on dispatch order or placement.
+// Every workgroup of a problem must be resident at once (one per CU: 140 KB of LDS): the host launches this form only when
+// 1 + tiles <= the CU count, every spin is bounded (`spin_limit` ticks of the 100 MHz clock), and a spin that gives up sets
+// the abort word, on which every other wait returns too: the kernel always drains, the host sees the word after the
+// factorisation and repeats it with the launch-per-step form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "potrf_step.hpp"
+
+namespace gmrf {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+struct PersistArgs {
+    double* S; double* L; double* X;
+    int64_t ld;
+    int nt;                 // tiles per dimension of the block
+    int j0, j1;             // column tiles [j0, j1) of this launch (blocks of up to 16 tiles: 0, nt)
+    int xrows;              // 1: the rows of the block inverse are assembled here too (j0 = 0, j1 = nt)
+    int* info; int blk;
+    int64_t pS, pL, pX; int blk_per_problem;
+    unsigned* flags;        // [problems][flag_stride]; zeroed by a memset node ahead of the launch
+    int flag_stride;
+    unsigned* abort_word;   // zeroed at the start of a factorisation, read by the host at its end
+    unsigned spin_limit;
+    unsigned long long* stamps;   // diagnostic (tests / tuning): s_memtime of the chain workgroup per step, else nullptr
+};
+
+// flag words of one problem: D[j] (L_jj, X_jj stored) | F[r][c] (tile (r,c) of S final) | PL[r][c] (L[r,c] stored) |
+// XF[r][c] (X[r,c] stored)
+__host__ __device__ inline int persist_flag_words(int nt) { return (nt + 3 * nt * nt + 3) & ~3; }
+
+// tiles owned by worker workgroups, column by column: column j0 (inverse only, when xrows), then c = j0+1 .. j1-1 with the
+// rows r = c+1 .. nt-1 and, from c = j0+2 on, the diagonal tile (c, c) (steps j0 .. c-2; step c-1 is the chain's)
+__host__ __device__ inline int persist_tiles(int nt, int j0, int j1, int xrows) {
+    int n = 0;
+    for (int c = xrows ? j0 : j0 + 1; c < j1; ++c) n += nt - 1 - c + ((c >= j0 + 2) ? 1 : 0);
+    return n;
+}
+__device__ __forceinline__ void persist_tile_of(int t, int nt, int j0, int j1, int xrows, int& r, int& c) {
+    for (c = xrows ? j0 : j0 + 1; c < j1; ++c) {
+        const int first = (c >= j0 + 2) ? c : c + 1;
+        const int cnt = nt - first;
+        if (t < cnt) { r = first + t; return; }
+        t -= cnt;
+    }
+    r = -1; c = -1;
+}
+
+__device__ __forceinline__ unsigned ld_flag(const unsigned* f) {
+    return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_flag(unsigned* f, unsigned v) {
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane: poll `f` until it is set; false when the abort word is set or the time limit passes (then sets it)
+__device__ __forceinline__ bool spin_until(const unsigned* f, unsigned* abort_w, unsigned limit) {
+    if (ld_flag(f)) return true;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned n = 0;
+    for (;;) {
+        __builtin_amdgcn_s_sleep(1);
+        if (ld_flag(f)) return true;
+        if ((++n & 31u) == 0u) {
+            if (ld_flag(abort_w)) return false;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > (unsigned long long)limit) { st_flag(abort_w, 1u); return false; }
+        }
+    }
+}
+
+// The workgroup waits for up to three flags (nullptr: none): lane 0 polls, everybody meets at the barrier.  `okw` are two LDS
+// words used alternately (`phase` counts the waits of this workgroup) so that a word is never rewritten while a slower wave
+// still reads the previous verdict.
+__device__ __forceinline__ bool wg_wait(const unsigned* a, const unsigned* b, const unsigned* c, const PersistArgs& pa,
+                                        volatile int* okw, int& phase, int tid) {
+    volatile int* w = okw + (phase & 1);
+    ++phase;
+    if (tid == 0) {
+        bool ok = true;
+        if (a) ok = spin_until(a, pa.abort_word, pa.spin_limit);
+        if (ok && b) ok = spin_until(b, pa.abort_word, pa.spin_limit);
+        if (ok && c) ok = spin_until(c, pa.abort_word, pa.spin_limit);
+        *w = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *w != 0;
+}
+
+// every wave has issued its sc1 stores: drain them, meet, ONE lane raises the flags
+__device__ __forceinline__ void wg_publish(unsigned* f1, unsigned* f2, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        if (f1) st_flag(f1, 1u);
+        if (f2) st_flag(f2, 1u);
+    }
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const double* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, 0x7fffffff, 0x00020000);
+}
+
+// 64 x 64 tile, global (row stride ld) -> LDS (row stride TLD), every load sc1; 256 threads
+__device__ __forceinline__ void tile_g2s_sc1(const double* g, int64_t ld, double* s, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
+    v4u v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((r * ld + c) * 8), 0, 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        *reinterpret_cast<v4u*>(s + r * TLD + c) = v[it];
+    }
+}
+// LDS -> global, every store sc1 (write through)
+__device__ __forceinline__ void tile_s2g_sc1(const double* s, double* g, int64_t ld, int tid) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int idx = tid + it * 256;
+        const int r = idx >> 5, c = (idx & 31) * 2;
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(s + r * TLD + c), rs, (int)((r * ld + c) * 8), 0, 16);
+    }
+}
+// this wave's 16-row strip of a tile in the MFMA C/D layout (row lq + 4 q of block row `wave`, column 16 Jb + li)
+__device__ __forceinline__ void strip_load_sc1(const double* g, int64_t ld, v4d (&t)[4], int jb_end, int wave, int li, int lq) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (Jb < jb_end) {
+                const v2u u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(((16 * wave + lq + 4 * q) * ld + 16 * Jb + li) * 8), 0, 16);
+                t[Jb][q] = __hiloint2double((int)u.y, (int)u.x);
+            } else {
+                t[Jb][q] = 0.0;
+            }
+        }
+}
+__device__ __forceinline__ void strip_store_sc1(double* g, int64_t ld, const v4d (&t)[4], int jb_end, bool negate, int wave, int li, int lq) {
+    const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (Jb < jb_end) {
+                const double x = negate ? -t[Jb][q] : t[Jb][q];
+                v2u u;
+                u.x = (unsigned)__double2loint(x); u.y = (unsigned)__double2hiint(x);
+                __builtin_amdgcn_raw_buffer_store_b64(u, rs, (int)(((16 * wave + lq + 4 * q) * ld + 16 * Jb + li) * 8), 0, 16);
+            }
+        }
+}
+
+constexpr size_t POTRF_PERSIST_LDS = POTRF_STEP_LDS + 64;      // + the two verdict words of wg_wait
+
+template <bool UNUSED>
+__global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
+    pa.S += (int64_t)blockIdx.y * pa.pS;
+    pa.L += (int64_t)blockIdx.y * pa.pL;
+    pa.X += (int64_t)blockIdx.y * pa.pX;
+    pa.blk += (int)blockIdx.y * pa.blk_per_problem;
+    pa.flags += (int64_t)blockIdx.y * pa.flag_stride;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Ts = smem;
+    double* Xs = Ts + TILE_ELEMS;
+    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
+    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* As = rinvs + 64;
+    double* Bs = As + TILE_ELEMS;
+    volatile int* okw = reinterpret_cast<volatile int*>(Bs + TILE_ELEMS);
+    int phase = 0;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
+    const int li = lane & 15, lq = lane >> 4;
+    const int64_t ld = pa.ld;
+    const int nt = pa.nt;
+    unsigned* const fD = pa.flags;
+    unsigned* const fF = fD + nt;
+    unsigned* const fPL = fF + nt * nt;
+    unsigned* const fXF = fPL + nt * nt;
+    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
+    bool bad = false;
+    SideLoad none;
+    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+
+    if (blockIdx.x == 0) {
+        // ------------------------------------------------------------------ the chain
+        const int64_t o0 = (int64_t)pa.j0 * 64;
+        tile_g2s(pa.S + o0 * ld + o0, ld, Ts, tid);
+        __syncthreads();
+        tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+        if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
+        tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
+        tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
+        wg_publish(fD + pa.j0, nullptr, tid);
+        if (pa.stamps && tid == 0) pa.stamps[0] = __builtin_amdgcn_s_memtime();
+        for (int j = pa.j0; j + 1 < pa.j1; ++j) {
+            const int64_t oj = (int64_t)j * 64, o1 = oj + 64;
+            const unsigned* w1 = (j > pa.j0) ? fF + (j + 1) * nt + j : nullptr;
+            const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
+            if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
+            v4d cpre[4];
+            strip_load_sc1(pa.S + o1 * ld + o1, ld, cpre, wave + 1, wave, li, lq);
+            tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
+            __syncthreads();
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 2] = __builtin_amdgcn_s_memtime();
+            // L[j+1, j] = As Xs^T   (X lower triangular: column block Jb needs the k groups 0 .. 2 Jb + 1)
+            v4d lr[4];
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) lr[Jb] = zero;
+#pragma unroll
+            for (int kg = 0; kg < 8; ++kg) {
+                const int k = 8 * kg + 2 * lq;
+                const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+                for (int Jb = kg / 2; Jb < 4; ++Jb) {
+                    const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+                    lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+                    lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+                }
+            }
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 3] = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+            __syncthreads();
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 4] = __builtin_amdgcn_s_memtime();
+            tile_s2g_sc1(As, pa.L + o1 * ld + oj, ld, tid);
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 5] = __builtin_amdgcn_s_memtime();
+            // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
+            v4d pacc[4];
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) pacc[Jb] = zero;
+            strip_nt_diag(wave, As + (16 * wave + li) * TLD, As, pacc, li, lq);
+            if (pa.stamps && tid == 192) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();      // (wave 3: the longest product)
+            // (L_jj has left Ts: its stores were drained by wg_publish)
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) {
+                if (Jb <= wave) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Ts[(16 * wave + lq + 4 * q) * TLD + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
+                }
+            }
+            __syncthreads();
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
+            tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+            if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
+            tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
+            tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
+            wg_publish(fD + j + 1, fPL + (j + 1) * nt + j, tid);
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- a tile of the trailing block
+    int r, c;
+    persist_tile_of((int)blockIdx.x - 1, nt, pa.j0, pa.j1, pa.xrows, r, c);
+    if (r < 0) return;
+    const int nsteps = (c > pa.j0) ? ((r == c) ? c - 1 - pa.j0 : c - pa.j0) : 0;
+    const int jb_end = (c == r) ? wave + 1 : 4;
+    double* Sg = pa.S + (int64_t)r * 64 * ld + (int64_t)c * 64;
+    v4d cpre[4];
+    if (nsteps > 0) {
+        // nobody else writes this tile in this launch: plain loads
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                cpre[Jb][q] = (Jb < jb_end) ? Sg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] : 0.0;
+    }
+    for (int s = 0; s < nsteps; ++s) {
+        const int j = pa.j0 + s;
+        const int64_t oj = (int64_t)j * 64;
+        const unsigned* w1 = (s > 0) ? fF + r * nt + j : nullptr;
+        const unsigned* w2 = (s > 0 && c != r) ? fF + c * nt + j : nullptr;
+        if (!wg_wait(fD + j, w1, w2, pa, okw, phase, tid)) return;
+        tile_g2s_sc1(pa.X + oj * ld + oj, ld, Xs, tid);
+        tile_g2s_sc1(pa.S + (int64_t)r * 64 * ld + oj, ld, As, tid);
+        if (c != r) tile_g2s_sc1(pa.S + (int64_t)c * 64 * ld + oj, ld, Bs, tid);
+        __syncthreads();
+        v4d lr[4], lc[4];
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) { lr[Jb] = zero; lc[Jb] = zero; }
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const int k = 8 * kg + 2 * lq;
+            const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+            v2d bv = av;
+            if (c != r) bv = *reinterpret_cast<const v2d*>(Bs + (16 * wave + li) * TLD + k);
+#pragma unroll
+            for (int Jb = kg / 2; Jb < 4; ++Jb) {
+                const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+                lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+                lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+                if (c != r) {
+                    lc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.x, xv.x, lc[Jb], 0, 0, 0);
+                    lc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv.y, xv.y, lc[Jb], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done reading As / Bs
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+            if (c != r) store_d16(Bs + (16 * wave) * TLD + 16 * Jb, TLD, lc[Jb], li, lq);
+        }
+        __syncthreads();
+        const bool panel_owner = (c == j + 1);             // (then r > c: the chain stores L[j+1, j] itself)
+        if (panel_owner) tile_s2g_sc1(As, pa.L + (int64_t)r * 64 * ld + oj, ld, tid);
+        const double* Lcs = (c != r) ? Bs : As;
+        v4d pacc[4];
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) pacc[Jb] = zero;
+        if (c != r) strip_nt<4>(As + (16 * wave + li) * TLD, Lcs, pacc, li, lq);
+        else strip_nt_diag(wave, As + (16 * wave + li) * TLD, Lcs, pacc, li, lq);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) cpre[Jb] = cpre[Jb] - pacc[Jb];
+        if (s + 1 == nsteps) {
+            // the tile is final: it is the panel tile of step c (diagonal tile: what the chain updates once more and factors)
+            strip_store_sc1(Sg, ld, cpre, jb_end, false, wave, li, lq);
+            wg_publish(fF + r * nt + c, panel_owner ? fPL + r * nt + j : nullptr, tid);
+        } else if (panel_owner) {
+            wg_publish(fPL + r * nt + j, nullptr, tid);    // (not reached: the panel owner's step c-1 is its last)
+        } else {
+            __syncthreads();                               // As / Bs are re-filled by the next step
+        }
+    }
+    if (!pa.xrows || r == c) return;
+
+    // ---------------------------------------------------------------------- tile (r, c) of the block inverse
+    //   T = sum_{p = c}^{r-1} L[r, p] X[p, c]  (p ascending, k in the slot order of xrow_strip), X[r, c] = -X_rr T
+    v4d acc[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) acc[Jb] = zero;
+    for (int p = c; p < r; ++p) {
+        const int64_t op = (int64_t)p * 64;
+        const unsigned* wx = (p == c) ? fD + c : fXF + p * nt + c;
+        if (!wg_wait(fPL + r * nt + p, wx, nullptr, pa, okw, phase, tid)) return;
+        tile_g2s_sc1(pa.L + (int64_t)r * 64 * ld + op, ld, As, tid);
+        tile_g2s_sc1(pa.X + op * ld + (int64_t)c * 64, ld, Bs, tid);
+        __syncthreads();
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const int k = 8 * kg + 2 * lq;
+            const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+            for (int Jb = 0; Jb < 4; ++Jb) {
+                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Bs[k * TLD + 16 * Jb + li], acc[Jb], 0, 0, 0);
+                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Bs[(k + 1) * TLD + 16 * Jb + li], acc[Jb], 0, 0, 0);
+            }
+        }
+        __syncthreads();                                   // As / Bs are re-filled by the next term
+    }
+    if (!wg_wait(fD + r, nullptr, nullptr, pa, okw, phase, tid)) return;
+    tile_g2s_sc1(pa.X + (int64_t)r * 64 * ld + (int64_t)r * 64, ld, As, tid);          // X_rr
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) store_d16(Bs + (16 * wave) * TLD + 16 * Jb, TLD, acc[Jb], li, lq);      // T
+    __syncthreads();
+    v4d res[4];
+#pragma unroll
+    for (int Jb = 0; Jb < 4; ++Jb) res[Jb] = zero;
+    strip_tri_nn_w(wave, As + (16 * wave + li) * TLD, Bs, res, li, lq);           // X_rr lower triangular: the k groups 0 .. 2 wave + 1
+    strip_store_sc1(pa.X + (int64_t)r * 64 * ld + (int64_t)c * 64, ld, res, 4, true, wave, li, lq);
+    wg_publish(fXF + r * nt + c, nullptr, tid);
+}
+
+}  // namespace gmrf

@@ -26,6 +26,9 @@
 
 namespace gmrf {
 
+#ifndef GMRF_PANEL_FLAT_LDS
+#define GMRF_PANEL_FLAT_LDS 0
+#endif
 #ifndef GMRF_TLD
 #define GMRF_TLD 66
 #endif
@@ -91,6 +94,91 @@ __device__ __forceinline__ void store_d16(double* p, int ld, const v4d& v, int l
     for (int r = 0; r < 4; ++r) p[(lq + 4 * r) * ld + li] = v[r];
 }
 
+// acc[Jb] += A(16 x 64 strip) B_Jb(16 x 64)^T for the column blocks Jb < JB_END: `arow` = this lane's row of the strip in an LDS tile
+// (+ (16 * wave + li) * TLD), Bs the LDS tile whose rows 16 Jb + li are the other operand; k in the slot order used everywhere
+// (two consecutive k per ds_read_b128).  JB_END is a COMPILE-TIME bound: with the run-time test `Jb <= wave` inside the
+// unrolled loops hipcc closed every MFMA pair with a branch join -- accumulators copied AGPR -> VGPR behind `s_nop 17` -- and
+// the 64 MFMAs of wave 3's diagonal update took 10 500 cycles instead of 4 100 (round 4, tools/persist_stamps.py).
+template <int JB_END>
+__device__ __forceinline__ void strip_nt(const double* arow, const double* Bs, v4d (&acc)[4], int li, int lq) {
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(arow + k);
+#pragma unroll
+        for (int Jb = 0; Jb < JB_END; ++Jb) {
+            const v2d bv = *reinterpret_cast<const v2d*>(Bs + (16 * Jb + li) * TLD + k);
+            acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc[Jb], 0, 0, 0);
+            acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc[Jb], 0, 0, 0);
+        }
+    }
+}
+// the same with the bound chosen by the (wave-uniform) strip index: column blocks 0 .. w of a diagonal tile
+__device__ __forceinline__ void strip_nt_diag(int w, const double* arow, const double* Bs, v4d (&acc)[4], int li, int lq) {
+    switch (w) {
+        case 0: strip_nt<1>(arow, Bs, acc, li, lq); break;
+        case 1: strip_nt<2>(arow, Bs, acc, li, lq); break;
+        case 2: strip_nt<3>(arow, Bs, acc, li, lq); break;
+        default: strip_nt<4>(arow, Bs, acc, li, lq); break;
+    }
+}
+// acc[Jb] += X_strip(rows 16 w .. of a lower-triangular LDS tile) T(64 x 64, stored [k][n])  for the four column blocks: only
+// the k groups 0 .. 2 w + 1 of the strip are non-zero (compile-time bound, as above)
+template <int W>
+__device__ __forceinline__ void strip_tri_nn(const double* xrow, const double* Tsm, v4d (&acc)[4], int li, int lq) {
+#pragma unroll
+    for (int kg = 0; kg < 2 * W + 2; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(xrow + k);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Tsm[k * TLD + 16 * Jb + li], acc[Jb], 0, 0, 0);
+            acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Tsm[(k + 1) * TLD + 16 * Jb + li], acc[Jb], 0, 0, 0);
+        }
+    }
+}
+__device__ __forceinline__ void strip_tri_nn_w(int w, const double* xrow, const double* Tsm, v4d (&acc)[4], int li, int lq) {
+    switch (w) {
+        case 0: strip_tri_nn<0>(xrow, Tsm, acc, li, lq); break;
+        case 1: strip_tri_nn<1>(xrow, Tsm, acc, li, lq); break;
+        case 2: strip_tri_nn<2>(xrow, Tsm, acc, li, lq); break;
+        default: strip_tri_nn<3>(xrow, Tsm, acc, li, lq); break;
+    }
+}
+
+// potrf_diag128: pacc[Jb] += L10_strip L10_Jb^T (Jb <= W) and wv[Jb] += L10_strip X00[:, Jb] (X00[k][c] = 0 for k < c: the k
+// groups 2 Jb .. 7), one pass over the strip; W = the strip index, compile-time (see strip_nt)
+template <int W>
+__device__ __forceinline__ void strip_syrk_and_w(const double* arow, const double* Ls, const double* Xs, v4d (&pacc)[4],
+                                                 v4d (&wv)[4], int li, int lq) {
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(arow + k);
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) {
+            if (Jb <= W) {
+                const v2d bv = *reinterpret_cast<const v2d*>(Ls + (16 * Jb + li) * TLD + k);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
+                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
+            }
+            if (kg >= 2 * Jb) {
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Xs[k * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Xs[(k + 1) * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void strip_syrk_and_w_w(int w, const double* arow, const double* Ls, const double* Xs, v4d (&pacc)[4],
+                                                   v4d (&wv)[4], int li, int lq) {
+    switch (w) {
+        case 0: strip_syrk_and_w<0>(arow, Ls, Xs, pacc, wv, li, lq); break;
+        case 1: strip_syrk_and_w<1>(arow, Ls, Xs, pacc, wv, li, lq); break;
+        case 2: strip_syrk_and_w<2>(arow, Ls, Xs, pacc, wv, li, lq); break;
+        default: strip_syrk_and_w<3>(arow, Ls, Xs, pacc, wv, li, lq); break;
+    }
+}
+
 // 1/p to fp64 accuracy: hardware seed (24 bits) + two Newton steps (measured 1 ulp, tools/acc.hip).
 __device__ __forceinline__ double rcp_nr(double p) {
     double y = __builtin_amdgcn_rcp(p);
@@ -118,7 +206,14 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
     // Make the LDS base opaque to the compiler: with a known constant address it materialises
     // every broadcast read address with an s_add + v_mov pair; with a VGPR base the constant part
     // goes into the instruction's offset field.
+    // (The opaque pointer is an LDS pointer, address space 3: left generic, every access of the chain below became a FLAT
+    // load / store -- 64-bit address arithmetic, both vmcnt and lgkmcnt to wait for, a longer round trip than ds_read.)
+#if GMRF_PANEL_FLAT_LDS
     double* lcol = lcol_in;
+#else
+    typedef __attribute__((address_space(3))) double lds_double;
+    lds_double* lcol = (lds_double*)lcol_in;
+#endif
     asm volatile("" : "+v"(lcol));
     double a[16];
 #pragma unroll
@@ -128,7 +223,7 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
     double lprev = 0.0;
 #pragma unroll
     for (int c = 0; c < 16; ++c) up[c] = 0.0;
-    double* rv = lcol + 16 * 64;            // rinv of the 16 pivots of this panel (wave-uniform values)
+    auto* rv = lcol + 16 * 64;              // rinv of the 16 pivots of this panel (wave-uniform values)
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
         const int j = c0 + jj;
@@ -168,7 +263,12 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
         // (SQ_LDS_UNALIGNED_STALL was 0.42 of this kernel's LDS-active cycles)
 #pragma unroll
         for (int cc = (jj + 2) & ~1; cc < 16; cc += 2) {
+#if GMRF_PANEL_FLAT_LDS
             const v2d q = *reinterpret_cast<const v2d*>(lcol + jj * 64 + c0 + cc);
+#else
+            typedef __attribute__((address_space(3))) v2d lds_v2d;
+            const v2d q = *reinterpret_cast<const lds_v2d*>(lcol + jj * 64 + c0 + cc);
+#endif
             if (cc >= jj + 2) up[cc] = q.x;
             up[cc + 1] = q.y;
         }
@@ -269,7 +369,7 @@ __device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int
 
 __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid,
                                                bool& bad, const SideLoad& side) {
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     // clear X (its strict upper part and the blocks the assembly does not write stay zero) and
     // the 16x16 blocks of the input above the block diagonal (they are part of the output L)
@@ -428,7 +528,7 @@ struct StepArgs {
 // diagonal inverses multiply, like inside the tile).  One workgroup per 64 x 16 output strip: wave w forms rows
 // 16 w .. of the sum (operands straight from L2), the four strips meet in LDS for the product with X_rr.
 __device__ __forceinline__ void xrow_strip(const StepArgs& sa, int q, double* sm) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld;
     const int r = sa.xrow, c = q >> 2, cs = q & 3;
@@ -495,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     double* Bs = As + TILE_ELEMS;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld;
     const int64_t oj = (int64_t)sa.j * 64;
@@ -601,19 +701,8 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     v4d pacc[4];
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) pacc[Jb] = zero;
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        const int k = 8 * kg + 2 * lq;
-        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-            if (Jb < jb_end) {
-                const v2d bv = *reinterpret_cast<const v2d*>(Lcs + (16 * Jb + li) * TLD + k);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
-            }
-        }
-    }
+    if (c != r) strip_nt<4>(As + (16 * wave + li) * TLD, Lcs, pacc, li, lq);
+    else strip_nt_diag(wave, As + (16 * wave + li) * TLD, Lcs, pacc, li, lq);
     if (stamp) sa.dbg[4] = __builtin_amdgcn_s_memtime();
     if (la && w == 0) {
         // look-ahead: the updated tile (j+1, j+1) stays in LDS and is factored here, for the next launch
@@ -660,7 +749,7 @@ __global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
     sa.L += (int64_t)blockIdx.y * sa.pL;
     sa.X += (int64_t)blockIdx.y * sa.pX;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
     const int64_t R0 = (int64_t)(sa.j + 1 + blockIdx.x) * 64 + 16 * wave;
@@ -685,7 +774,7 @@ __global__ __launch_bounds__(256, 2) void potrf_panel(StepArgs sa) {
 __global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
     sa.S += (int64_t)blockIdx.y * sa.pS;
     sa.L += (int64_t)blockIdx.y * sa.pL;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld, oj = (int64_t)sa.j * 64;
     int t = blockIdx.x, c = sa.j + 1;            // column by column: column c has nt - c row tiles
@@ -743,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void potrf_panel_ll(PanelLLArgs pa) {
     double* L = pa.L + (int64_t)blockIdx.y * pa.pL;
     const double* X = pa.X + (int64_t)blockIdx.y * pa.pX;
     __shared__ __attribute__((aligned(16))) double Ts[TILE_ELEMS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = pa.ld, oj = (int64_t)pa.j * 64;
     const int r = pa.j + 1 + (int)blockIdx.x;
@@ -879,7 +968,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
     double* Wk = As + TILE_ELEMS;               // 4 * 16 * 18
     double* rinvs = Wk + 4 * 16 * 18;           // 64
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld;
     const int64_t o0 = (int64_t)sa.j * 64, o1 = o0 + 64;
@@ -924,23 +1013,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
     v4d pacc[4], wv[4];
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) { pacc[Jb] = zero; wv[Jb] = zero; }
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        const int k = 8 * kg + 2 * lq;
-        const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-            if (Jb <= wave) {
-                const v2d bv = *reinterpret_cast<const v2d*>(As + (16 * Jb + li) * TLD + k);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
-            }
-            if (kg >= 2 * Jb) {
-                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Xs[k * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
-                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Xs[(k + 1) * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
-            }
-        }
-    }
+    strip_syrk_and_w_w(wave, As + (16 * wave + li) * TLD, As, Xs, pacc, wv, li, lq);
     __syncthreads();                                   // L10 (As) and X00 (Xs) have been read by everyone
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
@@ -961,18 +1034,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
     v4d xr[4];
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) xr[Jb] = zero;
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        if (kg < 2 * wave + 2) {
-            const int k = 8 * kg + 2 * lq;
-            const v2d av = *reinterpret_cast<const v2d*>(Xs + (16 * wave + li) * TLD + k);
-#pragma unroll
-            for (int Jb = 0; Jb < 4; ++Jb) {
-                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, As[k * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
-                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, As[(k + 1) * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
-            }
-        }
-    }
+    strip_tri_nn_w(wave, Xs + (16 * wave + li) * TLD, As, xr, li, lq);
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb)
 #pragma unroll
@@ -995,7 +1057,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
     double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
     double* rinvs = Wk + 4 * 16 * 18;           // 64
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     const int64_t ld = sa.ld;
     const int64_t o0 = (int64_t)sa.j * 64, o1 = o0 + 64;
@@ -1042,23 +1104,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
     v4d pacc[4], wv[4];
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) { pacc[Jb] = zero; wv[Jb] = zero; }
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        const int k = 8 * kg + 2 * lq;
-        const v2d av = *reinterpret_cast<const v2d*>(Ts + (16 * wave + li) * TLD + k);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-            if (Jb <= wave) {
-                const v2d bv = *reinterpret_cast<const v2d*>(Ts + (16 * Jb + li) * TLD + k);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, pacc[Jb], 0, 0, 0);
-                pacc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, pacc[Jb], 0, 0, 0);
-            }
-            if (kg >= 2 * Jb) {
-                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Xs[k * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
-                wv[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Xs[(k + 1) * TLD + 16 * Jb + li], wv[Jb], 0, 0, 0);
-            }
-        }
-    }
+    strip_syrk_and_w_w(wave, Ts + (16 * wave + li) * TLD, Ts, Xs, pacc, wv, li, lq);
     __syncthreads();                                   // L10 (Ts) and X00 (Xs) have been read by everyone
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) {
@@ -1080,18 +1126,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
     v4d xr[4];
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb) xr[Jb] = zero;
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) {
-        if (kg < 2 * wave + 2) {
-            const int k = 8 * kg + 2 * lq;
-            const v2d av = *reinterpret_cast<const v2d*>(Xs + (16 * wave + li) * TLD + k);
-#pragma unroll
-            for (int Jb = 0; Jb < 4; ++Jb) {
-                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, Ts[k * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
-                xr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, Ts[(k + 1) * TLD + 16 * Jb + li], xr[Jb], 0, 0, 0);
-            }
-        }
-    }
+    strip_tri_nn_w(wave, Xs + (16 * wave + li) * TLD, Ts, xr, li, lq);
 #pragma unroll
     for (int Jb = 0; Jb < 4; ++Jb)
 #pragma unroll

@@ -216,8 +216,11 @@ gmrf_status gmrf_bt_get_layout(gmrf_handle* h, int64_t* out, int64_t cap, int64_
  * gmrf_bt_packed_size doubles: the lower-triangular 64 x 64 tiles of Linv_i0 .. Linv_{i1-1} (tile (r, c), c <= r, of
  * block i at ((i - i0) * nt (nt + 1) / 2 + r (r + 1) / 2 + c) * 4096, row-major; nt = bsp / 64 -- the tiles above the
  * block diagonal are zero and never read, so they do not travel: 136 of 256 tiles at bsp = 1024), the stored windows
- * of the coupling blocks C_{i0-1} .. C_{i1-2}, and the blocks' log-determinant parts ((i1 - i0) doubles, rounded up to
- * an even count).  darcy256: 0.56 GB per posterior instead of the 0.83 GB of the raw Linv / C buffers.  dev_buf:
+ * of the coupling blocks C_{i0-1} .. C_{i1-2}, a two-double representation tag {split column of the SENDER's block inverses
+ * when it packed (0: full inverses), 1196249670.0}, and the blocks' log-determinant parts ((i1 - i0) doubles, rounded up to
+ * an even count).  The tag is authoritative: gmrf_bt_adopt_commit follows it, not the layout record (which can be older
+ * than the image: the sender converts to the full inverses for gmrf_bt_get_block(LINV) / export / exact variances and goes
+ * back to the split form at its next factorisation); raw-buffer transfers carry no tag and follow the record.  darcy256: 0.56 GB per posterior instead of the 0.83 GB of the raw Linv / C buffers.  dev_buf:
  * device memory, [batch][segment].  pack reads the handle's factor storage, unpack fills it (a receiving rank:
  * gmrf_bt_adopt_layout first, gmrf_bt_adopt_commit after the last range; gmrf_bt_logdet then works there too).
  * Both are enqueued on the handle's stream and return.  (No reference counterpart: the reference is one process.) */
@@ -237,7 +240,8 @@ gmrf_status gmrf_bt_set_storage(gmrf_handle* h, int64_t n, int64_t n_blocks, int
 
 /* A rank that RECEIVES the factor (broadcast): shape plus the root's layout record (adopt_shape =
  * dense coupling blocks), storage allocated WITHOUT factoring; once the buffers have been filled
- * adopt_commit marks the factor valid (l_blocks_valid != 0: the L buffer was filled too). */
+ * adopt_commit marks the factor valid (l_blocks_valid != 0: the L buffer was filled too); it waits for the handle's stream
+ * (the ranges must have been unpacked on it, or ordered behind it by gmrf_comm_wait) and reads the representation tag. */
 gmrf_status gmrf_bt_adopt_layout(gmrf_handle* h, int64_t n, int64_t n_blocks,
                                  const int64_t* layout, int64_t count);
 gmrf_status gmrf_bt_adopt_shape(gmrf_handle* h, int64_t n, int64_t n_blocks);
@@ -463,6 +467,9 @@ gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64 /* in: SPD, out:
 gmrf_status gmrf_test_tile_timing(double* out, int32_t n);
 gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/out: L */,
                                   double* Linv, int32_t* info);
+/* s_memtime stamps of the chain workgroup of the last gmrf_test_potrf_block that took the persistent form
+ * (csrc/potrf_persist.hpp): out[0] = tile 0 done, then eight per step (tools/persist_stamps.py names them); cycles relative to out[0], -1 = not written. */
+gmrf_status gmrf_test_persist_stamps(double* out, int32_t n);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
 gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps);
 gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n);

@@ -1323,7 +1323,7 @@ def test_packed_transport_image_between_handles(pkg):
         F2.unpack_blocks_async(i0, i1, buf)
         F2.synchronize()
     nt = 256 // 64
-    assert packed == N * (nt * (nt + 1) // 2) * 4096 + (F1.block_range(pkg._cabi.BLOCK_C, 0, N)[1]) + 6 + 12 and packed < 0.8 * raw
+    assert packed == N * (nt * (nt + 1) // 2) * 4096 + (F1.block_range(pkg._cabi.BLOCK_C, 0, N)[1]) + (2 + 6) + (2 + 12) and packed < 0.8 * raw    # (+ the 2-double representation tag per range)
     with pytest.raises(pkg.GmrfError):
         F2.solve_batch(rhs)                                  # not committed yet
     F2.adopt_commit(False)
@@ -1340,6 +1340,18 @@ def test_packed_transport_image_between_handles(pkg):
     F3.adopt_commit(False)
     with pytest.raises(pkg.GmrfError):
         F3.logdet()
+    # ... but a receiver that KEEPS L blocks and adopted the packed image without them reads the parts that travelled
+    # (the keep_l branch used to refuse before looking at them)
+    F4 = pkg.TridiagonalCholeskyFactor(batch=2)
+    F4.adopt_layout(w.n, w.n_blocks, F1.get_layout())
+    sz = F1.packed_size(0, N)
+    buf = torch.empty((2, sz), dtype=torch.float64, device="cuda")
+    F1.pack_blocks_async(0, N, buf); F1.synchronize()
+    F4.unpack_blocks_async(0, N, buf); F4.synchronize()
+    F4.adopt_commit(False)
+    for p in (0, 1):
+        F1.select_problem(p); F4.select_problem(p)
+        assert F1.logdet() == F4.logdet()
 
 
 def test_shallow_water_element_kernels_on_device(pkg):
@@ -1504,9 +1516,31 @@ def test_split_inverse_representation_of_batches(pkg):
     # sweeps after the conversion use the full form again and agree
     mu_c = Fs.solve_batch(rhs_t)[:, 0, :]
     assert float((mu_c - mu_f).norm() / mu_f.norm()) < 1e-12
+    # Round 4: the layout record can be OLDER than the image -- the sender converted to the full form
+    # (exact variances / get_block above) after the receiver fetched the record, and shares without re-factoring.
+    # The packed image carries the representation its sender was in; the receiver's commit follows the image.
+    stale_split = Fr.get_layout()                              # says 256; Fs now holds the FULL inverses
+    assert stale_split[-1] == 256 and Fs.get_layout()[-1] == 0
+    Fr.adopt_layout(ns, nb, stale_split)
+    Fs.pack_blocks_async(0, nb, buf); Fs.synchronize()
+    Fr.unpack_blocks_async(0, nb, buf); Fr.synchronize()
+    Fr.adopt_commit(False)
+    assert Fr.get_layout()[-1] == 0
+    mu_r = Fr.solve_batch(rhs_t)[:, 0, :]
+    assert torch.equal(mu_r, mu_c)
+    assert float((mu_r - mu_f).norm() / mu_f.norm()) < 1e-12
+    # the other order: the record was fetched while the sender was in the full form, the sender re-factors (split), shares
+    stale_full = Fs.get_layout()
+    assert stale_full[-1] == 0
     # re-factorisation returns to the split form
     Fs.refactor(vals)
     assert Fs.get_layout()[-1] == 256
+    Fr.adopt_layout(ns, nb, stale_full)
+    Fs.pack_blocks_async(0, nb, buf); Fs.synchronize()
+    Fr.unpack_blocks_async(0, nb, buf); Fr.synchronize()
+    Fr.adopt_commit(False)
+    assert Fr.get_layout()[-1] == 256
+    assert torch.equal(Fr.solve_batch(rhs_t), Fs.solve_batch(rhs_t))
     for F in (Fs, Ff, Fr):
         F.close()
 
