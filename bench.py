@@ -173,12 +173,36 @@ def cpu_baseline(w, k_samples: int, sample_blocks: int = 8):
     runs.sort(key=lambda r: r[0])
     t_med, t_fac, res = runs[2]
     scale = w.n_blocks / nb
-    return {"value": (1 + k_samples) / (t_med * scale), "unit": "solves/s", "cores": int(best), "kind": "port",
-            "sample": f"leading {nb} of {w.n_blocks} blocks of {w.name} (n={ns}, block size {w.block_size}): factor + mean + "
-                      f"{k_samples} samples, median of 5 after a warm-up = {t_med:.3f} s (factor {t_fac:.3f} s), scaled x{scale:g}; "
-                      f"SciPy/OpenBLAS with {best} threads (sweep, best of 2: "
-                      + ", ".join(f"{c}: {v:.3f} s" for c, v in sweep.items()) + ")",
-            }, (Qs, nb, rhs, Z, res)
+    extrapolated = (1 + k_samples) / (t_med * scale)
+    # Round 4: the WHOLE chain once at the best thread count -- 1 warm-up + median of 3 of factor + mean +
+    # k samples on the full matrix -- is the reported value; the bounded sample above picks the thread count and stays as a
+    # cross-check.  Bounded: skipped (value = the extrapolation, and the line says so) if one full run would exceed ~15 s.
+    full = None
+    if t_med * scale <= 15.0 and nb < w.n_blocks:
+        Qf = w.Q.tocsc()
+        Zf = np.random.default_rng(0).standard_normal((w.n, k_samples))
+
+        def job_full():
+            t0 = time.perf_counter()
+            F = O.tridiagonal_cholesky(Qf, w.n_blocks)
+            t1 = time.perf_counter()
+            mu = O.ldiv(F, w.rhs)
+            O.sample(F, mu, Zf)
+            return time.perf_counter() - t0, t1 - t0
+
+        with threadpool_limits(limits=best):
+            job_full()
+            fr = sorted(job_full() for _ in range(3))
+        full = fr[1]
+    value = (1 + k_samples) / full[0] if full else extrapolated
+    sample = (f"the whole chain of {w.name} (n={w.n}, {w.n_blocks} blocks of {w.block_size}): factor + mean + {k_samples} samples, "
+              f"median of 3 after a warm-up = {full[0]:.3f} s (factor {full[1]:.3f} s); " if full else
+              "the whole chain was NOT timed (one run would exceed 15 s): the value is the extrapolation below; ")
+    sample += (f"cross-check on the leading {nb} blocks (n={ns}), median of 5 after a warm-up = {t_med:.3f} s (factor {t_fac:.3f} s), "
+               f"x{scale:g} = {extrapolated:.1f} solves/s; SciPy/OpenBLAS with {best} threads (sweep on the leading blocks, best of 2: "
+               + ", ".join(f"{c}: {v:.3f} s" for c, v in sweep.items()) + ")")
+    return {"value": value, "unit": "solves/s", "cores": int(best), "kind": "port", "sample": sample,
+            "extrapolated_from_leading_blocks": extrapolated, "timed_whole_chain": bool(full)}, (Qs, nb, rhs, Z, res)
 
 
 def full_loop(pkg, torch, n_xy: int, batch: int, local: int, with_cpu: bool, sample_blocks: int = 8):
@@ -461,6 +485,9 @@ def main():
                          "then runs as side legs at N > 1); shared-factor: rank 0 factors, broadcast, samples sharded")
     ap.add_argument("--shared-batch", type=int, default=32, help="posteriors per step whose factor is shared (N > 1)")
     ap.add_argument("--group", type=int, default=8, help="blocks per broadcast range (shared-factor)")
+    ap.add_argument("--share", choices=["broadcast", "allgather"], default="allgather",
+                    help="shared-factor job: rank 0 factors the batch and broadcasts it, or every rank factors batch / N posteriors and "
+                         "the block ranges are all-gathered (round 4; both run as side legs at N > 1)")
     ap.add_argument("--keep-l", action="store_true", help="retain the L blocks (F.chos); default: only Linv and C are stored")
     ap.add_argument("--transport", choices=["auto", "cabi", "torch"], default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -566,11 +593,18 @@ def main():
                 comm = pkg.api.Comm(local, rank, world, box[0])   # a failure here is fatal on this rank (raises): the
                 transport = "cabi"                                # others sit in ncclCommInitRank until the launcher ends the job
 
-    def shared_job(wl, batch, k_per_rank, values=None, rhs=None):
-        eng = post.HipEngine(pkg, wl, device_index=local, batch=batch, values=values, rhs=rhs, keep_l=keep_l,
-                             transport=transport, comm=comm)
+    def shared_job(wl, batch, k_per_rank, values=None, rhs=None, share="broadcast"):
+        if share == "allgather":
+            # every rank factors batch / world posteriors, block ranges are all-gathered (posterior.HipGatherEngine)
+            va = values if values is not None else np.tile(np.ascontiguousarray(wl.Q.data), (batch, 1))
+            ra = rhs if rhs is not None else np.tile(np.ascontiguousarray(wl.rhs), (batch, 1))
+            eng = post.HipGatherEngine(pkg, wl, device_index=local, batch_total=batch, world=world, rank=rank, values_all=va, rhs_all=ra,
+                                       keep_l=False, transport=transport, comm=comm)
+        else:
+            eng = post.HipEngine(pkg, wl, device_index=local, batch=batch, values=values, rhs=rhs, keep_l=keep_l,
+                                 transport=transport, comm=comm)
         job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=k_per_rank, group=args.group,
-                                    force_shared=args.force_shared, keep_samples=False, timing=True)
+                                    force_shared=args.force_shared, keep_samples=False, timing=True, share=share)
         job.prepare()
         job.step(1 << 20)             # set-up, untimed (every rank): graph captures, first broadcasts
         return eng, job
@@ -589,14 +623,17 @@ def main():
             res["receivers_max"] = {k: round(max(b[k] for b in recv), 3) for k in recv[0]}
         return res
 
-    def run_shared(steps, warmup):
-        """The shared-factor job (north_star's split): per step rank 0 factors B posteriors, ranges of blocks cross xGMI as
-        packed images beside the factorisation, every rank takes the means and draws its own samples.  Returns the engine
-        (the regimes reuse it), seconds for `steps` steps (max over ranks), solves per step and what the line says about it."""
+    def run_shared(steps, warmup, share="broadcast"):
+        """The shared-factor job (north_star's split): per step B posteriors are factored -- all by rank 0 and broadcast
+        (share = "broadcast"), or B / N by every rank and all-gathered (share = "allgather", round 4) --, ranges of blocks
+        cross xGMI as packed images beside the factorisation, every rank takes the means and draws its own samples.  Returns
+        the engine (the regimes reuse it), seconds for `steps` steps (max over ranks), solves per step and what the line says."""
         B = max(1, args.shared_batch)
+        if share == "allgather" and B % world:
+            B = (B // world + 1) * world
         vals = np.stack([w.Q.data * (1.0 + 0.01 * p) for p in range(B)])
         rhs = np.stack([w.rhs] * B)
-        eng_s, job_s = shared_job(w, B, args.samples, vals, rhs)
+        eng_s, job_s = shared_job(w, B, args.samples, vals, rhs, share)
 
         def run(first, count):
             for s in range(count):
@@ -608,20 +645,25 @@ def main():
         phases = gather_phases(job_s)
         # (no scaling curve has been measured on real multi-GPU hardware before the driver's SCALE run; these fields say
         # which regime a record is in)
+        # what a ring algorithm puts on every busy link per step: the whole image for a broadcast (each link out of the root
+        # and onwards carries all of it), (N - 1) / N of all images for an all-gather (= what came INTO this rank, `moved`)
         rec = {"bytes_broadcast_per_step": moved, "bytes_broadcast_per_posterior": moved / B,
+               "form": share, "bytes_per_link_per_step": moved, "posteriors_factored_per_rank": (B // world if share == "allgather" else B),
                "transport": transport, "phase_ms_last_step": phases,
                "reading": "root-bound when root.factor_ms dominates ms_per_step; broadcast-bound when transfer_wait_ms does; "
                           "the samples-per-factor regimes of side_legs.regimes show where sharing the factor pays"}
-        wl = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored by rank 0, "
-              f"Linv / C ranges of {args.group} blocks broadcast (packed lower-triangular tiles) to {world} ranks beside the "
-              f"factorisation, every rank: {B} mean(s) + {args.samples} samples per posterior")
-        sh = (f"one shared factor per posterior, RCCL broadcast ({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), "
-              f"samples sharded by Philox sample id")
+        how = (f"{B // world} by every rank, Linv / C ranges of {args.group} blocks all-gathered" if share == "allgather" else
+               f"all by rank 0, Linv / C ranges of {args.group} blocks broadcast")
+        wl = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; per step {B} posterior(s) factored, {how} "
+              f"(packed lower-triangular tiles) over {world} ranks beside the factorisation, every rank: {B} mean(s) + {args.samples} "
+              f"samples per posterior")
+        sh = (f"one shared factor per posterior, RCCL {'all-gather' if share == 'allgather' else 'broadcast'} "
+              f"({'library communicator gmrf_comm_*' if transport == 'cabi' else 'torch.distributed ' + backend}), samples sharded by Philox sample id")
         return eng_s, el, job_s.solves_per_step(), rec, wl, sh
 
     pj = None
     if shared:
-        eng, elapsed, per_step, rec_s, workload, sharding = run_shared(args.steps, args.warmup)
+        eng, elapsed, per_step, rec_s, workload, sharding = run_shared(args.steps, args.warmup, args.share)
         extra["shared_factor"] = rec_s
     else:
         fit = fit_batch(torch, w, local, args.batch, max(1, args.streams), args.samples, keep_l)
@@ -689,10 +731,32 @@ def main():
                 pj.close()                    # the headline's posteriors (streams x batch of them) leave the HBM first
                 pj = None
                 steps_s = max(2, args.steps // 4)
-                eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1)
+                # (s') the all-gather form first (every rank factors its share): its engine leaves the HBM again before the
+                # broadcast form, whose engine the regimes below reuse
+                leg["name"] = "shared_factor_allgather"
+                eng_g, el_g, per_g, rec_g, wl_g, sh_g = run_shared(steps_s, 1, "allgather")
+                if rank == 0:
+                    side["shared_factor_allgather"] = dict({"value": per_g * steps_s / el_g, "unit": "solves/s", "ms_per_step": 1e3 * el_g / steps_s,
+                                                            "steps": steps_s, "workload": wl_g, "sharding": sh_g}, **rec_g)
+                eng_g.F.close(); eng_g.F_all.close()
+                del eng_g
+                sync()
+                leg["name"] = "shared_factor"
+                eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1, "broadcast")
                 if rank == 0:
                     side["shared_factor"] = dict({"value": per_s * steps_s / el_s, "unit": "solves/s", "ms_per_step": 1e3 * el_s / steps_s,
                                                   "steps": steps_s, "workload": wl_s, "sharding": sh_s}, **rec_s)
+            elif args.share == "allgather":
+                # the headline was the all-gather form: the regimes below run on the broadcast form's engine
+                leg["name"] = "shared_factor"
+                eng.F.close(); eng.F_all.close()
+                sync()
+                steps_s = max(2, args.steps // 4)
+                eng, el_s, per_s, rec_s, wl_s, sh_s = run_shared(steps_s, 1, "broadcast")
+                if rank == 0:
+                    side["shared_factor"] = dict({"value": per_s * steps_s / el_s, "unit": "solves/s", "ms_per_step": 1e3 * el_s / steps_s,
+                                                  "steps": steps_s, "workload": wl_s, "sharding": sh_s}, **rec_s)
+                    side["shared_factor_allgather"] = dict(extra.get("shared_factor", {}), value=out["value"], ms_per_step=out["ms_per_step"])
             # (r) the same shared-factor job at more samples per factor and rank: the factor (and its broadcast) is paid once
             # per posterior, the sample sweeps scale with the ranks -- which regime reaches what multiple of one rank
             leg["name"] = "regimes"
@@ -750,9 +814,11 @@ def main():
                         j4.step(first + s)
                 run4(0, 1)
                 el4 = timed(run4, sync, dist, torch, 1, 3)
+                ph4 = gather_phases(j4)
                 if rank == 0:
                     side["c4_elliptic512"] = {"ms_per_job": 1e3 * el4 / 3, "value": (1 + k4 * world) * 3 / el4, "unit": "solves/s",
                                               "samples_total": k4 * world, "samples_per_rank": k4,
+                                              "root_factor_ms": (ph4 or {}).get("root", {}).get("factor_ms"), "phase_ms_last_step": ph4,
                                               "workload": f"{w4.name}: n={w4.n}, {w4.n_blocks} blocks x {w4.block_size}"}
                 e4.F.close()
             except Exception as e:      # noqa: BLE001
@@ -780,6 +846,17 @@ def main():
             leg["failed"] = True
         if rank == 0:
             out["side_legs"] = side
+            # what a SCALE record is read for, at the top level: north_star's job in both forms, what it
+            # puts on a link, how many ranks RCCL saw, and for C4 the serial root factorisation beside the whole job
+            sg = side.get("shared_factor_allgather") or {}
+            sb = side.get("shared_factor") or ({} if not shared else dict(extra.get("shared_factor", {}), value=out["value"]))
+            out["shared_factor_solves_per_s"] = sg.get("value") if sg else sb.get("value")
+            out["shared_factor_form"] = "allgather" if sg else sb.get("form")
+            out["shared_factor_broadcast_solves_per_s"] = sb.get("value")
+            out["bytes_per_link_per_step"] = {"allgather": sg.get("bytes_per_link_per_step"), "broadcast": sb.get("bytes_per_link_per_step")}
+            out["rccl_ranks"] = world if (transport == "cabi" or backend == "nccl") else 0
+            c4 = side.get("c4_elliptic512") or {}
+            out["c4_elliptic512"] = {k: c4.get(k) for k in ("ms_per_job", "root_factor_ms", "value", "samples_total") if k in c4}
         watchdog.cancel()
     elif pj is not None and world > 1:
         pj.close()

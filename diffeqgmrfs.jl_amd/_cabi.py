@@ -31,7 +31,7 @@ EXPORTS = [
     "gmrf_bt_set_profiling", "gmrf_bt_set_eager", "gmrf_bt_synchronize", "gmrf_bt_set_batch", "gmrf_bt_select_problem",
     "gmrf_bt_marginal_var_batch", "gmrf_bt_export_size", "gmrf_bt_export_factor", "gmrf_bt_import_factor",
     "gmrf_comm_unique_id", "gmrf_comm_create", "gmrf_comm_destroy", "gmrf_comm_bcast_host", "gmrf_comm_allreduce_sum",
-    "gmrf_bt_bcast_blocks_async", "gmrf_comm_wait", "gmrf_comm_bytes", "gmrf_streams_create", "gmrf_streams_destroy",
+    "gmrf_bt_bcast_blocks_async", "gmrf_bt_allgather_blocks_async", "gmrf_comm_wait", "gmrf_comm_bytes", "gmrf_streams_create", "gmrf_streams_destroy",
     "gmrf_bt_packed_size", "gmrf_bt_pack_blocks_async", "gmrf_bt_unpack_blocks_async",
     "gmrf_csr_create", "gmrf_csr_destroy", "gmrf_spmm", "gmrf_spmm_rows", "gmrf_spmm_async", "gmrf_spmm_rows_async",
     "gmrf_darcy_p1_create", "gmrf_darcy_p2_create", "gmrf_darcy_p1_destroy", "gmrf_darcy_p1_pattern", "gmrf_darcy_p1_assemble",
@@ -39,7 +39,7 @@ EXPORTS = [
     "gmrf_shallow_water_p1_create", "gmrf_shallow_water_p1_destroy", "gmrf_shallow_water_p1_pattern", "gmrf_shallow_water_p1_qpoints",
     "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
-    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_gemm_shapes", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing", "gmrf_test_persist_stamps",
+    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_gemm_shapes", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing", "gmrf_test_persist_stamps", "gmrf_test_clock_probe_start", "gmrf_test_clock_probe_finish",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench", "gmrf_test_symbolic_csc",
 ]
 
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
         "gmrf_comm_bcast_host": [vp, vp, i64, i32],
         "gmrf_comm_allreduce_sum": [vp, vp, vp, i64],
         "gmrf_bt_bcast_blocks_async": [vp, vp, i32, i64, i64, i32],
+        "gmrf_bt_allgather_blocks_async": [vp, vp, vp, i64, i64],
         "gmrf_comm_wait": [vp, vp],
         "gmrf_comm_bytes": [vp, i32, P(dbl)],
         "gmrf_bt_packed_size": [vp, i64, i64, P(i64)],
@@ -176,6 +177,8 @@ def load() -> C.CDLL:
         "gmrf_test_potrf_block": [i32, i64, vp, vp, P(i32)],
         "gmrf_test_tile_timing": [vp, i32],
         "gmrf_test_persist_stamps": [vp, i32],
+        "gmrf_test_clock_probe_start": [i32, i32, i32, P(vp)],
+        "gmrf_test_clock_probe_finish": [vp, vp, vp],
         "gmrf_test_mfma_f64_rate": [i32, P(dbl)],
         "gmrf_test_hbm_rate": [i32, i64, P(dbl)],
         "gmrf_test_microbench": [i32, vp, i32],

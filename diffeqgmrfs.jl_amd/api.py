@@ -986,6 +986,11 @@ class Comm:
     def bcast_blocks_async(self, F: TridiagonalCholeskyFactor, i0: int, i1: int, root: int = 0, with_l: bool = False):
         _cabi.check(self._lib.gmrf_bt_bcast_blocks_async(F._h, self._h, root, i0, i1, int(with_l)))
 
+    def allgather_blocks_async(self, F_own: TridiagonalCholeskyFactor, F_all: TridiagonalCholeskyFactor, i0: int, i1: int):
+        """Blocks [i0, i1) of every rank's share `F_own` (batch b) -> `F_all` (batch world * b) on every rank
+        (gmrf_bt_allgather_blocks_async: pack, ncclAllGather, unpack on the communicator's stream)."""
+        _cabi.check(self._lib.gmrf_bt_allgather_blocks_async(F_own._h, F_all._h, self._h, i0, i1))
+
     def wait(self, F: TridiagonalCholeskyFactor):
         _cabi.check(self._lib.gmrf_comm_wait(F._h, self._h))
 

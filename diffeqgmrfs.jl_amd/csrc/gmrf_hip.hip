@@ -143,6 +143,7 @@ struct gmrf_handle {
     std::vector<int> kst, mend;        // mend[u]: column tile u (64 columns from cmin) is zero below row mend[u]
     int* d_kst = nullptr;              // device copies: [bsp / 64] each
     int* d_mend = nullptr;
+    int* d_kbx = nullptr;              // [bsp / 64]: max(0, 64 u - cmin): first non-zero row of column tile u of Linv_i[cmin:, :] (selected inversion)
     int kst_cap = 0;
     double c_streamed = 0.0;           // doubles of one C_i inside the staircase (what a k = 1 sweep reads)
     double g2_tile_k = 0.0;            // sum over lower tiles of the K extent of S = -C C^T (flop accounting)
@@ -164,6 +165,8 @@ struct gmrf_handle {
     int64_t alloc_rm = 0, alloc_wc = 0;
     bool alloc_keep_l = true;
     double *d_S = nullptr, *d_B = nullptr, *d_T = nullptr, *d_W = nullptr;
+    double* d_V = nullptr;             // two more work blocks per problem, allocated by the first exact-variance call (var_exact)
+    int64_t v_elems = 0;
     int* d_info = nullptr;
     double* d_logdet = nullptr;
     int64_t alloc_N = 0, alloc_bsp = 0;
@@ -363,10 +366,17 @@ static gmrf_status set_layout(gmrf_handle* h, int64_t cmin, int64_t rmax, const 
         h->g2_tile_k += (double)(t + 1) * (double)(bsp - cmin - h->kst[t]);    // tiles (t, 0..t) start at kst[t]
     }
     if (!h->d_kst || !h->d_mend || h->kst_cap < ntile) {
-        free_dev(h->d_kst); free_dev(h->d_mend); h->d_kst = h->d_mend = nullptr; h->kst_cap = 0;
+        free_dev(h->d_kst); free_dev(h->d_mend); free_dev(h->d_kbx); h->d_kst = h->d_mend = h->d_kbx = nullptr; h->kst_cap = 0;
         HIPCHK(hipMalloc(&h->d_kst, sizeof(int) * ntile));
         HIPCHK(hipMalloc(&h->d_mend, sizeof(int) * ntile));
+        HIPCHK(hipMalloc(&h->d_kbx, sizeof(int) * ntile));
         h->kst_cap = ntile;
+    }
+    {
+        std::vector<int> kbx((size_t)ntile);
+        for (int u = 0; u < ntile; ++u) kbx[(size_t)u] = (int)std::max<int64_t>(0, 64 * (int64_t)u - cmin);
+        HIPCHK(hipMemcpyAsync(h->d_kbx, kbx.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));        // (kbx is a local)
     }
     HIPCHK(hipMemcpyAsync(h->d_kst, h->kst.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(h->d_mend, h->mend.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, h->stream));
@@ -1231,6 +1241,9 @@ static gmrf_status ensure_full_inverse(gmrf_handle* h) {
 
 // Stream captures of different handles (host threads) are taken one at a time: capture + instantiate is a
 // once-per-shape set-up step, and concurrent captures are the one place where handles would meet inside the runtime.
+// A PRECAUTION, not a diagnosed fix: no fault of the runtime under concurrent thread-local captures was ever reproduced or
+// traced to a cause here (round 2 saw one unexplained profiler-side crash and kept no log of it); the mutex costs nothing
+// in steady state (graphs are replayed, not re-captured) and can go once concurrent captures have been shown to be safe.
 static std::mutex g_capture_mu;
 
 static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
@@ -1567,7 +1580,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
-    free_dev(h->d_info); free_dev(h->d_logdet); free_dev(h->d_pflags);
+    free_dev(h->d_info); free_dev(h->d_logdet); free_dev(h->d_pflags); free_dev(h->d_kbx); free_dev(h->d_V);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
     free_dev(h->d_stage); free_dev(h->d_mean); free_dev(h->d_acc);
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -2107,6 +2120,7 @@ struct RcclApi {
     int (*CommDestroy)(void*) = nullptr;
     int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
@@ -2132,7 +2146,7 @@ static gmrf_status rccl_load() {
     if (!g_rccl.field) { g_last_error = std::string("librccl lacks ") + name; return GMRF_ERR_RCCL; }
     GMRF_RCCL_SYM(GetUniqueId, "ncclGetUniqueId") GMRF_RCCL_SYM(CommInitRank, "ncclCommInitRank")
     GMRF_RCCL_SYM(CommDestroy, "ncclCommDestroy") GMRF_RCCL_SYM(Broadcast, "ncclBroadcast")
-    GMRF_RCCL_SYM(AllReduce, "ncclAllReduce") GMRF_RCCL_SYM(GroupStart, "ncclGroupStart")
+    GMRF_RCCL_SYM(AllReduce, "ncclAllReduce") GMRF_RCCL_SYM(AllGather, "ncclAllGather") GMRF_RCCL_SYM(GroupStart, "ncclGroupStart")
     GMRF_RCCL_SYM(GroupEnd, "ncclGroupEnd") GMRF_RCCL_SYM(GetErrorString, "ncclGetErrorString")
 #undef GMRF_RCCL_SYM
     g_rccl.lib = lib;
@@ -2283,6 +2297,42 @@ gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t roo
         if (rc != 0 || rg != 0) { g_last_error = std::string("ncclBroadcast: ") + g_rccl.GetErrorString(rc ? rc : rg); return GMRF_ERR_RCCL; }
         c->bytes_moved += (double)cnt * (double)h->B * sizeof(double);
     }
+    return GMRF_OK;
+}
+
+// The other way to share a batch of factors (round 4): EVERY rank factors its own share of the batch -- `src`, src->B
+// posteriors -- and the packed images of the blocks [i0, i1) are all-gathered into `dst`, a handle of the same shape and layout
+// with a batch of world * src->B: problem r * src->B + p of dst is problem p of rank r.  Against the root broadcast every link
+// of the fabric carries a share of the traffic (per rank (world - 1) / world of the batch comes in over all its links, instead of
+// the whole batch leaving the root over each of ITS links) and the factorisation itself is spread over the ranks.
+// Enqueued on the communicator's stream behind src's stream; gmrf_comm_wait(dst, c) orders dst's stream behind the unpack.
+gmrf_status gmrf_bt_allgather_blocks_async(gmrf_handle* src, gmrf_handle* dst, gmrf_comm* c, int64_t i0, int64_t i1) {
+    if (!src || !dst || !c) return bad_shape("null pointer");
+    if (!src->d_Linv || !dst->d_Linv || src->N <= 0) { g_last_error = "no factor storage"; return GMRF_ERR_NO_FACTOR; }
+    if (src->n != dst->n || src->N != dst->N || src->bsp != dst->bsp || src->cmin != dst->cmin || src->rmax != dst->rmax || src->kst != dst->kst)
+        return bad_shape("the two handles differ in shape or coupling-block layout (gmrf_bt_adopt_layout the gathering handle with the factoring handle's record)");
+    if (dst->B != src->B * (int64_t)c->world) return bad_shape("the gathering handle's batch must be world x the factoring handle's");
+    if (i0 < 0 || i1 > src->N || i0 >= i1) return bad_shape("bad block range");
+    if (c->device != src->device || c->device != dst->device) return bad_shape("communicator and handles live on different devices");
+    HIPCHK(hipSetDevice(src->device));
+    int64_t seg = 0;
+    GCHK(gmrf_bt_packed_size(src, i0, i1, &seg));
+    const size_t own = (size_t)seg * (size_t)src->B, all = own * (size_t)c->world;
+    const size_t need = (own + all) * sizeof(double);          // [own image | gathered images]
+    if (need > c->pack_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        free_dev(c->d_pack); c->d_pack = nullptr; c->pack_cap = 0;
+        HIPCHK(hipMalloc(&c->d_pack, need));
+        c->pack_cap = need;
+    }
+    HIPCHK(hipEventRecord(c->ev_in, src->stream));
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    HIPCHK(hipEventRecord(c->ev_in, dst->stream));            // dst's earlier sweeps still read the blocks the unpack overwrites
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_in, 0));
+    GCHK(pack_blocks_on(src, c->stream, i0, i1, c->d_pack, true));
+    NCCLCHK(g_rccl.AllGather(c->d_pack, c->d_pack + own, own, /*ncclFloat64*/ 8, c->comm, c->stream));
+    c->bytes_moved += (double)(all - own) * sizeof(double);    // what came in over this rank's links
+    GCHK(pack_blocks_on(dst, c->stream, i0, i1, c->d_pack + own, false));
     return GMRF_OK;
 }
 
@@ -3517,32 +3567,78 @@ static gmrf_status need_single(gmrf_handle* h) {
 }
 
 static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
-    // S_NN = Linv_N^T Linv_N ;  S_ii = Linv_i^T Linv_i + G^T S_{i+1,i+1} G,  G = C_i Linv_i
-    // (all problems of a batch in lock step: problem strides on every operand; d_out is [B][n])
+    // Selected inversion (Takahashi recurrence on the block-tridiagonal factor), all problems of a batch in lock step:
+    //   S_NN = X_N^T X_N,   S_ii = X_i^T (I + C_i^T S_{i+1,i+1} C_i) X_i,      X_i = Linv_i, C_i = L_{i+1,i};  d_out[B][n] = diag.
+    // Round 4: what the recurrence NEEDS of S_ii is its diagonal and its leading rmax x rmax block (C_i is zero below row rmax
+    // and left of column cmin), and both follow from  S_ii = X^T Y,  Y = X with its rows >= cmin replaced by
+    // (I + M) X[cmin:, :],  M = C_w^T S' C_w  (C_w: the stored window of C_i, S' = S_{i+1,i+1}[0:rmax, 0:rmax]):
+    //   T1 = S' C_w                 rmax x wc,   K = rmax, column tile u of C_w ends at row mend[u]
+    //   M  = T1^T C_w               wc x wc, lower tiles, same K bound (T1^T by a tile transpose: the LDS-DMA GEMM takes no
+    //                               operand stored [k][m]), mirrored
+    //   Y[cmin:, :] = M X[cmin:, :] + X[cmin:, :]          K = wc from the first non-zero row of each column tile of X
+    //   S[0:rmax, 0:rmax] = X^T[0:rmax, :] Y[:, 0:rmax]    lower tiles, K from each row tile's diagonal (X^T by a tile transpose)
+    //   diag(S)[n] = sum_k X[k][n] Y[k][n]                  (coldot_lower)
+    // 1.9 GF per 1024-block instead of 5.7 (two full 1024^3 products, two of them on the register-staged kernel that the
+    // [k][m] operand forced), every product on gemm_f64_dma.
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp;
     const int64_t pX = stride_pX(h), pCm = stride_pC(h), pW = bstride;
     const int cm = (int)h->cmin, rm = (int)h->rmax, wc = bsp - cm;
+    const unsigned nb = (unsigned)h->B;
     GCHK(ensure_full_inverse(h));
-    double* Sg = h->d_S;     // current Sigma_{i+1,i+1}
-    double* G = h->d_B;
-    double* Hm = h->d_T;
+    if (!h->d_V || h->v_elems < 2 * bstride * h->B) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        free_dev(h->d_V); h->d_V = nullptr; h->v_elems = 0;
+        HIPCHK(hipMalloc(&h->d_V, sizeof(double) * 2 * (size_t)bstride * (size_t)h->B));
+        h->v_elems = 2 * bstride * h->B;
+    }
+    double* Sg = h->d_S;     // leading block of Sigma_{i+1,i+1} (full, mirrored)
     double* Sn = h->d_W;
-    // G = C_i Linv_i has the rows of C_i: those below rmax stay zero throughout
-    if (h->N > 1 && rm < bsp) HIPCHK(hipMemsetAsync(G, 0, sizeof(double) * bstride * h->B, h->stream));
+    double* Xt = h->d_B;     // rows 0 .. rmax of Linv_i^T
+    double* Y = h->d_T;
+    double* V1 = h->d_V;                                 // T1, then M
+    double* V2 = h->d_V + bstride * h->B;                // T1^T
+    const int nt = bsp / 64, trm = rm / 64, twc = wc / 64;
     for (int64_t i = h->N - 1; i >= 0; --i) {
         const double* X = h->d_Linv + i * bstride;
-        GCHK(gemm(h, true, true, bsp, bsp, bsp, TRI_A_UPPER | TRI_B_LOWER, 0, 1.0, X, ld, X, ld, 0.0, Sn, ld, pX, pX, pW));
-        if (i < h->N - 1) {
-            // stored window of C_i: rows 0 .. rm, columns cm ..  ->  G[0:rm, :] = C_w * Linv_i[cm:, :]
+        const bool coupled = i < h->N - 1;
+        if (coupled) {
             const double* C = h->d_C + i * c_blk(h);
-            GCHK(gemm(h, false, true, rm, bsp, wc, 0, 0, 1.0, C, c_ld(h), X + (int64_t)cm * ld, ld, 0.0, G, ld, pCm, pX, pW,
-                      1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, h->d_kst, nullptr, nullptr));
-            GCHK(gemm(h, false, true, bsp, bsp, bsp, 0, 0, 1.0, Sg, ld, G, ld, 0.0, Hm, ld, pW, pW, pW));
-            GCHK(gemm(h, true, true, bsp, bsp, bsp, 0, 0, 1.0, G, ld, Hm, ld, 1.0, Sn, ld, pW, pW, pW));
+            // T1 = S' C_w
+            GCHK(gemm(h, false, true, rm, wc, rm, 0, 0, 1.0, Sg, ld, C, c_ld(h), 0.0, V1, ld, pW, pCm, pW,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * rm * h->c_streamed * (double)h->B, nullptr, nullptr, h->d_mend));
+            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(trm * twc), nb), dim3(256), 0, h->stream, V1, ld, V2, ld, pW, pW, trm, twc, 0);
+            HIPCHK(hipGetLastError());
+            // M = T1^T C_w (lower tiles), mirrored
+            GCHK(gemm(h, false, true, wc, wc, rm, 0, 1, 1.0, V2, ld, C, c_ld(h), 0.0, V1, ld, pW, pCm, pW,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, nullptr, nullptr, h->d_mend));
+            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(twc * (twc + 1) / 2), nb), dim3(256), 0, h->stream, V1, ld, V1, ld, pW, pW, twc, twc, 2);
+            HIPCHK(hipGetLastError());
+            // Y[cmin:, :] = M X[cmin:, :] + X[cmin:, :]   (column tile u of X[cmin:, :] starts at row max(0, 64 u - cmin))
+            GCHK(gemm(h, false, true, wc, bsp, wc, 0, 0, 1.0, V1, ld, X + (int64_t)cm * ld, ld, 1.0, Y + (int64_t)cm * ld, ld, pW, pX, pW,
+                      1, 0, 0, 0, X + (int64_t)cm * ld, ld, pX, 0, -1.0, nullptr, h->d_kbx, nullptr));
         }
-        hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((h->bs + 255) / 256), (unsigned)h->B), dim3(256), 0, h->stream,
-                           Sn, ld, (int)h->bs, d_out + i * h->bs, bstride, h->n);
+        // diag(S_ii)
+        hipLaunchKernelGGL(coldot_lower, dim3((unsigned)nt, nb), dim3(256), 0, h->stream, X, coupled ? Y : nullptr, ld, bsp, cm, (int)h->bs,
+                           d_out + i * h->bs, pX, pW, h->n);
+        HIPCHK(hipGetLastError());
+        if (i == 0) break;                               // nobody needs the leading block of S_00
+        // leading block of S_ii for the next step: rows 0 .. rmax of X^T, then the product on its lower tiles, mirrored
+        {
+            int tiles = 0;
+            for (int c = 0; c < trm; ++c) tiles += nt - c;
+            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)tiles, nb), dim3(256), 0, h->stream, X, ld, Xt, ld, pX, pW, nt, trm, 1);
+            HIPCHK(hipGetLastError());
+        }
+        if (coupled) {
+            if (cm > 0)
+                GCHK(gemm(h, false, true, rm, rm, cm, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, Xt, ld, X, ld, 0.0, Sn, ld, pW, pX, pW));
+            GCHK(gemm(h, false, true, rm, rm, wc, 0, 1, 1.0, Xt + cm, ld, Y + (int64_t)cm * ld, ld, cm > 0 ? 1.0 : 0.0, Sn, ld, pW, pW, pW,
+                      1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, h->d_kbx, nullptr, nullptr));
+        } else {
+            GCHK(gemm(h, false, true, rm, rm, bsp, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, Xt, ld, X, ld, 0.0, Sn, ld, pW, pX, pW));
+        }
+        hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(trm * (trm + 1) / 2), nb), dim3(256), 0, h->stream, Sn, ld, Sn, ld, pW, pW, trm, trm, 2);
         HIPCHK(hipGetLastError());
         std::swap(Sg, Sn);
     }
@@ -3763,6 +3859,45 @@ gmrf_status gmrf_test_gemm_shapes(gmrf_handle* h, double* rows, int64_t cap_rows
         for (int c = 0; c < 8; ++c) rows[i * 11 + c] = (double)g.key[c];
         rows[i * 11 + 8] = g.launches; rows[i * 11 + 9] = g.ms; rows[i * 11 + 10] = g.work;
     }
+    return GMRF_OK;
+}
+
+// Shader clock under load: _start launches clock_probe_kernel on a stream of its own and returns; the caller
+// runs the load under test on its streams; _finish waits for the probe and returns, per sample interval, the clock in GHz
+// (median over the probe's 8 waves) and the interval's start in ms since the first sample.  ghz / t_ms: n - 1 values.
+struct ClockProbe { int device; hipStream_t st; unsigned long long* d; int n; };
+gmrf_status gmrf_test_clock_probe_start(int32_t device, int32_t n, int32_t sleeps, void** probe) {
+    if (!probe || n < 2 || n > 100000 || sleeps < 1 || sleeps > 64) return bad_shape("clock probe: 2 <= n <= 100000, 1 <= sleeps <= 64");
+    HIPCHK(hipSetDevice(device));
+    ClockProbe* p = new ClockProbe{device, nullptr, nullptr, n};
+    HIPCHK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&p->d, sizeof(unsigned long long) * 2 * 8 * (size_t)n));
+    HIPCHK(hipMemsetAsync(p->d, 0, sizeof(unsigned long long) * 2 * 8 * (size_t)n, p->st));
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(8), dim3(64), 0, p->st, p->d, n, sleeps);
+    HIPCHK(hipGetLastError());
+    *probe = p;
+    return GMRF_OK;
+}
+gmrf_status gmrf_test_clock_probe_finish(void* probe, double* ghz, double* t_ms) {
+    ClockProbe* p = static_cast<ClockProbe*>(probe);
+    if (!p || !ghz) return bad_shape("null pointer");
+    HIPCHK(hipSetDevice(p->device));
+    HIPCHK(hipStreamSynchronize(p->st));
+    std::vector<unsigned long long> h((size_t)2 * 8 * p->n);
+    HIPCHK(hipMemcpy(h.data(), p->d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int i = 0; i + 1 < p->n; ++i) {
+        double v[8];
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long* a = &h[((size_t)b * p->n + i) * 2];
+            const double dc = (double)(a[2] - a[0]), dr = (double)(a[3] - a[1]);
+            v[b] = dr > 0 ? dc / dr * 0.1 : 0.0;
+        }
+        std::sort(v, v + 8);
+        ghz[i] = 0.5 * (v[3] + v[4]);
+        if (t_ms) t_ms[i] = (double)(h[(size_t)i * 2 + 1] - h[1]) * 1e-5;
+    }
+    (void)hipFree(p->d); (void)hipStreamDestroy(p->st);
+    delete p;
     return GMRF_OK;
 }
 

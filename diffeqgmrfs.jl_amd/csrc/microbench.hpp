@@ -46,6 +46,19 @@ __global__ __launch_bounds__(256) void mb_valu_f64(unsigned long long* out, doub
     if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
 }
 
+// Shader-clock probe (round 4): one wave per block (8 blocks: one per XCD under the observed round-robin placement) stamps
+// {s_memtime, s_memrealtime} every ~`sleeps` x 3.4 us for n samples while OTHER streams run the load under test; the clock between
+// two samples is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).  Bounded: n samples, then it ends.
+__global__ __launch_bounds__(64) void clock_probe_kernel(unsigned long long* out, int n, int sleeps) {
+    for (int i = 0; i < n; ++i) {
+        if (threadIdx.x == 0) {
+            out[((size_t)blockIdx.x * n + i) * 2] = __builtin_amdgcn_s_memtime();
+            out[((size_t)blockIdx.x * n + i) * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+        }
+        for (int s = 0; s < sleeps; ++s) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
 __global__ void mb_null(int* p) {
     if (p && threadIdx.x == 1000) p[0] = 1;
 }

@@ -985,6 +985,59 @@ __global__ void extract_diag_dense(const double* __restrict__ S, int64_t ld, int
 
 // S = 0.5 (S + S^T) is not needed: selected inversion keeps symmetry to rounding.
 
+// ---- selected inversion, round 4 (gmrf_hip.hip: var_exact) ----------------------------------------------------------
+// 64 x 64 tiles of a row-major matrix transposed through LDS: dst[c][r] = src[r][c].
+//   mode 0: every tile of a (64 tr) x (64 tc) matrix            -> grid.x = tr * tc
+//   mode 1: the tiles r >= c, c < tc, of a lower-triangular (64 tr)^2 matrix (Linv_i -> its transpose, rows 0 .. 64 tc)
+//           -> grid.x = sum_{c < tc} (tr - c)
+//   mode 2: in place, the lower triangle of a (64 tr)^2 matrix into the upper one (mirror of a product that was formed
+//           on its lower tiles only) -> grid.x = tr (tr + 1) / 2.  Diagonal tiles are mirrored element-wise: the 64 x 64
+//           kernels write them whole, the 32 x 32-tile kernel of small launches (gemm_f64_ll) leaves their upper-right
+//           quarter unwritten.
+// blockIdx.y = problem.
+__global__ __launch_bounds__(256) void transpose_tiles(const double* __restrict__ src, int64_t lds_, double* __restrict__ dst,
+                                                       int64_t ldd, int64_t pS, int64_t pD, int tr, int tc, int mode) {
+    __shared__ double t[64][65];
+    int r, c;
+    const int w = (int)blockIdx.x;
+    if (mode == 0) { r = w / tc; c = w % tc; }
+    else if (mode == 1) { int q = w; c = 0; while (q >= tr - c) { q -= tr - c; ++c; } r = c + q; }
+    else { int q = w; r = 0; while (q > r) { q -= r + 1; ++r; } c = q; }
+    const double* s = src + (int64_t)blockIdx.y * pS + (int64_t)r * 64 * lds_ + (int64_t)c * 64;
+    double* d = dst + (int64_t)blockIdx.y * pD + (int64_t)c * 64 * ldd + (int64_t)r * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[ty + 4 * i][tx] = s[(int64_t)(ty + 4 * i) * lds_ + tx];
+    __syncthreads();
+    const bool diag = mode == 2 && r == c;
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+        if (!diag || ty + 4 * i < tx) d[(int64_t)(ty + 4 * i) * ldd + tx] = t[tx][ty + 4 * i];
+}
+
+// out[n] = sum_{k >= n} X[k][n] * (k < cm || !Y ? X[k][n] : Y[k][n])     diag(Linv^T Y) with Y = Linv above row cm:
+// a workgroup owns 64 columns (a lane a column: rows are read as whole 512-byte lines), its four waves split the
+// rows from the column block's diagonal down, fixed summation order (rows ascending per wave, waves 0 .. 3).
+__global__ __launch_bounds__(256) void coldot_lower(const double* __restrict__ X, const double* __restrict__ Y, int64_t ld, int bsp,
+                                                    int cm, int bs, double* __restrict__ out, int64_t pX, int64_t pY, int64_t pout) {
+    __shared__ double part[4][64];
+    const int u = (int)blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = 64 * u + lane;
+    const double* x = X + (int64_t)blockIdx.y * pX;
+    const double* y = Y ? Y + (int64_t)blockIdx.y * pY : nullptr;
+    const int k0 = 64 * u, span = bsp - k0, per = (span / 4 + 63) / 64 * 64;
+    const int kb = k0 + wv * per, ke = min(bsp, kb + per);
+    double acc = 0.0;
+    for (int k = kb; k < ke; ++k) {
+        const double xv = x[(int64_t)k * ld + n];
+        const double yv = (y && k >= cm) ? y[(int64_t)k * ld + n] : xv;
+        acc = fma(xv, yv, acc);
+    }
+    part[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && n < bs) out[(int64_t)blockIdx.y * pout + n] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+}
+
 // dense identity add: M[i][i] += 1
 __global__ void add_identity(double* __restrict__ M, int64_t ld, int bs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -33,6 +33,9 @@ namespace gmrf {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+// words in LDS that waves of one workgroup pass to each other: address space 3 (a generic `volatile int*` became FLAT loads /
+// stores with sc0 sc1, which wait for every outstanding global store of the wave: 1 200 cycles per look, round 4)
+typedef __attribute__((address_space(3))) volatile int lds_word;
 
 struct PersistArgs {
     double* S; double* L; double* X;
@@ -96,8 +99,8 @@ __device__ __forceinline__ bool spin_until(const unsigned* f, unsigned* abort_w,
 // words used alternately (`phase` counts the waits of this workgroup) so that a word is never rewritten while a slower wave
 // still reads the previous verdict.
 __device__ __forceinline__ bool wg_wait(const unsigned* a, const unsigned* b, const unsigned* c, const PersistArgs& pa,
-                                        volatile int* okw, int& phase, int tid) {
-    volatile int* w = okw + (phase & 1);
+                                        lds_word* okw, int& phase, int tid) {
+    lds_word* w = okw + (phase & 1);
     ++phase;
     if (tid == 0) {
         bool ok = true;
@@ -181,7 +184,114 @@ __device__ __forceinline__ void strip_store_sc1(double* g, int64_t ld, const v4d
         }
 }
 
-constexpr size_t POTRF_PERSIST_LDS = POTRF_STEP_LDS + 64;      // + the two verdict words of wg_wait
+constexpr size_t POTRF_PERSIST_LDS = POTRF_STEP_LDS + 64;      // + the two verdict words of wg_wait, two prefetch words
+
+// Diagonal tile update  T = N - L L^T  (lower 16 x 16 blocks) with the ten blocks dealt 3 / 3 / 2 / 2 over the four waves instead of
+// strip by strip (1 / 2 / 3 / 4: wave 3's 64 MFMAs were the length of the step, 4 450 cycles; now 48).  Every block is summed as
+// strip_nt sums it (k groups ascending, the two k of a group in order): bitwise the same tile.
+template <int W>
+__device__ __forceinline__ void diag_update_balanced(const double* Ls, const double* Ns, double* Ts, int li, int lq) {
+    constexpr int BI[4][3] = {{0, 3, 3}, {1, 1, 3}, {2, 2, -1}, {2, 3, -1}};
+    constexpr int BJ[4][3] = {{0, 0, 1}, {0, 1, 2}, {0, 1, -1}, {2, 3, -1}};
+    v4d acc[3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) acc[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            if (BI[W][b] >= 0) {
+                const v2d av = *reinterpret_cast<const v2d*>(Ls + (16 * BI[W][b] + li) * TLD + k);
+                const v2d bv = *reinterpret_cast<const v2d*>(Ls + (16 * BJ[W][b] + li) * TLD + k);
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc[b], 0, 0, 0);
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc[b], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        if (BI[W][b] >= 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int off = (16 * BI[W][b] + lq + 4 * q) * TLD + 16 * BJ[W][b] + li;
+                Ts[off] = Ns[off] - acc[b][q];
+            }
+        }
+    }
+}
+__device__ __forceinline__ void diag_update_balanced_w(int w, const double* Ls, const double* Ns, double* Ts, int li, int lq) {
+    switch (w) {
+        case 0: diag_update_balanced<0>(Ls, Ns, Ts, li, lq); break;
+        case 1: diag_update_balanced<1>(Ls, Ns, Ts, li, lq); break;
+        case 2: diag_update_balanced<2>(Ls, Ns, Ts, li, lq); break;
+        default: diag_update_balanced<3>(Ls, Ns, Ts, li, lq); break;
+    }
+}
+
+// What waves 1 and 2 of the chain workgroup do in the shadow of wave 0's panel factorisations (tile_potrf_inv<Side>):
+//   a0        store L[j+1, j] (in As since the last product): 628 cycles of store issue off the chain;
+//   b(kb)     at the START of their part of panels 1 .. 3 (their own deferred work there is short), never waiting for a flag:
+//             one relaxed look at the two flags of the NEXT step's operands; once both are up, this wave's half of
+//             S'[j+2, j+1] -> As in the same panel and its half of tile (j+2, j+2) -> Bs in the next one, then `tag` into its
+//             LDS word.  The chain takes the prefetched operands only if both words carry the step's tag after the
+//             factorisation, otherwise it waits and loads as before (1 450 + 2 400 cycles a step).
+struct ChainSide {
+    const double* sL; double* gL;             // LDS tile -> global (nullptr: nothing to store)
+    const unsigned* f1; const unsigned* f2;   // flags the prefetch needs (nullptr: none)
+    const double* gA; double* sA;             // nullptr: no next step
+    const double* gN; double* sN;
+    int64_t ld;
+    lds_word* done;                           // LDS: [0] wave 1, [1] wave 2
+    int tag;
+    int state;                                // per wave: 0 flags not seen, 1 As half loaded, 2 both halves loaded
+    unsigned long long* stamps;
+    __device__ __forceinline__ void half_load(const double* g, double* s, int half, int lane) const {
+        const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
+        v4u v[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = half * 1024 + lane + it * 64;
+            const int r = idx >> 5, c = (idx & 31) * 2;
+            v[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((r * ld + c) * 8), 0, 16);
+        }
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int idx = half * 1024 + lane + it * 64;
+            const int r = idx >> 5, c = (idx & 31) * 2;
+            *reinterpret_cast<v4u*>(s + r * TLD + c) = v[it];
+        }
+    }
+    __device__ __forceinline__ void a0(int tid) {
+        if (gL && tid < 192) {
+            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(gL);
+            const int t128 = tid - 64;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int idx = t128 + it * 128;
+                const int r = idx >> 5, c = (idx & 31) * 2;
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(sL + r * TLD + c), rs, (int)((r * ld + c) * 8), 0, 16);
+            }
+        }
+    }
+    __device__ __forceinline__ void b(int, int tid) {
+        if (!gA || tid >= 192 || state >= 2) return;
+        const int half = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, lane = tid & 63;
+        if (state == 0) {
+            unsigned ok = 1u;
+            if (f1) ok &= ld_flag(f1);
+            if (f2) ok &= ld_flag(f2);
+            if (!__builtin_amdgcn_readfirstlane(ok)) return;
+            half_load(gA, sA, half, lane);
+            state = 1;
+            return;
+        }
+        half_load(gN, sN, half, lane);
+        state = 2;
+        if (lane == 0) done[half] = tag;
+    }
+    __device__ __forceinline__ void ak(int, int) const {}
+};
 
 template <bool UNUSED>
 __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
@@ -197,7 +307,7 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
     double* rinvs = Wk + 4 * 16 * 18;           // 64
     double* As = rinvs + 64;
     double* Bs = As + TILE_ELEMS;
-    volatile int* okw = reinterpret_cast<volatile int*>(Bs + TILE_ELEMS);
+    lds_word* okw = (lds_word*)reinterpret_cast<int*>(Bs + TILE_ELEMS);
     int phase = 0;
 
     const int tid = threadIdx.x;
@@ -216,25 +326,53 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
 
     if (blockIdx.x == 0) {
         // ------------------------------------------------------------------ the chain
+        lds_word* done = okw + 2;
+        if (tid == 0) { done[0] = 0; done[1] = 0; }
+        ChainSide cs;
+        cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
+        auto prefetch_for = [&](int jn) {                    // operands of step jn (tile jn + 1) -> cs, or none past the last step
+            cs.state = 0; cs.tag = jn + 1;
+            if (jn + 1 < pa.j1) {
+                const int64_t oj = (int64_t)jn * 64, o1 = oj + 64;
+                cs.gA = pa.S + o1 * ld + oj; cs.gN = pa.S + o1 * ld + o1;
+                cs.f1 = (jn > pa.j0) ? fF + (jn + 1) * nt + jn : nullptr;
+                cs.f2 = (jn + 1 >= pa.j0 + 2) ? fF + (jn + 1) * nt + (jn + 1) : nullptr;
+            } else {
+                cs.gA = nullptr; cs.gN = nullptr; cs.f1 = nullptr; cs.f2 = nullptr;
+            }
+        };
         const int64_t o0 = (int64_t)pa.j0 * 64;
         tile_g2s(pa.S + o0 * ld + o0, ld, Ts, tid);
+        cs.gL = nullptr;
+        prefetch_for(pa.j0);
         __syncthreads();
-        tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+        tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
         if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
         tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
         tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
-        wg_publish(fD + pa.j0, nullptr, tid);
+        // The write-through stores of L_jj / X_jj drain BEHIND the next step's first product (1 500 cycles off the chain): the
+        // flags `pend1` / `pend2` go up at that step's first barrier, after every wave's vmcnt(0).  (The step's prefetch words
+        // were written before tile_potrf_inv's last barrier.)
+        unsigned* pend1 = fD + pa.j0;
+        unsigned* pend2 = nullptr;
         if (pa.stamps && tid == 0) pa.stamps[0] = __builtin_amdgcn_s_memtime();
         for (int j = pa.j0; j + 1 < pa.j1; ++j) {
             const int64_t oj = (int64_t)j * 64, o1 = oj + 64;
-            const unsigned* w1 = (j > pa.j0) ? fF + (j + 1) * nt + j : nullptr;
-            const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
-            if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
-            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
-            v4d cpre[4];
-            strip_load_sc1(pa.S + o1 * ld + o1, ld, cpre, wave + 1, wave, li, lq);
-            tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
-            __syncthreads();
+            // (the publish above was a barrier: the two words are what waves 1, 2 left during the last factorisation)
+            const bool pre = done[0] == j + 1 && done[1] == j + 1;
+            if (pre) {
+                if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
+            } else {
+                wg_publish(pend1, pend2, tid);              // (nothing stays unpublished across a wait)
+                pend1 = nullptr; pend2 = nullptr;
+                const unsigned* w1 = (j > pa.j0) ? fF + (j + 1) * nt + j : nullptr;
+                const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
+                if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
+                if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
+                tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
+                tile_g2s_sc1(pa.S + o1 * ld + o1, ld, Bs, tid);
+                __syncthreads();
+            }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 2] = __builtin_amdgcn_s_memtime();
             // L[j+1, j] = As Xs^T   (X lower triangular: column block Jb needs the k groups 0 .. 2 Jb + 1)
             v4d lr[4];
@@ -252,36 +390,36 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
                 }
             }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 3] = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the last tile's stores (every wave its own)
             __syncthreads();
+            if (tid == 0) {
+                if (pend1) st_flag(pend1, 1u);
+                if (pend2) st_flag(pend2, 1u);
+            }
+            pend1 = nullptr; pend2 = nullptr;
 #pragma unroll
             for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 4] = __builtin_amdgcn_s_memtime();
-            tile_s2g_sc1(As, pa.L + o1 * ld + oj, ld, tid);
+            // (L[j+1, j] leaves for global memory in the shadow of the first panel below: ChainSide::a0)
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 5] = __builtin_amdgcn_s_memtime();
             // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
-            v4d pacc[4];
-#pragma unroll
-            for (int Jb = 0; Jb < 4; ++Jb) pacc[Jb] = zero;
-            strip_nt_diag(wave, As + (16 * wave + li) * TLD, As, pacc, li, lq);
-            if (pa.stamps && tid == 192) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();      // (wave 3: the longest product)
-            // (L_jj has left Ts: its stores were drained by wg_publish)
-#pragma unroll
-            for (int Jb = 0; Jb < 4; ++Jb) {
-                if (Jb <= wave) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Ts[(16 * wave + lq + 4 * q) * TLD + 16 * Jb + li] = cpre[Jb][q] - pacc[Jb][q];
-                }
-            }
+            // (the ten lower blocks dealt evenly over the waves; L_jj has left Ts: its stores were drained by wg_publish; the tile
+            //  (j+1, j+1) waits in Bs, prefetched or just loaded)
+            diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
+            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();
+            cs.gL = pa.L + o1 * ld + oj;
+            prefetch_for(j + 1);
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
-            tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
+            tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
             if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
             tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
             tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
-            wg_publish(fD + j + 1, fPL + (j + 1) * nt + j, tid);
+            pend1 = fD + j + 1; pend2 = fPL + (j + 1) * nt + j;
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();
         }
+        wg_publish(pend1, pend2, tid);
         return;
     }
 

@@ -343,11 +343,23 @@ __device__ __forceinline__ void subtile_update(double* Ts, int I, int J, int c0,
 
 // Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
 // Wk: scratch of 4 * 16 * 18 doubles.  All 256 threads of the workgroup must call this.
+__device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int64_t ld, double* s, int t192);
+
+// Work that waves 1-3 do in the shadow of wave 0's panel factorisations (tile_potrf_inv is a template on this type):
+//   a0(tid)      during the first 16-column panel, where they have nothing of their own to do;
+//   b(kb, tid) / ak(kb, tid)  during panels 1 .. 3, before / after their deferred updates and inverse pieces (wave 3 is busy for
+//                most of the panel, waves 1 and 2 are nearly free): loads issued in b() fly beside that work.
 struct SideLoad {          // global 64x64 tiles staged into LDS by waves 1-3 during the first panel
     const double* gA; double* sA;
     const double* gB; double* sB;
     int64_t ld;
     unsigned long long* stamps;     // diagnostic: s_memtime at phase boundaries (tests only)
+    __device__ __forceinline__ void a0(int tid) const {
+        if (gA) side_load_tile(gA, ld, sA, tid - 64);
+        if (gB) side_load_tile(gB, ld, sB, tid - 64);
+    }
+    __device__ __forceinline__ void b(int, int) const {}
+    __device__ __forceinline__ void ak(int, int) const {}
 };
 
 #define TILE_STAMP(i) do { if (side.stamps && tid == 0) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -367,8 +379,9 @@ __device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int
     }
 }
 
+template <class Side>
 __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid,
-                                               bool& bad, const SideLoad& side) {
+                                               bool& bad, Side& side) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     // clear X (its strict upper part and the blocks the assembly does not write stay zero) and
@@ -416,9 +429,9 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
             panel_factor16(Ts, rinvs, Wk, c0, lane, bad, (side.stamps && kb == 0) ? side.stamps + 20 : nullptr);
             TILE_STAMP(2 + 3 * kb);
         } else if (kb == 0) {
-            if (side.gA) side_load_tile(side.gA, side.ld, side.sA, tid - 64);
-            if (side.gB) side_load_tile(side.gB, side.ld, side.sB, tid - 64);
+            side.a0(tid);
         } else {
+            side.b(kb, tid);
             // deferred work of the previous panel (columns c0-16..c0-1): sub-tiles (I, J >= kb+1)
             const int pc0 = c0 - 16;
             if (kb == 1) {
@@ -439,6 +452,7 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
                     store_d16(s31, TLD, sum_ij(2, 1), li, lq);
                 }
             }
+            side.ak(kb, tid);
         }
         __syncthreads();
         TILE_STAMP(3 + 3 * kb);

@@ -174,12 +174,81 @@ class HipEngine:
         self.torch.cuda.synchronize(self.dev)
 
 
+class HipGatherEngine(HipEngine):
+    """The all-gather form of sharing a BATCH of factors (round 4): the `batch_total` posteriors of a step are dealt to
+    the ranks in contiguous shares of b = batch_total / world; every rank factors ITS share (handle `F`, batch b), the
+    packed images of each finished block range are all-gathered into `F_all` (batch batch_total: problem r * b + p = problem
+    p of rank r), and every rank then takes the means of ALL posteriors and draws its own sample ids on `F_all`.  Against
+    the root broadcast the factorisation is spread over the ranks and every link of the fabric carries 1 / world of the
+    images (gmrf_bt_allgather_blocks_async, or torch.distributed.all_gather_into_tensor of the packed image)."""
+
+    def __init__(self, pkg, workload, device_index: int, batch_total: int, world: int, rank: int, values_all, rhs_all,
+                 keep_l: bool = False, transport: str = "torch", comm=None):
+        if batch_total % world:
+            raise ValueError("the shared batch must be a multiple of the number of ranks")
+        b = batch_total // world
+        values_all = np.ascontiguousarray(values_all, dtype=np.float64).reshape(batch_total, -1)
+        rhs_all = np.ascontiguousarray(rhs_all, dtype=np.float64).reshape(batch_total, -1)
+        super().__init__(pkg, workload, device_index=device_index, batch=b, values=values_all[rank * b:(rank + 1) * b],
+                         rhs=rhs_all[rank * b:(rank + 1) * b], keep_l=keep_l, transport=transport, comm=comm)
+        t = self.torch
+        self.share_batch, self.batch, self.world, self.rank = b, batch_total, world, rank      # `batch`: what mean / sample address
+        self.F_all = pkg.TridiagonalCholeskyFactor(device=device_index, stream=self.stream.cuda_stream, batch=batch_total)
+        self.F_all.set_keep_l(False)
+        self.rhs = t.from_numpy(rhs_all.reshape(batch_total, 1, -1)).to(self.dev)
+        self._own, self._all = {}, {}
+
+    def prepare(self, is_root: bool, shared_storage: bool, dist=None):
+        self.F.factor(self.w.Q, self.w.n_blocks, values=self.values_host)      # every rank analyses the pattern and factors once
+        self.F_all.adopt_layout(self.w.n, self.w.n_blocks, self.F.get_layout())
+
+    def adopt_commit(self):
+        self.F_all.adopt_commit(False)
+
+    def share_range(self, dist, i0: int, i1: int, is_root: bool = True):
+        if self.transport == "cabi":
+            self.comm.allgather_blocks_async(self.F, self.F_all, i0, i1)
+            return
+        t = self.torch
+        key = (i0, i1)
+        if key not in self._own:
+            seg = self.F.packed_size(i0, i1)
+            self._own[key] = t.empty((self.share_batch, seg), dtype=t.float64, device=self.dev)
+            self._all[key] = t.empty((self.batch, seg), dtype=t.float64, device=self.dev)
+        own, allb = self._own[key], self._all[key]
+        self.F.pack_blocks_async(i0, i1, own)
+        self._pending.append((dist.all_gather_into_tensor(allb, own, async_op=True), i0, i1, allb))
+        self.bytes_moved += (allb.numel() - own.numel()) * 8
+
+    def share_finish(self, is_root: bool = True):
+        if self.transport == "cabi":
+            self.comm.wait(self.F_all)
+            return
+        for hnd, i0, i1, allb in self._pending:
+            hnd.wait()
+            self.F_all.unpack_blocks_async(i0, i1, allb)
+        self._pending = []
+
+    def mean(self):
+        return self.F_all.solve_batch(self.rhs)[:, 0, :]
+
+    def sample(self, k: int, mean, seed: int, first_id: int, keep: bool = True):
+        if k <= 128:
+            return self.F_all.sample_batch(k, mean=mean, seed=seed, first_id=first_id, like=self.rhs)
+        outs = []
+        for c0 in range(0, k, 128):
+            kc = min(128, k - c0)
+            x = self.F_all.sample_batch(kc, mean=mean, seed=seed, first_id=first_id + c0 * self.batch, like=self.rhs)
+            outs = outs + [x] if keep else [x]
+        return self.torch.cat(outs, dim=1) if keep else outs[0]
+
+
 class ShardedPosterior:
     """One posterior job across `world` ranks (see module docstring)."""
 
     def __init__(self, engine, dist=None, rank: int = 0, world: int = 1, k_samples: int = 64,
                  seed: int = 0x5EED, group: int = 8, replicate_factor: bool = False, force_shared: bool = False,
-                 keep_samples: bool = True, timing: bool = False):
+                 keep_samples: bool = True, timing: bool = False, share: str = "broadcast"):
         """`force_shared`: run the shared-factor protocol (ranged factorisation, broadcasts, commit) even
         with a world of one rank -- rehearsals of the multi-GPU path on a one-GPU box.  `timing`: device events
         around the phases of a step (`phase_ms()` after a synchronisation); HipEngine only."""
@@ -188,6 +257,13 @@ class ShardedPosterior:
         self.replicate = replicate_factor or (world == 1 and not force_shared)
         self.groups = block_groups(engine.w.n_blocks, group)
         self.keep_samples = keep_samples
+        # "broadcast": rank 0 factors, every range is broadcast; "allgather": every rank factors its share of the engine's
+        # batch and the ranges are all-gathered (HipGatherEngine, or an engine with the same protocol)
+        self.share = share
+        if share not in ("broadcast", "allgather"):
+            raise ValueError(share)
+        if share == "allgather":
+            self.replicate = False
         self.timing = timing and hasattr(engine, "torch")
         self._ev = None
 
@@ -207,6 +283,17 @@ class ShardedPosterior:
         if self.replicate:
             self.e.factor()
             self._mark(1); self._mark(2)
+            return
+        if self.share == "allgather":
+            # every rank factors its share of the batch range by range; each finished range is all-gathered beside the next
+            for gi, (i0, i1) in enumerate(self.groups):
+                self.e.factor_range_async(i0, i1, first=(gi == 0))
+                self.e.share_range(self.dist, i0, i1, True)
+            self._mark(1)
+            self.e.factor_end()
+            self.e.share_finish(True)
+            self._mark(2)
+            self.e.adopt_commit()
             return
         root = self.rank == 0
         for gi, (i0, i1) in enumerate(self.groups):

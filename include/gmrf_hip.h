@@ -271,6 +271,17 @@ gmrf_status gmrf_comm_allreduce_sum(gmrf_comm* c, gmrf_handle* stream_of, double
 gmrf_status gmrf_bt_bcast_blocks_async(gmrf_handle* h, gmrf_comm* c, int32_t root, int64_t i0,
                                        int64_t i1, int32_t with_l);
 gmrf_status gmrf_comm_wait(gmrf_handle* h, gmrf_comm* c);
+/* The all-gather form of sharing a BATCH of factors (round 4): every rank factors its own share of the batch on `src`
+ * (src batch b) and the packed images of the blocks [i0, i1) are all-gathered (ncclAllGather) into `dst`, a handle of the same
+ * shape with batch world * b that adopted src's layout record: problem r * b + p of dst = problem p of rank r.  Every rank
+ * then takes means / samples of ALL world * b posteriors on dst (its own sample ids).  Against the root broadcast the
+ * factorisation is spread over the ranks and every xGMI link carries 1 / world of the images instead of the root's links
+ * carrying all of them.
+ *   per job, for each block range:  all: gmrf_bt_factor_step_async(src, i0, i1);
+ *                                        gmrf_bt_allgather_blocks_async(src, dst, c, i0, i1)
+ *            then  all: gmrf_bt_factor_end(src);  gmrf_comm_wait(dst, c);  gmrf_bt_adopt_commit(dst, 0)
+ * (No reference counterpart: the reference is one process.) */
+gmrf_status gmrf_bt_allgather_blocks_async(gmrf_handle* src, gmrf_handle* dst, gmrf_comm* c, int64_t i0, int64_t i1);
 /* Factor bytes this communicator has broadcast so far (reset != 0 clears the counter afterwards). */
 gmrf_status gmrf_comm_bytes(gmrf_comm* c, int32_t reset, double* bytes);
 
@@ -471,6 +482,11 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/ou
  * (csrc/potrf_persist.hpp): out[0] = tile 0 done, then eight per step (tools/persist_stamps.py names them); cycles relative to out[0], -1 = not written. */
 gmrf_status gmrf_test_persist_stamps(double* out, int32_t n);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
+/* Shader clock under load: _start launches a bounded probe (8 waves stamping s_memtime / s_memrealtime every ~3.4 us x sleeps,
+ * n samples) on a stream of its own and returns; run the load under test; _finish waits and returns n - 1 interval clocks in GHz
+ * (median over the 8 waves) and the intervals' start times in ms. */
+gmrf_status gmrf_test_clock_probe_start(int32_t device, int32_t n, int32_t sleeps, void** probe);
+gmrf_status gmrf_test_clock_probe_finish(void* probe, double* ghz, double* t_ms);
 gmrf_status gmrf_test_hbm_rate(int32_t device, int64_t bytes, double* gbps);
 gmrf_status gmrf_test_microbench(int32_t device, double* out, int32_t n);
 /* Host-only part of the symbolic phase of gmrf_bt_factor_csc (needs no device): driven by the sanitizer build of the host

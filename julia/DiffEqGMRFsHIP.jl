@@ -570,6 +570,9 @@ function factor_end!(F::TridiagonalCholeskyFactor)
     check(ccall((:gmrf_bt_factor_end, libgmrf), Int32, (Ptr{Cvoid}, Ref{Int32}), F.handle, info), info[])
     return F
 end
+# the all-gather form (every rank factors its share `Fown`; `Fall` has batch world * batch(Fown) and adopted Fown's layout)
+allgather_blocks_async!(Fown::TridiagonalCholeskyFactor, Fall::TridiagonalCholeskyFactor, c::GmrfComm, i0::Integer, i1::Integer) =
+    check(ccall((:gmrf_bt_allgather_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64), Fown.handle, Fall.handle, c.handle, i0, i1))
 bcast_blocks_async!(F::TridiagonalCholeskyFactor, c::GmrfComm, i0::Integer, i1::Integer; root::Integer = 0, with_l::Bool = false) =
     check(ccall((:gmrf_bt_bcast_blocks_async, libgmrf), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int32, Int64, Int64, Int32), F.handle, c.handle, root, i0, i1, with_l ? 1 : 0))
 comm_wait!(F::TridiagonalCholeskyFactor, c::GmrfComm) =

@@ -66,3 +66,53 @@ def test_two_rank_broadcast_and_sample_sharding(tmp_path, pkg):
     assert np.allclose(np.concatenate([r0["X"], r1["X"]], axis=1), X, rtol=1e-10, atol=1e-12)
     assert np.allclose(r0["acc"], ((X - mu[:, None]) ** 2).sum(axis=1), rtol=1e-12)
     assert np.array_equal(r0["acc"], r1["acc"])
+
+
+def _gather_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import __graft_entry__ as g
+    from importlib import import_module
+    pkg = g.load_package()
+    post = import_module(g.PKG_NAME + ".posterior")
+    from tests.oracle_engine import OracleGatherEngine
+    w = pkg.workloads.make("darcy16")
+    eng = OracleGatherEngine(w, batch_total=2, world=world, rank=rank, scales=[1.0, 1.5])
+    job = post.ShardedPosterior(eng, dist=dist, rank=rank, world=world, k_samples=5, seed=42, group=3, share="allgather")
+    job.prepare()
+    mu, X = job.step(0)
+    np.savez(os.path.join(outdir, f"g{rank}.npz"), mu=mu, X=X, Li=eng.Li.numpy(), C=eng.C.numpy(), Li_own=eng.Li_own.numpy(),
+             solves=job.solves_per_step())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allgather_of_a_shared_batch(tmp_path, pkg):
+    """Round 4: the all-gather form of the shared-factor job -- every rank factors its share of the batch, block ranges are
+    all-gathered, every rank takes the means of ALL posteriors and draws its own sample ids (world 2 over gloo, oracle
+    numerics).  Same factors on both ranks, each rank factored only its own problem, samples independent of the rank count."""
+    world = 2
+    mp.start_processes(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, start_method="spawn")
+    g0 = np.load(tmp_path / "g0.npz")
+    g1 = np.load(tmp_path / "g1.npz")
+    assert np.array_equal(g0["Li"], g1["Li"]) and np.array_equal(g0["C"], g1["C"]) and np.array_equal(g0["mu"], g1["mu"])
+    # problem r of the gathered batch is what rank r factored (and nobody else did)
+    assert np.array_equal(g0["Li"][0], g0["Li_own"][0]) and np.array_equal(g0["Li"][1], g1["Li_own"][0])
+    assert not np.array_equal(g0["Li_own"], g1["Li_own"])
+    assert int(g0["solves"]) == 2 * (1 + 5 * 2)
+    # one process, the same protocol with a world of one: steps 0 and 1 draw the sample ids of ranks 0 and 1
+    from importlib import import_module
+    import __graft_entry__ as g
+    post = import_module(g.PKG_NAME + ".posterior")
+    from tests.oracle_engine import OracleGatherEngine
+    w = pkg.workloads.make("darcy16")
+    eng = OracleGatherEngine(w, batch_total=2, world=1, rank=0, scales=[1.0, 1.5])
+    job = post.ShardedPosterior(eng, k_samples=5, seed=42, group=3, share="allgather")
+    job.prepare()
+    mu, X0 = job.step(0)
+    _, X1 = job.step(1)
+    assert np.allclose(mu, g0["mu"], rtol=1e-12, atol=1e-14)
+    assert np.allclose(X0, g0["X"], rtol=1e-10, atol=1e-12) and np.allclose(X1, g1["X"], rtol=1e-10, atol=1e-12)
+    # the two problems are different posteriors
+    assert not np.allclose(mu[0], mu[1])
