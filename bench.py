@@ -49,6 +49,7 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
     15: ("gemm_f64_dma<B[k][n]>", "mfma"),       # LDS-DMA staged GEMM, B stored [k][n]
     12: ("gemm_f64_mfma<true,*>", "mfma"),       # A stored [k][m] (selected inversion only)
     16: ("potrf_diag128", "mfma"),               # 128 x 128 diagonal block of a batch (two tile Choleskys + its inverse)
+    17: ("potrf_panel256", "mfma"),              # the 128^3 products of a 256-column panel, one workgroup per problem (round 4)
     6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
     7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
     1: ("potrf_step<false>", "mfma"),       # tile Cholesky + inverse (latency-bound, B workgroups)

@@ -31,6 +31,7 @@
 #include "misc_kernels.hpp"
 #include "potrf_step.hpp"
 #include "potrf_persist.hpp"
+#include "potrf_panel256.hpp"
 #include "sweep.hpp"
 #include "swe_assemble.hpp"
 #include "fem_assemble_p2.hpp"
@@ -206,6 +207,7 @@ struct gmrf_handle {
     int cu_count = 0;
     unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zeroed by a memset node ahead of each)
     int64_t pflags_words = 0;
+    bool gemm128 = true;               // batches: the 128^3 products of a 256-column panel as GEMM launches (default); false (set_eager bit 14): potrf_panel256, measured slower
     bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
@@ -805,6 +807,7 @@ static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* 
     HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)words * (size_t)h->B, h->stream));
     PersistArgs pa;
     pa.S = S; pa.L = L; pa.X = X; pa.ld = h->bsp; pa.nt = nt; pa.j0 = j0; pa.j1 = j1; pa.xrows = xrows;
+    pa.tail_panel = (!xrows && j1 < nt) ? 1 : 0;
     pa.info = h->d_info; pa.blk = blk_id;
     pa.pS = h->bsp * h->bsp; pa.pL = stride_pL(h); pa.pX = stride_pX(h); pa.blk_per_problem = (int)h->N;
     pa.flags = h->d_pflags; pa.flag_stride = words;
@@ -944,17 +947,37 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         for (int j = 0; j < nt; j += 4) {
             const int64_t oa = (int64_t)j * 64, ob = oa + 128, oc = oa + 256;
             GCHK(diag128(j));
-            // L_BA = S_BA X_A^T (X_A lower triangular, stored [n][k]);  S_BB -= L_BA L_BA^T (lower tiles)
-            GCHK(gemm(h, false, false, 128, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + ob * ld + oa, ld,
-                      sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * 2.0 * nb));
-            GCHK(gemm(h, false, false, 128, 128, 128, 0, 1, -1.0, L + ob * ld + oa, ld, L + ob * ld + oa, ld, 1.0, S + ob * ld + ob, ld,
-                      sa.pL, sa.pL, sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * 3.0 * nb));
+            // The four 128^3 products of the panel -- L_BA = S_BA X_A^T, S_BB -= L_BA L_BA^T before the second diagonal block,
+            // X_BA = -X_B (L_BA X_A) after it -- are four GEMM launches of 256 workgroups (13 % of a step's GEMM time at 20.7 TF/s).
+            // Round 4 built the alternative, ONE workgroup per problem in two launches (potrf_panel256.hpp, set_eager bit 14):
+            // bitwise the same results, the time-weighted GEMM fraction rises to 0.66 -- and the job is SLOWER (45.6 k against
+            // 48.1 k solves/s in one gpurun call: twelve dependent 64^3 products take one CU 57 us, the four launches 39 us).
+            Panel256Args pp;
+            pp.S = S; pp.L = L; pp.X = X; pp.ld = ld; pp.j = j; pp.pS = sa.pS; pp.pL = sa.pL; pp.pX = sa.pX;
+            pp.Lba = L + ob * ld + oa; pp.ldl = ld; pp.pLba = sa.pL;
+            if (!h->gemm128) {
+                ProfScope ps(h, 17, (2.0 * t3 * 3.0 * 2.0 + 2.0 * t3 * 2.0 * 3.0) * nb);
+                hipLaunchKernelGGL(potrf_panel256<0>, dim3(1, (unsigned)h->B), dim3(256), PANEL256_LDS, h->stream, pp);
+                HIPCHK(hipGetLastError());
+            } else {
+                // L_BA = S_BA X_A^T (X_A lower triangular, stored [n][k]);  S_BB -= L_BA L_BA^T (lower tiles)
+                GCHK(gemm(h, false, false, 128, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + ob * ld + oa, ld,
+                          sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * 2.0 * nb));
+                GCHK(gemm(h, false, false, 128, 128, 128, 0, 1, -1.0, L + ob * ld + oa, ld, L + ob * ld + oa, ld, 1.0, S + ob * ld + ob, ld,
+                          sa.pL, sa.pL, sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * 3.0 * nb));
+            }
             GCHK(diag128(j + 2));
             // X_BA = -X_B (L_BA X_A): the level-128 doubling step of this pair (T is the work block doubling_levels uses)
-            GCHK(gemm(h, false, true, 128, 128, 128, TRI_B_LOWER, 0, 1.0, L + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, T + ob * ld + oa, ld,
-                      sa.pL, sa.pX, pW));
-            GCHK(gemm(h, false, true, 128, 128, 128, TRI_A_LOWER, 0, -1.0, X + ob * ld + ob, ld, T + ob * ld + oa, ld, 0.0, X + ob * ld + oa, ld,
-                      sa.pX, pW, sa.pX));
+            if (!h->gemm128) {
+                ProfScope ps(h, 17, 2.0 * (2.0 * 128.0 * 128.0 * 128.0 * 0.75) * nb);
+                hipLaunchKernelGGL(potrf_panel256<1>, dim3(1, (unsigned)h->B), dim3(256), PANEL256_LDS, h->stream, pp);
+                HIPCHK(hipGetLastError());
+            } else {
+                GCHK(gemm(h, false, true, 128, 128, 128, TRI_B_LOWER, 0, 1.0, L + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, T + ob * ld + oa, ld,
+                          sa.pL, sa.pX, pW));
+                GCHK(gemm(h, false, true, 128, 128, 128, TRI_A_LOWER, 0, -1.0, X + ob * ld + ob, ld, T + ob * ld + oa, ld, 0.0, X + ob * ld + oa, ld,
+                          sa.pX, pW, sa.pX));
+            }
             const int m3 = nt - j - 4;                             // row tiles below the panel
             if (m3 <= 0) continue;
             // Split representation with p = the panel width and no L blocks kept: L[p:, 0:p] is read by this panel's own
@@ -997,8 +1020,8 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         const double f_upd = 2.0 * 64.0 * 64.0 * 64.0 * utiles * nb;
         if (fused_in_panel && !h->no_lookahead && !overlap && j % pw == 0 && cend - j >= 2 && persist_fits(h, nt, j, cend, 0)) {
             // One problem, larger blocks: the panel's column tiles [j, cend) as ONE persistent launch (potrf_persist.hpp): the
-            // look-ahead chain over the panel's own columns; the last column's rows below (potrf_panel) and the rank-256
-            // update of the rest of the block (GEMM) follow as before
+            // look-ahead chain over the panel's own columns, the last column's rows below included (the launch's last-column
+            // workgroups form them: `tail_panel`); the rank-256 update of the rest of the block (GEMM) follows as before
             const int npc = cend - j;
             double fl = 64.0 * 64.0 * 64.0 / 3.0 * npc;
             for (int jj = j; jj + 1 < cend; ++jj) {
@@ -1006,14 +1029,10 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                 for (int c = jj + 1; c < cend; ++c) ut += nt - c;
                 fl += 64.0 * (nt - jj - 1) * 64.0 * 64.0 + 2.0 * 64.0 * 64.0 * 64.0 * ut;
             }
+            fl += 64.0 * (nt - cend) * 64.0 * 64.0;          // (the last column's rows below the panel: formed inside the launch too)
             GCHK(launch_persist(h, S, L, X, nt, j, cend, 0, blk_id, fl));
-            j = cend - 1;                                     // the loop continues with the panel's last column
+            j = cend - 1;                                     // the loop continues behind the panel's last column
             sa.j = j;
-            const int ml = nt - j - 1;
-            if (ml > 0) {
-                ProfScope ps(h, 8, 64.0 * ml * 64.0 * 64.0);
-                hipLaunchKernelGGL(potrf_panel, dim3(ml, 1), dim3(256), 0, h->stream, sa);
-            }
         } else if (fused || m == 0) {
             // one problem, fused steps: the tiles of row j - 1 of the inverse ride in the launch of step j (4 workgroups
             // per tile on CUs the step leaves idle; see xrow_strip), the last row gets a launch of its own below
@@ -1560,6 +1579,9 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_PERSIST_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_panel256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL256_LDS));
+    HIPCHK(hipFuncSetAttribute((const void*)potrf_panel256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL256_LDS));
+    { const char* e = getenv("GMRF_GEMM128"); if (e && atoi(e) == 0) h->gemm128 = false; }      // tuning aid: potrf_panel256 instead of the 128^3 GEMM launches
     HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
     { const char* e = getenv("GMRF_PERSIST"); if (e && atoi(e) == 0) h->no_persist = true; }      // tuning aid
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128_slim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1637,6 +1659,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 2048) != 0) != h->panels128) { destroy_graphs(h); h->panels128 = (eager & 2048) != 0; }
     if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
     if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
+    if (((eager & 16384) == 0) != h->gemm128) { destroy_graphs(h); h->gemm128 = (eager & 16384) == 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -3618,10 +3641,14 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
             GCHK(gemm(h, false, true, wc, bsp, wc, 0, 0, 1.0, V1, ld, X + (int64_t)cm * ld, ld, 1.0, Y + (int64_t)cm * ld, ld, pW, pX, pW,
                       1, 0, 0, 0, X + (int64_t)cm * ld, ld, pX, 0, -1.0, nullptr, h->d_kbx, nullptr));
         }
-        // diag(S_ii)
-        hipLaunchKernelGGL(coldot_lower, dim3((unsigned)nt, nb), dim3(256), 0, h->stream, X, coupled ? Y : nullptr, ld, bsp, cm, (int)h->bs,
-                           d_out + i * h->bs, pX, pW, h->n);
-        HIPCHK(hipGetLastError());
+        // diag(S_ii): of the last block processed (i = 0) and of the columns >= rmax by column dot products; the columns below
+        // rmax of the other blocks are the diagonal of the leading block formed below (saves reading X and Y once more)
+        const int u0 = (i == 0) ? 0 : trm;
+        if (u0 < nt) {
+            hipLaunchKernelGGL(coldot_lower, dim3((unsigned)(nt - u0), nb), dim3(256), 0, h->stream, X, coupled ? Y : nullptr, ld, bsp, cm, (int)h->bs,
+                               d_out + i * h->bs, pX, pW, h->n, u0);
+            HIPCHK(hipGetLastError());
+        }
         if (i == 0) break;                               // nobody needs the leading block of S_00
         // leading block of S_ii for the next step: rows 0 .. rmax of X^T, then the product on its lower tiles, mirrored
         {
@@ -3640,6 +3667,12 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
         }
         hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(trm * (trm + 1) / 2), nb), dim3(256), 0, h->stream, Sn, ld, Sn, ld, pW, pW, trm, trm, 2);
         HIPCHK(hipGetLastError());
+        {
+            const int cnt = (int)std::min<int64_t>(rm, h->bs);
+            hipLaunchKernelGGL(extract_diag_dense, dim3((unsigned)((cnt + 255) / 256), nb), dim3(256), 0, h->stream, Sn, ld, cnt,
+                               d_out + i * h->bs, bstride, h->n);
+            HIPCHK(hipGetLastError());
+        }
         std::swap(Sg, Sn);
     }
     return GMRF_OK;

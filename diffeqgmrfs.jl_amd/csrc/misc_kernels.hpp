@@ -1019,9 +1019,9 @@ __global__ __launch_bounds__(256) void transpose_tiles(const double* __restrict_
 // a workgroup owns 64 columns (a lane a column: rows are read as whole 512-byte lines), its four waves split the
 // rows from the column block's diagonal down, fixed summation order (rows ascending per wave, waves 0 .. 3).
 __global__ __launch_bounds__(256) void coldot_lower(const double* __restrict__ X, const double* __restrict__ Y, int64_t ld, int bsp,
-                                                    int cm, int bs, double* __restrict__ out, int64_t pX, int64_t pY, int64_t pout) {
+                                                    int cm, int bs, double* __restrict__ out, int64_t pX, int64_t pY, int64_t pout, int u0) {
     __shared__ double part[4][64];
-    const int u = (int)blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int u = u0 + (int)blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;      // column tiles u0 .. only
     const int n = 64 * u + lane;
     const double* x = X + (int64_t)blockIdx.y * pX;
     const double* y = Y ? Y + (int64_t)blockIdx.y * pY : nullptr;

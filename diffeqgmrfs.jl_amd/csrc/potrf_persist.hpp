@@ -43,6 +43,7 @@ struct PersistArgs {
     int nt;                 // tiles per dimension of the block
     int j0, j1;             // column tiles [j0, j1) of this launch (blocks of up to 16 tiles: 0, nt)
     int xrows;              // 1: the rows of the block inverse are assembled here too (j0 = 0, j1 = nt)
+    int tail_panel;         // 1 (larger blocks): the workgroups of the last column also form L[r, j1-1] for the rows below the panel
     int* info; int blk;
     int64_t pS, pL, pX; int blk_per_problem;
     unsigned* flags;        // [problems][flag_stride]; zeroed by a memset node ahead of the launch
@@ -102,12 +103,13 @@ __device__ __forceinline__ bool wg_wait(const unsigned* a, const unsigned* b, co
                                         lds_word* okw, int& phase, int tid) {
     lds_word* w = okw + (phase & 1);
     ++phase;
-    if (tid == 0) {
+    if (tid < 64) {
+        // lanes 0, 1, 2 of wave 0 poll one flag each, side by side (three round trips to the fabric in the time of one)
+        const unsigned* f = tid == 0 ? a : (tid == 1 ? b : (tid == 2 ? c : nullptr));
         bool ok = true;
-        if (a) ok = spin_until(a, pa.abort_word, pa.spin_limit);
-        if (ok && b) ok = spin_until(b, pa.abort_word, pa.spin_limit);
-        if (ok && c) ok = spin_until(c, pa.abort_word, pa.spin_limit);
-        *w = ok ? 1 : 0;
+        if (f) ok = spin_until(f, pa.abort_word, pa.spin_limit);
+        const bool all_ok = __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+        if (tid == 0) *w = all_ok ? 1 : 0;
     }
     __syncthreads();
     return *w != 0;
@@ -233,16 +235,21 @@ __device__ __forceinline__ void diag_update_balanced_w(int w, const double* Ls, 
 //   a0        store L[j+1, j] (in As since the last product): 628 cycles of store issue off the chain;
 //   b(kb)     at the START of their part of panels 1 .. 3 (their own deferred work there is short), never waiting for a flag:
 //             one relaxed look at the two flags of the NEXT step's operands; once both are up, this wave's half of
-//             S'[j+2, j+1] -> As in the same panel and its half of tile (j+2, j+2) -> Bs in the next one, then `tag` into its
-//             LDS word.  The chain takes the prefetched operands only if both words carry the step's tag after the
-//             factorisation, otherwise it waits and loads as before (1 450 + 2 400 cycles a step).
+//             S'[j+2, j+1] -> As in the same panel and its half of tile (j+2, j+2) -> Bs in the next one (the last panel: both),
+//             then `tag` into its LDS words.  The chain takes a prefetched operand only if both waves' words for it carry
+//             the step's tag after the factorisation; what is missing it waits for and loads as before (1 450 + 2 400 cycles
+//             a step when it has to do both).
+// (Measured against this, one gpurun call each: loads issued in b() and moved to LDS after the wave's deferred work, flag looks
+//  issued one call ahead -- nothing blocks, but an operand then needs two more panels after its flags are seen and every second
+//  step fell back: 36.0 k cycles per step against 34.3 k; the tile stores drained behind the next product instead of X_jj
+//  flagged at once: the workers start 3 500 cycles later and the prefetch misses every second step: 34.3 k against 33.6 k.)
 struct ChainSide {
     const double* sL; double* gL;             // LDS tile -> global (nullptr: nothing to store)
     const unsigned* f1; const unsigned* f2;   // flags the prefetch needs (nullptr: none)
     const double* gA; double* sA;             // nullptr: no next step
     const double* gN; double* sN;
     int64_t ld;
-    lds_word* done;                           // LDS: [0] wave 1, [1] wave 2
+    lds_word* done;                           // LDS: [0], [1] As halves of waves 1, 2;  [2], [3] Bs halves
     int tag;
     int state;                                // per wave: 0 flags not seen, 1 As half loaded, 2 both halves loaded
     unsigned long long* stamps;
@@ -274,7 +281,7 @@ struct ChainSide {
             }
         }
     }
-    __device__ __forceinline__ void b(int, int tid) {
+    __device__ __forceinline__ void b(int kb, int tid) {
         if (!gA || tid >= 192 || state >= 2) return;
         const int half = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, lane = tid & 63;
         if (state == 0) {
@@ -284,11 +291,12 @@ struct ChainSide {
             if (!__builtin_amdgcn_readfirstlane(ok)) return;
             half_load(gA, sA, half, lane);
             state = 1;
-            return;
+            if (lane == 0) done[half] = tag;
+            if (kb < 3) return;                          // (the last panel: no later call -- both halves now)
         }
         half_load(gN, sN, half, lane);
         state = 2;
-        if (lane == 0) done[half] = tag;
+        if (lane == 0) done[2 + half] = tag;
     }
     __device__ __forceinline__ void ak(int, int) const {}
 };
@@ -303,8 +311,8 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
-    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
-    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* Wk = Xs + TILE_ELEMS;               // WK_ELEMS
+    double* rinvs = Wk + WK_ELEMS;           // 64
     double* As = rinvs + 64;
     double* Bs = As + TILE_ELEMS;
     lds_word* okw = (lds_word*)reinterpret_cast<int*>(Bs + TILE_ELEMS);
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
     if (blockIdx.x == 0) {
         // ------------------------------------------------------------------ the chain
         lds_word* done = okw + 2;
-        if (tid == 0) { done[0] = 0; done[1] = 0; }
+        if (tid < 4) done[tid] = 0;
         ChainSide cs;
         cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
         auto prefetch_for = [&](int jn) {                    // operands of step jn (tile jn + 1) -> cs, or none past the last step
@@ -348,19 +356,20 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
         __syncthreads();
         tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
         if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
-        tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
         tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
-        // The write-through stores of L_jj / X_jj drain BEHIND the next step's first product (1 500 cycles off the chain): the
-        // flags `pend1` / `pend2` go up at that step's first barrier, after every wave's vmcnt(0).  (The step's prefetch words
-        // were written before tile_potrf_inv's last barrier.)
-        unsigned* pend1 = fD + pa.j0;
+        wg_publish(fD + pa.j0, nullptr, tid);
+        tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
+        // The write-through stores of L_jj drain BEHIND the next step's first product: whatever `pend1` / `pend2` name goes up at
+        // that step's first barrier, after every wave's vmcnt(0).  (The step's prefetch words were written before
+        // tile_potrf_inv's last barrier.)
+        unsigned* pend1 = nullptr;
         unsigned* pend2 = nullptr;
         if (pa.stamps && tid == 0) pa.stamps[0] = __builtin_amdgcn_s_memtime();
         for (int j = pa.j0; j + 1 < pa.j1; ++j) {
             const int64_t oj = (int64_t)j * 64, o1 = oj + 64;
             // (the publish above was a barrier: the two words are what waves 1, 2 left during the last factorisation)
-            const bool pre = done[0] == j + 1 && done[1] == j + 1;
-            if (pre) {
+            const bool pre_a = done[0] == j + 1 && done[1] == j + 1, pre_n = done[2] == j + 1 && done[3] == j + 1;
+            if (pre_a && pre_n) {
                 if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
             } else {
                 wg_publish(pend1, pend2, tid);              // (nothing stays unpublished across a wait)
@@ -369,8 +378,8 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
                 const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
                 if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
                 if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
-                tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
-                tile_g2s_sc1(pa.S + o1 * ld + o1, ld, Bs, tid);
+                if (!pre_a) tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
+                if (!pre_n) tile_g2s_sc1(pa.S + o1 * ld + o1, ld, Bs, tid);
                 __syncthreads();
             }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 2] = __builtin_amdgcn_s_memtime();
@@ -414,9 +423,12 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
             tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
             if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
-            tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
+            // X_{j+1,j+1} is what every workgroup of the next step waits for: stored, drained and flagged at once; L_{j+1,j+1}
+            // (read by nobody inside the launch) and the flag of L[j+1, j] drain behind the next step's first product
             tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
-            pend1 = fD + j + 1; pend2 = fPL + (j + 1) * nt + j;
+            wg_publish(fD + j + 1, nullptr, tid);
+            tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
+            pend1 = fPL + (j + 1) * nt + j; pend2 = nullptr;
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();
         }
         wg_publish(pend1, pend2, tid);
@@ -495,6 +507,36 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
         } else {
             __syncthreads();                               // As / Bs are re-filled by the next step
         }
+    }
+    if (pa.tail_panel && c == pa.j1 - 1 && r > c) {
+        // Larger blocks, the panel's last column: L[r, c] = S'[r, c] X_cc^T for the rows below the panel, here instead of in a
+        // potrf_panel launch of its own (8 192 launches of a C5 factorisation).  The final tile waits in registers.
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, cpre[Jb], li, lq);
+        if (!wg_wait(fD + c, nullptr, nullptr, pa, okw, phase, tid)) return;
+        const int64_t oc = (int64_t)c * 64;
+        tile_g2s_sc1(pa.X + oc * ld + oc, ld, Xs, tid);
+        __syncthreads();
+        v4d lr[4];
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb) lr[Jb] = zero;
+#pragma unroll
+        for (int kg = 0; kg < 8; ++kg) {
+            const int k = 8 * kg + 2 * lq;
+            const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+#pragma unroll
+            for (int Jb = kg / 2; Jb < 4; ++Jb) {
+                const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+                lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+                lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+            }
+        }
+        double* Lg = pa.L + (int64_t)r * 64 * ld + oc;
+#pragma unroll
+        for (int Jb = 0; Jb < 4; ++Jb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Lg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = lr[Jb][q];
+        return;
     }
     if (!pa.xrows || r == c) return;
 

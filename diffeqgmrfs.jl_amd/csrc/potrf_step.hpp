@@ -38,6 +38,12 @@ constexpr int TLD = GMRF_TLD;           // LDS row stride (doubles) of a 64x64 t
                                         // (68 = 8 mod 64 put rows r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT was
                                         // 0.34 of the tile kernel's LDS-active cycles)
 constexpr int TILE_ELEMS = 64 * TLD;
+// scratch of the tile factorisation: TWO copies (panels alternate) of {the panel's 16 columns, one row of the tile per lane:
+// lcol[jj * 64 + row]; the 16 reciprocal pivots rv[jj]} -- the second copy lets a follower wave read panel 3 while it is being
+// written (inv16_follow) after that copy's rv slots were cleared during panel 2; the 16 x 18 strips of the inverse assembly's
+// tail (Wm, waves 0 .. 2) lie in the first copy, which the last panel no longer uses
+constexpr int LCOL_ELEMS = 16 * 64 + 16;
+constexpr int WK_ELEMS = 2 * LCOL_ELEMS;
 
 __device__ __forceinline__ double bcast_lane(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -248,9 +254,10 @@ __device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double
         __builtin_amdgcn_sched_barrier(0);
         GMRF_DELAYED_SLOT(3)
         const double l = a[jj] * rinv;       // lane j: p * rinv = sqrt(p)
-        rv[jj] = rinv;                       // same value from every lane: no branch
         a[jj] = l;
         lcol[jj * 64 + r] = l;
+        asm volatile("" ::: "memory");       // (the column BEFORE its reciprocal pivot: a wave's LDS stores land in order, and
+        rv[jj] = rinv;                       //  inv16_follow takes a non-zero rv[jj] as "column jj is there"); same value from every lane: no branch
         __builtin_amdgcn_sched_barrier(0);
         GMRF_DELAYED_SLOT(0)                 // includes column jj + 1, needed by the update below
         if (jj < 15) {
@@ -328,6 +335,43 @@ __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, dou
     GMRF_INV16_STEP(8) GMRF_INV16_STEP(9) GMRF_INV16_STEP(10) GMRF_INV16_STEP(11)
     GMRF_INV16_STEP(12) GMRF_INV16_STEP(13) GMRF_INV16_STEP(14) GMRF_INV16_STEP(15)
 #undef GMRF_INV16_STEP
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
+}
+
+// inv16 for the LAST diagonal block, run by another wave WHILE wave 0 still factors the panel (c0 = 48): step k needs column k of
+// the block and its reciprocal pivot, which panel_factor16 leaves in the panel scratch as it goes (lcol[k * 64 + row], then
+// rv[k]); this wave waits for rv[k] to turn non-zero (the slots were cleared one panel earlier), reads the column and does the
+// step of inv16 -- the same operations on the same values, so the same X_33 bitwise -- and is done a step after wave 0 instead of
+// 2 900 cycles after the panel (the call used to open the tile's tail, on the critical path of every tile).
+__device__ __forceinline__ void inv16_follow(const double* lcol_in, double* Xs, int c0, int lane) {
+    typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+    lds_cvd* lcol = (lds_cvd*)lcol_in;
+    lds_cvd* rvp = lcol + 16 * 64;
+    const int c = lane >> 2, q = lane & 3;
+    double x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = (4 * i + q == c) ? 1.0 : 0.0;
+#define GMRF_INV16F_STEP(K)                                                                       \
+    {                                                                                              \
+        constexpr int ik = (K) / 4, qk = (K) % 4;                                                  \
+        double rk = rvp[K];                                                                        \
+        while (rk == 0.0) { __builtin_amdgcn_s_sleep(1); rk = rvp[K]; }                            \
+        double lvk[4];                                                                             \
+        _Pragma("unroll") for (int i = ik; i < 4; ++i) {                                           \
+            const double v = lcol[(K) * 64 + c0 + 4 * i + q];                                      \
+            lvk[i] = (4 * i + q > (K)) ? v : 0.0;                                                  \
+        }                                                                                          \
+        const double xs = x[ik] * rk;                                                              \
+        if (q == qk) x[ik] = xs;                                                                   \
+        const double xk = quad_bcast<qk>(x[ik]);                                                   \
+        _Pragma("unroll") for (int i = ik; i < 4; ++i) x[i] = fma(-lvk[i], xk, x[i]);             \
+    }
+    GMRF_INV16F_STEP(0) GMRF_INV16F_STEP(1) GMRF_INV16F_STEP(2) GMRF_INV16F_STEP(3)
+    GMRF_INV16F_STEP(4) GMRF_INV16F_STEP(5) GMRF_INV16F_STEP(6) GMRF_INV16F_STEP(7)
+    GMRF_INV16F_STEP(8) GMRF_INV16F_STEP(9) GMRF_INV16F_STEP(10) GMRF_INV16F_STEP(11)
+    GMRF_INV16F_STEP(12) GMRF_INV16F_STEP(13) GMRF_INV16F_STEP(14) GMRF_INV16F_STEP(15)
+#undef GMRF_INV16F_STEP
 #pragma unroll
     for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
 }
@@ -426,7 +470,7 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         const int c0 = 16 * kb;
         TILE_STAMP(1 + 3 * kb);
         if (wave == 0) {
-            panel_factor16(Ts, rinvs, Wk, c0, lane, bad, (side.stamps && kb == 0) ? side.stamps + 20 : nullptr);
+            panel_factor16(Ts, rinvs, Wk + (kb & 1) * LCOL_ELEMS, c0, lane, bad, (side.stamps && kb == 0) ? side.stamps + 20 : nullptr);
             TILE_STAMP(2 + 3 * kb);
         } else if (kb == 0) {
             side.a0(tid);
@@ -441,7 +485,10 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
             } else if (kb == 2) {
                 if (wave == 1) subtile_update(Ts, 3, 3, pc0, li, lq);
             }
-            if (wave == 3) inv16(Ts, rinvs, Xs, pc0, lane);
+            // diagonal inverse of the previous panel: wave 3 -- in the last panel wave 2 (after its one sum), because there wave 3
+            // follows wave 0 through the panel with the LAST diagonal inverse and must start with it
+            if (kb < 3 && wave == 3) inv16(Ts, rinvs, Xs, pc0, lane);
+            if (kb == 2 && wave == 2 && lane < 16) Wk[LCOL_ELEMS + 16 * 64 + lane] = 0.0;      // rv slots of the last panel's scratch (inv16_follow)
             if (kb == 3) {
                 // block row 1 and the sums of block row 2 (diagonal inverses 0 and 1 are final)
                 if (wave == 1) {
@@ -450,6 +497,10 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
                     store_d16(s30, TLD, sum_ij(2, 0), li, lq);
                 } else if (wave == 2) {
                     store_d16(s31, TLD, sum_ij(2, 1), li, lq);
+                    inv16(Ts, rinvs, Xs, pc0, lane);
+                } else if (wave == 3) {
+                    // the last diagonal inverse follows wave 0 through the last panel, a step behind (round 4; it used to open the tail)
+                    inv16_follow(Wk + LCOL_ELEMS, Xs, 48, lane);
                 }
             }
             side.ak(kb, tid);
@@ -465,31 +516,27 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
     }
     TILE_STAMP(13);
     double* Wm = Wk + wave * 16 * 18;
-    // after the last panel, no barrier until the last diagonal inverse is there: wave 3 inverts it; wave 1 finishes
-    // X[2][0] and sums column 0 of block row 3 (it wrote X[1][0], X[2][0] itself), wave 2 the same for column 1,
-    // wave 0 zeroes the strict upper triangles of the diagonal blocks (don't-care values above a panel's diagonal)
-    // and sums column 2 (needs X[2][2] only).  Then one product with X[3][3] per wave.
-    int J3 = -1;
+    // after the last panel every diagonal inverse is there (the last one followed the panel: inv16_follow): wave 1 finishes
+    // X[2][0] and forms column 0 of block row 3 (it wrote X[1][0], X[2][0] itself), wave 2 the same for column 1, wave 0 column 2
+    // (needs X[2][2] only) -- sum, then at once the product with X[3][3] -- and wave 3 zeroes the strict upper triangles of the
+    // diagonal blocks of L (don't-care values above a panel's diagonal).  One barrier.
     if (wave == 3) {
-        inv16(Ts, rinvs, Xs, 48, lane);
+        for (int i = lane; i < 4 * 256; i += 64) {
+            const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
+            if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
+        }
     } else {
-        if (wave == 0) {
-            for (int i = lane; i < 4 * 256; i += 64) {
-                const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
-                if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
-            }
-            J3 = 2;
-        } else if (wave == 1) {
+        int J3 = 2;
+        if (wave == 1) {
             finish_ij(2, 0, s30, TLD);
             J3 = 0;
-        } else {
+        } else if (wave == 2) {
             finish_ij(2, 1, s31, TLD);
             J3 = 1;
         }
         store_d16(Wm, 18, sum_ij(3, J3), li, lq);
+        finish_ij(3, J3, Wm, 18);
     }
-    __syncthreads();
-    if (wave < 3) finish_ij(3, J3, Wm, 18);
     __syncthreads();
     TILE_STAMP(14);
 }
@@ -603,8 +650,8 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
     double* Xs = Ts + TILE_ELEMS;
     // the tile-only launch (grid.x = 1) allocates up to here only (POTRF_TILE_LDS): with 75 KB instead
     // of 144 KB a GEMM workgroup of another stream still fits on the CU beside it
-    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
-    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* Wk = Xs + TILE_ELEMS;               // WK_ELEMS
+    double* rinvs = Wk + WK_ELEMS;           // 64
     double* As = rinvs + 64;                    // fused form only: the two panel tiles
     double* Bs = As + TILE_ELEMS;
 
@@ -979,8 +1026,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
     double* As = Xs + TILE_ELEMS;
-    double* Wk = As + TILE_ELEMS;               // 4 * 16 * 18
-    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* Wk = As + TILE_ELEMS;               // WK_ELEMS
+    double* rinvs = Wk + WK_ELEMS;           // 64
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
@@ -1054,7 +1101,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) sa.X[(o1 + 16 * wave + lq + 4 * q) * ld + o0 + 16 * Jb + li] = -xr[Jb][q];
 }
-constexpr size_t POTRF_DIAG128_LDS = (3 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+constexpr size_t POTRF_DIAG128_LDS = (3 * TILE_ELEMS + WK_ELEMS + 64) * sizeof(double);
 
 // The same block with TWO LDS tiles (77 KB: two GEMM workgroups of another stream fit beside it instead of one): S10 goes
 // straight from L2 into registers as the MFMA A operand of L10 = S10 X00^T (as potrf_panel did), L10 takes the place of
@@ -1068,8 +1115,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
-    double* Wk = Xs + TILE_ELEMS;               // 4 * 16 * 18
-    double* rinvs = Wk + 4 * 16 * 18;           // 64
+    double* Wk = Xs + TILE_ELEMS;               // WK_ELEMS
+    double* rinvs = Wk + WK_ELEMS;           // 64
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
@@ -1146,10 +1193,10 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) sa.X[(o1 + 16 * wave + lq + 4 * q) * ld + o0 + 16 * Jb + li] = -xr[Jb][q];
 }
-constexpr size_t POTRF_DIAG128_SLIM_LDS = (2 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+constexpr size_t POTRF_DIAG128_SLIM_LDS = (2 * TILE_ELEMS + WK_ELEMS + 64) * sizeof(double);
 
 
-constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+constexpr size_t POTRF_STEP_LDS = (4 * TILE_ELEMS + WK_ELEMS + 64) * sizeof(double);
 
 // Stand-alone tile kernel (tests): S (ld 64) -> L, X.
 __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(const double* S, double* L, double* X, int* info,
@@ -1158,7 +1205,7 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(const double* S, dou
     double* Ts = smem;
     double* Xs = Ts + TILE_ELEMS;
     double* Wk = Xs + TILE_ELEMS;
-    double* rinvs = Wk + 4 * 16 * 18;
+    double* rinvs = Wk + WK_ELEMS;
     const int tid = threadIdx.x;
     tile_g2s(S, 64, Ts, tid);
     __syncthreads();
@@ -1172,6 +1219,6 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(const double* S, dou
     tile_s2g(Xs, X, 64, tid);
     if (stamps && tid == 0) stamps[16] = __builtin_amdgcn_s_memtime();
 }
-constexpr size_t POTRF_TILE_LDS = (2 * TILE_ELEMS + 4 * 16 * 18 + 64) * sizeof(double);
+constexpr size_t POTRF_TILE_LDS = (2 * TILE_ELEMS + WK_ELEMS + 64) * sizeof(double);
 
 }  // namespace gmrf

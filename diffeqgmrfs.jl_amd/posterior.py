@@ -217,7 +217,16 @@ class HipGatherEngine(HipEngine):
             self._all[key] = t.empty((self.batch, seg), dtype=t.float64, device=self.dev)
         own, allb = self._own[key], self._all[key]
         self.F.pack_blocks_async(i0, i1, own)
-        self._pending.append((dist.all_gather_into_tensor(allb, own, async_op=True), i0, i1, allb))
+        if dist.get_backend() == "nccl":
+            self._pending.append((dist.all_gather_into_tensor(allb, own, async_op=True), i0, i1, allb))
+        else:
+            # gloo has no all-gather of device tensors (rehearsals on one GPU): every rank broadcasts its share into its slot
+            b = self.share_batch
+            allb[self.rank * b:(self.rank + 1) * b].copy_(own)
+            hs = [dist.broadcast(allb[r * b:(r + 1) * b], src=r, async_op=True) for r in range(self.world)]
+            for h in hs[:-1]:
+                self._pending.append((h, None, None, None))
+            self._pending.append((hs[-1], i0, i1, allb))
         self.bytes_moved += (allb.numel() - own.numel()) * 8
 
     def share_finish(self, is_root: bool = True):
@@ -226,7 +235,8 @@ class HipGatherEngine(HipEngine):
             return
         for hnd, i0, i1, allb in self._pending:
             hnd.wait()
-            self.F_all.unpack_blocks_async(i0, i1, allb)
+            if allb is not None:
+                self.F_all.unpack_blocks_async(i0, i1, allb)
         self._pending = []
 
     def mean(self):

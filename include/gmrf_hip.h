@@ -84,7 +84,8 @@ typedef struct {
      * 10 spmm_bxt (sparse C = B X^T)          13 gemm_f64_ll (32 x 32 tile GEMM of small launches)
      * 14 / 15 gemm_f64_dma<.., B [n][k]> / <.., B [k][n]> (LDS-DMA staged GEMM: the batches' products since round 3)
      * 16 potrf_diag128 (128 x 128 diagonal block of a batch: two tile Choleskys + the block's inverse)
-     * work = algorithmic flops (0-2, 6-9, 11-16) or algorithmic bytes (3-5, 10). */
+     * 17 potrf_panel256 (the 128^3 products of a 256-column panel of a batch, one workgroup per problem: round 4)
+     * work = algorithmic flops (0-2, 6-9, 11-17) or algorithmic bytes (3-5, 10). */
 #define GMRF_KERNEL_CLASSES 24
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];

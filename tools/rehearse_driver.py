@@ -50,6 +50,18 @@ try:
         # the packed transport image (lower-triangular tiles of Linv + C windows + log-determinant parts) is what moved
         c["logdet_travelled"] = bool(np.array_equal(r0["logdet"], r1["logdet"]) and np.all(np.isfinite(r1["logdet"])))
         c["packed_bytes_below_raw"] = bool(0 < float(r0["bytes"][0]) < 2 * 2 * 8.0 * (16 * 256 * 256 + 15 * 256 * 256))
+        # round 4, the all-gather form: each rank factored one of the two problems; same means / samples / log-determinants as the
+        # broadcast form (the factor of a problem does not depend on who made it), samples rank-invariant
+        # (to rounding, not bitwise: a share of ONE problem takes the one-problem kernels, the broadcast form's root factored the
+        #  batch of two; both ranks of the all-gather form hold bitwise the same gathered factors)
+        close = lambda a, b: bool(np.linalg.norm(a - b) <= 1e-9 * np.linalg.norm(b))
+        c["allgather_equal_across_ranks"] = bool(np.array_equal(r0["gmu1"], r1["gmu1"]) and np.array_equal(r0["glogdet"], r1["glogdet"]))
+        c["allgather_mean_equals_broadcast"] = close(r0["gmu1"], r0["mu1"])
+        c["allgather_samples_rank_invariant"] = bool(all(close(r[f"gX{st}"], s[f"X{st}_{k}"])
+                                                         for st in (0, 1) for k, r in ((0, r0), (1, r1))))
+        c["allgather_logdet"] = bool(np.allclose(r0["glogdet"], r0["logdet"], rtol=1e-12, atol=0))
+        c["allgather_moved_half"] = bool(0 < float(r0["gbytes"][0]) < float(r0["bytes"][0]))
+        c["allgather_solves_per_step"] = int(r0["gsolves"]) == 2 * (1 + 6 * 2)
         # RCCL through the C ABI, world of one: same job, rank 0 of a world of one at step 1 draws ids (1*1+0)*6*2 = 12.. = step 0 / rank 1 above
         c["cabi_mean"] = bool(np.array_equal(s["mu_cabi"], s["mu"]))
         c["cabi_samples"] = bool(np.array_equal(s["X_cabi"], s["X0_1"]))

@@ -44,6 +44,25 @@ for p in range(batch):                      # rank 1 adopted the factor without 
 out["logdet"] = np.array(lds)
 out["bytes"] = np.array([eng.transport_bytes()])
 out["layout"] = eng.F.get_layout()
+# Round 4: the all-gather form of the same batch -- every rank factors ONE of the two problems (HipGatherEngine), block ranges are
+# all-gathered (gloo moves the packed images through the host), both ranks take both means and draw their own sample ids
+eng.F.close()
+geng = post.HipGatherEngine(pkg, w, device_index=0, batch_total=batch, world=world, rank=rank, values_all=vals, rhs_all=rhs,
+                            keep_l=False, transport="torch")
+gjob = post.ShardedPosterior(geng, dist=dist, rank=rank, world=world, k_samples=6, seed=42, group=5, share="allgather")
+gjob.prepare()
+for step in range(2):
+    gmu, gX = gjob.step(step)
+    torch.cuda.synchronize()
+    out[f"gmu{step}"] = gmu.cpu().numpy()
+    out[f"gX{step}"] = gX.cpu().numpy()
+glds = []
+for p in range(batch):
+    geng.F_all.select_problem(p)
+    glds.append(geng.F_all.logdet())
+out["glogdet"] = np.array(glds)
+out["gbytes"] = np.array([geng.transport_bytes()])
+out["gsolves"] = gjob.solves_per_step()
 np.savez(os.path.join(outdir, f"r{rank}.npz"), **out)
 dist.barrier()
 dist.destroy_process_group()
