@@ -207,6 +207,7 @@ struct gmrf_handle {
     int cu_count = 0;
     unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zeroed by a memset node ahead of each)
     int64_t pflags_words = 0;
+    bool no_persist_panels = false;    // batches small enough for it keep potrf_diag128 + the 128^3 products instead of one persistent launch per panel (set_eager bit 15)
     bool gemm128 = true;               // batches: the 128^3 products of a 256-column panel as GEMM launches (default); false (set_eager bit 14): potrf_panel256, measured slower
     bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
@@ -795,9 +796,10 @@ static int planned_xsplit(const gmrf_handle* h) {
 // a memset node ahead of it (re-initialised on every graph replay).  false: this shape does not fit the chip (every workgroup
 // must be resident: 140 KB of LDS = one per CU) or the form is switched off.
 static bool persist_fits(const gmrf_handle* h, int nt, int j0, int j1, int xrows) {
-    if (h->no_persist || h->B != 1 || h->cu_count <= 0) return false;
+    if (h->no_persist || h->cu_count <= 0) return false;
     static const int margin = [] { const char* e = getenv("GMRF_PERSIST_CU_MARGIN"); return e ? atoi(e) : 0; }();   // tuning aid
-    return 1 + persist_tiles(nt, j0, j1, xrows) + margin <= h->cu_count;
+    // (a batch: every problem brings its own set of workgroups and flag words; all of them must fit the chip at once)
+    return (int64_t)(1 + persist_tiles(nt, j0, j1, xrows)) * h->B + margin <= h->cu_count;
 }
 
 static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* X, int nt, int j0, int j1, int xrows, int blk_id,
@@ -944,8 +946,19 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
             return GMRF_OK;
         }
+        // Small batches (round 4): 9 workgroups per problem fit the chip up to a batch of 28, and then the panel's whole
+        // 256 x 256 diagonal block -- two potrf_diag128 launches and the four 128^3 products -- is ONE persistent launch
+        // (potrf_persist on the 4 x 4 tiles of the block, inverse rows included): 55 us instead of ~109 us per panel, on
+        // 9 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
+        // the one-workgroup kernels: their chain hides behind the other problems, and 9 B workgroups of 140 KB would not fit.
+        static const bool no_small = [] { const char* e = getenv("GMRF_PERSIST_PANELS"); return e && atoi(e) == 0; }();   // tuning aid
+        const bool persist_panels = !no_small && !h->no_persist_panels && h->gemm128 && persist_fits(h, 4, 0, 4, 1);
         for (int j = 0; j < nt; j += 4) {
             const int64_t oa = (int64_t)j * 64, ob = oa + 128, oc = oa + 256;
+            if (persist_panels) {
+                const double fl = (4.0 * t3 / 3.0 + 2.0 * t3 * (6.0 * 0.625 + 10.0 + 10.0 + 6.0 * 0.625)) * nb;
+                GCHK(launch_persist(h, S + oa * ld + oa, L + oa * ld + oa, X + oa * ld + oa, 4, 0, 4, 1, blk_id, fl));
+            } else {
             GCHK(diag128(j));
             // The four 128^3 products of the panel -- L_BA = S_BA X_A^T, S_BB -= L_BA L_BA^T before the second diagonal block,
             // X_BA = -X_B (L_BA X_A) after it -- are four GEMM launches of 256 workgroups (13 % of a step's GEMM time at 20.7 TF/s).
@@ -977,6 +990,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                           sa.pL, sa.pX, pW));
                 GCHK(gemm(h, false, true, 128, 128, 128, TRI_A_LOWER, 0, -1.0, X + ob * ld + ob, ld, T + ob * ld + oa, ld, 0.0, X + ob * ld + oa, ld,
                           sa.pX, pW, sa.pX));
+            }
             }
             const int m3 = nt - j - 4;                             // row tiles below the panel
             if (m3 <= 0) continue;
@@ -1660,6 +1674,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
     if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
     if (((eager & 16384) == 0) != h->gemm128) { destroy_graphs(h); h->gemm128 = (eager & 16384) == 0; }
+    if (((eager & 32768) != 0) != h->no_persist_panels) { destroy_graphs(h); h->no_persist_panels = (eager & 32768) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -4038,7 +4053,9 @@ gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
 // then per step j four stamps (flags seen, operands in LDS, tile updated, tile j + 1 published), relative to the first, in cycles
 gmrf_status gmrf_test_persist_stamps(double* out, int32_t n) {
     if (!out || n < 1 || n > 128) return bad_shape("1 .. 128 outputs");
-    for (int i = 0; i < n; ++i) out[i] = g_persist_stamps[i] ? (double)(g_persist_stamps[i] - g_persist_stamps[0]) : -1.0;
+    // (slot 8 s + 5 holds a small number, not a time: the panel in which the next step's operands were seen ready)
+    for (int i = 0; i < n; ++i)
+        out[i] = g_persist_stamps[i] ? (g_persist_stamps[i] < 64 ? (double)g_persist_stamps[i] : (double)(g_persist_stamps[i] - g_persist_stamps[0])) : -1.0;
     return GMRF_OK;
 }
 

@@ -253,6 +253,7 @@ struct ChainSide {
     int tag;
     int state;                                // per wave: 0 flags not seen, 1 As half loaded, 2 both halves loaded
     unsigned long long* stamps;
+    unsigned long long* dbg;                  // diagnostic: the panel in which wave 1 saw the flags (tools/persist_stamps.py), else nullptr
     __device__ __forceinline__ void half_load(const double* g, double* s, int half, int lane) const {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
         v4u v[16];
@@ -292,6 +293,7 @@ struct ChainSide {
             half_load(gA, sA, half, lane);
             state = 1;
             if (lane == 0) done[half] = tag;
+            if (dbg && half == 0 && lane == 0) *dbg = (unsigned long long)kb;
             if (kb < 3) return;                          // (the last panel: no later call -- both halves now)
         }
         half_load(gN, sN, half, lane);
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
         lds_word* done = okw + 2;
         if (tid < 4) done[tid] = 0;
         ChainSide cs;
-        cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
+        cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.dbg = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
         auto prefetch_for = [&](int jn) {                    // operands of step jn (tile jn + 1) -> cs, or none past the last step
             cs.state = 0; cs.tag = jn + 1;
             if (jn + 1 < pa.j1) {
@@ -411,7 +413,6 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 4] = __builtin_amdgcn_s_memtime();
             // (L[j+1, j] leaves for global memory in the shadow of the first panel below: ChainSide::a0)
-            if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 5] = __builtin_amdgcn_s_memtime();
             // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
             // (the ten lower blocks dealt evenly over the waves; L_jj has left Ts: its stores were drained by wg_publish; the tile
             //  (j+1, j+1) waits in Bs, prefetched or just loaded)
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();
             cs.gL = pa.L + o1 * ld + oj;
             prefetch_for(j + 1);
+            cs.dbg = pa.stamps ? pa.stamps + 8 * (j - pa.j0) + 5 : nullptr;
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
             tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
@@ -456,10 +458,12 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
         const int64_t oj = (int64_t)j * 64;
         const unsigned* w1 = (s > 0) ? fF + r * nt + j : nullptr;
         const unsigned* w2 = (s > 0 && c != r) ? fF + c * nt + j : nullptr;
-        if (!wg_wait(fD + j, w1, w2, pa, okw, phase, tid)) return;
-        tile_g2s_sc1(pa.X + oj * ld + oj, ld, Xs, tid);
+        // the panel tiles of this step were final a step ago; X_jj is what arrives last: load them while waiting for it
+        if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
         tile_g2s_sc1(pa.S + (int64_t)r * 64 * ld + oj, ld, As, tid);
         if (c != r) tile_g2s_sc1(pa.S + (int64_t)c * 64 * ld + oj, ld, Bs, tid);
+        if (!wg_wait(fD + j, nullptr, nullptr, pa, okw, phase, tid)) return;
+        tile_g2s_sc1(pa.X + oj * ld + oj, ld, Xs, tid);
         __syncthreads();
         v4d lr[4], lc[4];
 #pragma unroll

@@ -57,6 +57,12 @@ class HipEngine:
         self.dev = torch.device("cuda", device_index)
         torch.cuda.set_device(self.dev)
         self.stream = torch.cuda.current_stream(self.dev)
+        if self.stream.cuda_stream == 0:
+            # On the legacy default stream the library would give the handle a stream of its OWN (gmrf_bt_create: stream 0 =
+            # none given), and the torch work of this engine (copies, collectives on packed images) would not be ordered with
+            # the handle's launches: the engine takes a stream of its own and makes it the thread's current stream.
+            self.stream = torch.cuda.Stream(self.dev)
+            torch.cuda.set_stream(self.stream)
         self.F = pkg.TridiagonalCholeskyFactor(device=device_index, stream=self.stream.cuda_stream, batch=batch)
         if not keep_l:
             self.F.set_keep_l(False)

@@ -639,24 +639,32 @@ def test_two_level_panel_factor_of_batches(pkg):
     Fr.select_problem(0)
     assert 0 < np.max(np.abs(Fr.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
     assert rel(Fr.solve_batch(rhs[:, None, :])[0, 0], O.ldiv(Fo, w.rhs)) < solve_tol(w)
-    # round 4, opt-in (set_eager bit 14; measured slower, see potrf_block): the 128^3 products of a 256-column panel by one
-    # workgroup per problem (potrf_panel256) instead of four GEMM launches: same factor and inverse (measured: bitwise -- both
-    # routes sum every product in the same k order, from zero, one subtraction), same oracle tolerance; each route launches
-    # its own kernels and none of the other's
+    # round 4: a batch this small (9 workgroups per problem fit the chip) factors the 256 x 256 diagonal block of every panel in
+    # ONE persistent launch (potrf_persist on the block's 4 x 4 tiles) instead of two potrf_diag128 launches and four 128^3
+    # GEMMs; set_eager bit 15 keeps those, bit 14 then swaps the GEMMs for potrf_panel256 (one workgroup per problem; measured
+    # slower).  Same factor and inverse up to rounding (the two one-workgroup / GEMM routes: bitwise -- the same k order in every
+    # product), same oracle tolerance; each route launches its own kernels and none of the others'
+    is128 = lambda F: any(s["M"] == 128 and s["N"] == 128 and s["K"] == 128 for s in F.gemm_shapes())
+    Fb.set_profiling(1); Fb.refactor(vals); st = Fb.stats(); Fb.set_profiling(0)
+    assert st["kernel_launches"][16] == 0 and st["kernel_launches"][17] == 0 and not is128(Fb)
+    Fd = pkg.TridiagonalCholeskyFactor(batch=2)
+    Fd.set_eager(32768)
+    Fd.factor(w.Q, w.n_blocks, values=vals)
+    Fd.select_problem(0)
+    assert 0 < np.max(np.abs(Fd.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
+    Xd, Xb = Fd.get_block(pkg._cabi.BLOCK_LINV, 31), Fb.get_block(pkg._cabi.BLOCK_LINV, 31)
+    assert np.max(np.abs(Xd - Xb)) < 1e-11 * np.max(np.abs(Xb))
+    assert rel(Fd.solve_batch(rhs[:, None, :])[0, 0], mu_b[0]) < 1e-12
+    Fd.set_profiling(1); Fd.refactor(vals); std = Fd.stats(); Fd.set_profiling(0)
+    assert std["kernel_launches"][16] == 2 * (w.block_size // 256) * w.n_blocks and std["kernel_launches"][17] == 0 and is128(Fd)
     Fg = pkg.TridiagonalCholeskyFactor(batch=2)
-    Fg.set_eager(16384)
+    Fg.set_eager(32768 | 16384)
     Fg.factor(w.Q, w.n_blocks, values=vals)
     Fg.select_problem(0)
-    d = np.max(np.abs(Fg.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63]))
-    assert d < 1e-12
+    assert np.max(np.abs(Fg.chos[63] - Fd.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12        # (measured: 0)
+    assert np.max(np.abs(Fg.get_block(pkg._cabi.BLOCK_LINV, 31) - Xd)) < 1e-11 * np.max(np.abs(Xd))
     Fg.set_profiling(1); Fg.refactor(vals); stg = Fg.stats(); Fg.set_profiling(0)
-    assert stg["kernel_launches"][17] == 2 * (w.block_size // 256) * w.n_blocks
-    assert not any(s["M"] == 128 and s["N"] == 128 and s["K"] == 128 for s in Fg.gemm_shapes())
-    Xg, Xb = Fg.get_block(pkg._cabi.BLOCK_LINV, 31), Fb.get_block(pkg._cabi.BLOCK_LINV, 31)
-    assert np.max(np.abs(Xg - Xb)) < 1e-11 * np.max(np.abs(Xb))
-    assert rel(Fg.solve_batch(rhs[:, None, :])[0, 0], mu_b[0]) < 1e-12
-    Fb.set_profiling(1); Fb.refactor(vals); st = Fb.stats(); Fb.set_profiling(0)
-    assert st["kernel_launches"][17] == 0 and any(s["M"] == 128 and s["N"] == 128 and s["K"] == 128 for s in Fb.gemm_shapes())
+    assert stg["kernel_launches"][17] == 2 * (w.block_size // 256) * w.n_blocks and not is128(Fg)
 
 
 def test_config_elliptic_long_chain_properties(pkg):

@@ -17,11 +17,14 @@ L = np.linalg.cholesky(A)
 print("info", info.value, "L err", np.max(np.abs(np.tril(S) - L)) / np.max(np.abs(L)), "inv err", np.max(np.abs(np.tril(Linv) @ L - np.eye(bs))))
 nt = bs // 64
 out = np.zeros(8 * (nt - 1) + 1); pkg._cabi.check(lib.gmrf_test_persist_stamps(pkg._cabi.ptr(out), len(out)))
+out_base = 0
 print("tile 0 done at 0; per step (cycles): wait for flags | operands -> LDS | L[j+1,j] = S X^T | -> LDS | store issued | S - L L^T (wave 3) | tile in LDS | potrf + inverse + publish")
 prev = 0.0
 for j in range(nt - 1):
-    s = out[8 * j + 1: 8 * j + 9]
+    s = out[8 * j + 1: 8 * j + 9].copy()
+    seen = s[4]                        # slot 5: the panel in which the NEXT step's operands were seen ready (-1 / 0: not prefetched), relative
+    s[4] = s[3]
     d = np.diff(np.concatenate([[prev], s]))
-    print(f"step {j:2d}: " + " ".join(f"{x:7.0f}" for x in d) + f"   total {s[7]-prev:7.0f}")
+    print(f"step {j:2d}: " + " ".join(f"{x:7.0f}" for x in d) + f"   total {s[7]-prev:7.0f}   next operands seen ready in panel {int(seen)}")
     prev = s[7]
 print(f"chain total {prev:.0f} cycles for {nt - 1} steps = {prev / max(nt - 1, 1):.0f} per step")

@@ -1,0 +1,20 @@
+#!/bin/bash
+set -o pipefail
+OUT=gpurun_out/${1:-r4m}; mkdir -p $OUT
+timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1 || { tail -40 $OUT/pytest.log; exit 1; }
+tail -2 $OUT/pytest.log
+for env in "GMRF_PERSIST_PANELS=1" "GMRF_PERSIST_PANELS=0"; do
+  env $env timeout -k 10 500 python bench.py --config elliptic512 --batch 8 --steps 3 --warmup 1 --no-cpu-baseline --no-spmm --no-full-loop --no-single-problem > $OUT/bench_c4_$env.json 2> $OUT/bench_c4_$env.err || { tail -20 $OUT/bench_c4_$env.err; exit 1; }
+  python - <<PY
+import json
+d = json.loads(open("$OUT/bench_c4_$env.json").read().strip().splitlines()[-1])
+print("elliptic512 4x8 $env", {k: d.get(k) for k in ("value", "ms_per_step")}, d.get("phases_ms"))
+print("   kernels", {k: (round(v["ms_per_step"], 2), v["launches"]) for k, v in d.get("kernels", {}).items() if v["launches"]})
+PY
+done
+timeout -k 10 500 python bench.py --config elliptic512 --batch 16 --streams 2 --steps 3 --warmup 1 --no-cpu-baseline --no-spmm --no-full-loop --no-single-problem > $OUT/bench_c4_2x16.json 2> $OUT/bench_c4_2x16.err || { tail -20 $OUT/bench_c4_2x16.err; exit 1; }
+python - <<PY
+import json
+d = json.loads(open("$OUT/bench_c4_2x16.json").read().strip().splitlines()[-1])
+print("elliptic512 2x16", {k: d.get(k) for k in ("value", "ms_per_step")}, d.get("phases_ms"))
+PY
