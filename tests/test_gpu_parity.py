@@ -654,7 +654,7 @@ def test_two_level_panel_factor_of_batches(pkg):
     assert 0 < np.max(np.abs(Fd.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
     Xd, Xb = Fd.get_block(pkg._cabi.BLOCK_LINV, 31), Fb.get_block(pkg._cabi.BLOCK_LINV, 31)
     assert np.max(np.abs(Xd - Xb)) < 1e-11 * np.max(np.abs(Xb))
-    assert rel(Fd.solve_batch(rhs[:, None, :])[0, 0], mu_b[0]) < 1e-12
+    assert rel(Fd.solve_batch(rhs[:, None, :])[0, 0], mu_b[0]) < solve_tol(w)      # (two roundings of one ill-conditioned solve)
     Fd.set_profiling(1); Fd.refactor(vals); std = Fd.stats(); Fd.set_profiling(0)
     assert std["kernel_launches"][16] == 2 * (w.block_size // 256) * w.n_blocks and std["kernel_launches"][17] == 0 and is128(Fd)
     Fg = pkg.TridiagonalCholeskyFactor(batch=2)
