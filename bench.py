@@ -49,6 +49,7 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
     15: ("gemm_f64_dma<B[k][n]>", "mfma"),       # LDS-DMA staged GEMM, B stored [k][n]
     12: ("gemm_f64_mfma<true,*>", "mfma"),       # A stored [k][m] (selected inversion only)
     16: ("potrf_diag128", "mfma"),               # 128 x 128 diagonal block of a batch (two tile Choleskys + its inverse)
+    18: ("gemm_f64_dma<A[k][m]>", "mfma"),       # LDS-DMA staged GEMM, A stored [k][m] (selected inversion, round 4)
     17: ("potrf_panel256", "mfma"),              # the 128^3 products of a 256-column panel, one workgroup per problem (round 4)
     6: ("gemm_f64_big<false>", "mfma"),     # 128 x 128 tile GEMM, B stored [n][k]
     7: ("gemm_f64_big<true>", "mfma"),      # 128 x 128 tile GEMM, B stored [k][n]
@@ -889,7 +890,7 @@ def main():
             got, traffic_src = pmc_traffic("hbm_traffic", [sym], batch=eng.batch)
             if got:
                 traffic = next(iter(got.values()))
-        gemm_cls = [c for c in (0, 11, 12, 13, 14, 15, 6, 7) if ms[c] > 0]
+        gemm_cls = [c for c in (0, 11, 12, 13, 14, 15, 18, 6, 7) if ms[c] > 0]
         tw = sum(work[c] for c in gemm_cls) / max(sum(ms[c] for c in gemm_cls), 1e-9) / 1e9 if gemm_cls else 0.0
         out["roofline"] = {"bound": bound, "achieved": achieved, "peak": peak, "unit": unit,
                            "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src, "kernel": name,

@@ -756,7 +756,8 @@ inline bool gemm_uses_ll(const GemmArgs& g, int batch) {
     // real batch is better served by 64 x 64 tiles even when they fill few CUs: with several handles in flight what counts is
     // what a launch takes from the chip, not how soon it ends (darcy256, 4 x 32: the 128-tile launches on gemm_f64_dma are
     // slower one by one -- 1-stream GEMM time 46.9 -> 48.9 ms -- and the job is faster, 43.7 k -> 44.2 k solves/s).
-    return tiles <= 128 && batch < 8;
+    // (round 4: a batch of EIGHT counts as a handful -- elliptic512 at 4 x 8: 6.28 k -> 6.46 k solves/s with its 128-tile launches here)
+    return tiles <= 128 && batch <= 8;
 }
 
 // The LDS-DMA kernels (gemm_f64_dma.hpp) take the launches that qualify; defined there.

@@ -82,13 +82,19 @@ __device__ __forceinline__ void gemm_dma_tile_order(const GemmArgs& g, int& bm, 
     z = xg + groups * zq;
 }
 
-template <int BM, int BN, bool B_N, int STAGES>
+// A_T (round 4): A stored [k][m] -- the product A^T B of two operands that both lie [k][.] in memory (selected inversion:
+// M = T1^T C_w, S = X^T Y) without a transposing pass before it.  Its LDS image is the [16][BM] image of a B stored [k][n], its
+// fragments pair neighbouring ROW tiles the way that image pairs column tiles: MFMA tile i = 2 ip + q of a wave holds the rows
+// wm + 32 ip + 2 li + q (li = MFMA row index), which only moves where the epilogue puts a register.  Same k slots, same
+// summation order: bitwise the result of transposing A first.
+template <int BM, int BN, bool B_N, int STAGES, bool A_T = false>
 __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(GemmArgs g) {
     constexpr int BK = DMA_BK;
     constexpr int MI = BM / 32, NJ = BN / 32;                    // 16 x 16 MFMA tiles of a wave: MI x NJ
     constexpr int NA = BM / 32, NB = BN / 32;                    // LDS-DMA instructions per wave and K step (A, B)
     constexpr int A_ST = BM * BK, B_ST = BN * BK, ST = A_ST + B_ST;   // doubles per stage
     static_assert(NJ % 2 == 0 || !B_N, "the [k][n] image pairs neighbouring column tiles");
+    static_assert(MI % 2 == 0 || !A_T, "the [k][m] image pairs neighbouring row tiles");
     int bm, bn, z;
     gemm_dma_tile_order<BM, BN>(g, bm, bn, z);
     const int m0 = bm * BM, n0 = bn * BN;
@@ -125,8 +131,15 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
     uint32_t offa[NA], offb[NB];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int q = w + 4 * i, row = 8 * q + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
-        offa[i] = (uint32_t)(((int64_t)(m0 + row) * g.lda + 2 * ch) * 8);
+        const int q = w + 4 * i;
+        if (A_T) {
+            constexpr int LPR = BM / 2;                          // lanes per k row
+            const int k = q * (64 / LPR) + lane / LPR, col = (lane % LPR) * 2;
+            offa[i] = (uint32_t)(((int64_t)k * g.lda + m0 + col) * 8);
+        } else {
+            const int row = 8 * q + (lane >> 3), ch = (lane & 7) ^ ((row >> 1) & 7);
+            offa[i] = (uint32_t)(((int64_t)(m0 + row) * g.lda + 2 * ch) * 8);
+        }
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
     }
     auto issue = [&](int kt, int stage) {
         const int k0 = kb + kt * BK;
-        const char* abase = reinterpret_cast<const char*>(A + k0);
+        const char* abase = reinterpret_cast<const char*>(A_T ? A + (int64_t)k0 * g.lda : A + k0);
         const char* bbase = reinterpret_cast<const char*>(B_N ? B + (int64_t)k0 * g.ldb : B + k0);
         double* as = gsm + stage * ST;
         double* bs = as + A_ST;
@@ -168,11 +181,14 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
     // fragment addresses inside a stage (doubles): A rows wm + 16 i + li, chunk kg * 4 + lq swizzled by the row
     int fa[MI], fb[NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int row = wm + 16 * i + li; fa[i] = row * 16 + 2 * (lq ^ ((row >> 1) & 3)) ; }
+    for (int i = 0; i < MI; ++i) {
+        const int row = wm + 16 * i + li;
+        fa[i] = A_T ? (2 * lq + (i & 1)) * BM + wm + 32 * (i >> 1) + 2 * li : row * 16 + 2 * (lq ^ ((row >> 1) & 3));
+    }
     // (chunk = kg * 4 + lq; swizzle key (row >> 1) & 7 = 4 * s2 + s01: chunk ^ key = (kg ^ s2) * 4 + (lq ^ s01))
     int sa2[MI], sb2[NJ];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) { const int row = wm + 16 * i + li; sa2[i] = ((row >> 1) & 4) ? 8 : 0; }   // doubles: chunk bit 2 = 4 chunks = 8 doubles
+    for (int i = 0; i < MI; ++i) { const int row = wm + 16 * i + li; sa2[i] = (!A_T && ((row >> 1) & 4)) ? 8 : 0; }   // doubles: chunk bit 2 = 4 chunks = 8 doubles
     if (!B_N) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -208,7 +224,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
 #pragma unroll
             for (int kg = 0; kg < BK / 8; ++kg) {
 #pragma unroll
-                for (int i = 0; i < MI; ++i) a[kg][i] = *reinterpret_cast<const v2d*>(sm + fa[i] + ((kg * 8) ^ sa2[i]));
+                for (int i = 0; i < MI; ++i) a[kg][i] = *reinterpret_cast<const v2d*>(sm + fa[i] + (A_T ? kg * 8 * BM : ((kg * 8) ^ sa2[i])));
 #pragma unroll
                 for (int j = 0; j < NJ; ++j)
                     b[kg][j] = *reinterpret_cast<const v2d*>(sm + fb[j] + (B_N ? kg * 8 * BN : ((kg * 8) ^ sb2[j])));
@@ -224,7 +240,9 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NJ; ++j) {
-                            const double av = p ? a[kg][i].y : a[kg][i].x;
+                            double av;                             // ([k][m] image: a[2 ip + p] = row k + p, .x / .y = rows 2 li / 2 li + 1 = tiles 2 ip / 2 ip + 1)
+                            if (A_T) av = (i & 1) ? a[kg][2 * (i >> 1) + p].y : a[kg][2 * (i >> 1) + p].x;
+                            else av = p ? a[kg][i].y : a[kg][i].x;
                             // [n][k] image: tile j = b[j], k slot = .x / .y.  [k][n] image: b[2 jp + p] = row k + p,
                             // .x / .y = even / odd columns = output tiles 2 jp / 2 jp + 1
                             double bv;
@@ -240,6 +258,9 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
     // f64 MFMA C/D map: col = lane & 15, row = (lane >> 4) + 4 * reg.  With an addend (beta != 0) all of its loads are
     // issued before the first is used (one wait instead of one per element).
     const double alpha = g.alpha, beta = g.beta;
+    auto orow = [&](int i, int r) -> int64_t {          // row of register r of the wave's MFMA tile i
+        return A_T ? m0 + wm + 32 * (i >> 1) + 2 * (lq + 4 * r) + (i & 1) : m0 + wm + i * 16 + lq + 4 * r;
+    };
     if (B_N) {
         v2d d[MI][4][NJ / 2 > 0 ? NJ / 2 : 1];
         if (beta != 0.0) {
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int jp = 0; jp < NJ / 2; ++jp)
-                        d[i][r][jp] = *reinterpret_cast<const v2d*>(Dm + (int64_t)(m0 + wm + i * 16 + lq + 4 * r) * ldd + n0 + wn + jp * 32 + 2 * li);
+                        d[i][r][jp] = *reinterpret_cast<const v2d*>(Dm + orow(i, r) * ldd + n0 + wn + jp * 32 + 2 * li);
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                 for (int jp = 0; jp < NJ / 2; ++jp) {
                     v2d v = (v2d){alpha * acc[i][2 * jp][r], alpha * acc[i][2 * jp + 1][r]};
                     if (beta != 0.0) { v.x += beta * d[i][r][jp].x; v.y += beta * d[i][r][jp].y; }
-                    *reinterpret_cast<v2d*>(C + (int64_t)(m0 + wm + i * 16 + lq + 4 * r) * g.ldc + n0 + wn + jp * 32 + 2 * li) = v;
+                    *reinterpret_cast<v2d*>(C + orow(i, r) * g.ldc + n0 + wn + jp * 32 + 2 * li) = v;
                 }
     } else {
         double d[MI][4][NJ];
@@ -270,7 +291,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                 for (int r = 0; r < 4; ++r)
 #pragma unroll
                     for (int j = 0; j < NJ; ++j)
-                        d[i][r][j] = Dm[(int64_t)(m0 + wm + i * 16 + lq + 4 * r) * ldd + n0 + wn + j * 16 + li];
+                        d[i][r][j] = Dm[orow(i, r) * ldd + n0 + wn + j * 16 + li];
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i)
@@ -280,7 +301,7 @@ __global__ __launch_bounds__(256, (BM + BN > 128) ? 3 : 4) void gemm_f64_dma(Gem
                 for (int j = 0; j < NJ; ++j) {
                     double v = alpha * acc[i][j][r];
                     if (beta != 0.0) v += beta * d[i][r][j];
-                    C[(int64_t)(m0 + wm + i * 16 + lq + 4 * r) * g.ldc + n0 + wn + j * 16 + li] = v;
+                    C[orow(i, r) * g.ldc + n0 + wn + j * 16 + li] = v;
                 }
     }
 }
@@ -304,14 +325,15 @@ inline int gemm_dma_stages() {
 // 0: not a DMA launch; 1: 64 x 64; 2: 128 x 64; 3: 64 x 128
 inline int gemm_dma_shape(bool a_t, const GemmArgs& g, int batch) {
     const int policy = gemm_dma_force() ? 2 : gemm_dma_policy();
-    if (policy == 0 || a_t || g.stamps || (g.tri & ~15) || g.K % DMA_BK || g.M % 64 || g.N % 64) return 0;
+    if (policy == 0 || g.stamps || (g.tri & ~15) || g.K % DMA_BK || g.M % 64 || g.N % 64) return 0;
     if ((g.lda & 1) || (g.ldb & 1) || ((uintptr_t)g.A & 15) || ((uintptr_t)g.B & 15) || ((g.strideA | g.strideB | g.pA | g.pB) & 1)) return 0;
     // the B [k][n] epilogue loads the addend and stores the result as 16-byte pieces
     if (((uintptr_t)g.C & 15) || (g.ldc & 1) || ((g.strideC | g.pC) & 1)) return 0;
     if (g.D && (((uintptr_t)g.D & 15) || (g.ldd & 1) || (g.pD & 1))) return 0;
     if ((int64_t)g.M * g.ldc * 8 >= ((int64_t)1 << 32) || (g.D && (int64_t)g.M * g.ldd * 8 >= ((int64_t)1 << 32))) return 0;
     // 32-bit byte offsets inside a problem's operand
-    if ((int64_t)g.M * g.lda * 8 >= ((int64_t)1 << 32) || (int64_t)std::max(g.N, g.K) * g.ldb * 8 >= ((int64_t)1 << 32)) return 0;
+    if ((int64_t)(a_t ? g.K : g.M) * g.lda * 8 >= ((int64_t)1 << 32) || (int64_t)std::max(g.N, g.K) * g.ldb * 8 >= ((int64_t)1 << 32)) return 0;
+    if (a_t) return 1;                                  // A stored [k][m]: the 64 x 64 tile
     const int force = gemm_dma_force();
     if (force == 2 && g.M % 128 == 0) return 2;
     if (force == 3 && g.N % 128 == 0 && !g.lower_only) return 3;
@@ -360,7 +382,9 @@ inline bool gemm_try_dma(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, 
         const dim3 grid((unsigned)(tiles * batch));                                                               \
         static const size_t lds_pad = [] { const char* e = getenv("GMRF_GEMM_DMA_LDS_PAD_KB"); return (size_t)(e ? atoi(e) : 0) * 1024; }();   /* tuning aid */ \
         const size_t lds = gemm_dma_lds_bytes<BM, BN>(stages) + lds_pad;                                          \
-        if (stages == 3) {                                                                                        \
+        if (a_t && BM == 64 && BN == 64) {                                                                        \
+            if (b_n) GMRF_DMA_K((gemm_f64_dma<64, 64, true, 2, true>)); else GMRF_DMA_K((gemm_f64_dma<64, 64, false, 2, true>)); \
+        } else if (stages == 3) {                                                                                 \
             if (b_n) GMRF_DMA_K((gemm_f64_dma<BM, BN, true, 3>)); else GMRF_DMA_K((gemm_f64_dma<BM, BN, false, 3>)); \
         } else {                                                                                                  \
             if (b_n) GMRF_DMA_K((gemm_f64_dma<BM, BN, true, 2>)); else GMRF_DMA_K((gemm_f64_dma<BM, BN, false, 2>)); \

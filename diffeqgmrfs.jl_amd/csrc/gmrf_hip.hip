@@ -205,7 +205,7 @@ struct gmrf_handle {
     bool no_persist = false;           // set_eager bit 13, or a persistent launch gave up
     int persist_aborts = 0;
     int cu_count = 0;
-    unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zeroed by a memset node ahead of each)
+    unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zero between launches: potrf_persist cleans up after itself)
     int64_t pflags_words = 0;
     bool no_persist_panels = false;    // batches small enough for it keep potrf_diag128 + the 128^3 products instead of one persistent launch per panel (set_eager bit 15)
     bool gemm128 = true;               // batches: the 128^3 products of a 256-column panel as GEMM launches (default); false (set_eager bit 14): potrf_panel256, measured slower
@@ -301,7 +301,7 @@ static gmrf_status gemm(gmrf_handle* h, bool a_t, bool b_n, int M, int N, int K,
     if (gemm_uses_big(a_t, g, batch * (int)h->B)) { pclass = b_n ? 7 : 6; pwork = -1.0; }
     else if (pclass == 0) {
         if (gemm_uses_ll(g, batch * (int)h->B)) pclass = 13;
-        else if (gemm_uses_dma(a_t, g, batch * (int)h->B)) pclass = b_n ? 15 : 14;     // gemm_f64_dma<.., B [n][k]> / <.., B [k][n]>
+        else if (gemm_uses_dma(a_t, g, batch * (int)h->B)) pclass = a_t ? 18 : (b_n ? 15 : 14);   // gemm_f64_dma<.., B [n][k]> / <.., B [k][n]> / <.., A [k][m]>
         else pclass = a_t ? 12 : (b_n ? 11 : 0);
     }
     if (h->profiling > 0) {
@@ -441,6 +441,8 @@ static gmrf_status alloc_work(gmrf_handle* h) {
         if (!h->d_pflags || h->pflags_words < words) {
             free_dev(h->d_pflags); h->d_pflags = nullptr; h->pflags_words = 0;
             HIPCHK(hipMalloc(&h->d_pflags, sizeof(unsigned) * (size_t)words));
+            HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)words, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));     // (whatever stream the first launch is on later sees the zeros)
             h->pflags_words = words;
         }
     }
@@ -806,7 +808,7 @@ static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* 
                                   double flops) {
     const int words = persist_flag_words(nt);
     if (!h->d_pflags || h->pflags_words < (int64_t)words * h->B) return bad_shape("internal: flag words of the persistent launches not allocated");
-    HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)words * (size_t)h->B, h->stream));
+    // (no memset node: the words are zero -- zeroed when allocated, left zero by the last workgroup out of every launch)
     PersistArgs pa;
     pa.S = S; pa.L = L; pa.X = X; pa.ld = h->bsp; pa.nt = nt; pa.j0 = j0; pa.j1 = j1; pa.xrows = xrows;
     pa.tail_panel = (!xrows && j1 < nt) ? 1 : 0;
@@ -1311,6 +1313,7 @@ static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
         h->no_persist = true; h->persist_aborts++;
         destroy_graphs(h);
         HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
+        if (h->d_pflags) HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)h->pflags_words, h->stream));   // (belt and braces: the drained launches cleaned up themselves)
         GCHK(factor_blocks_range(h, 0, h->N));
         HIPCHK(hipMemcpyAsync(hinfo2, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
@@ -3611,10 +3614,9 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     // and left of column cmin), and both follow from  S_ii = X^T Y,  Y = X with its rows >= cmin replaced by
     // (I + M) X[cmin:, :],  M = C_w^T S' C_w  (C_w: the stored window of C_i, S' = S_{i+1,i+1}[0:rmax, 0:rmax]):
     //   T1 = S' C_w                 rmax x wc,   K = rmax, column tile u of C_w ends at row mend[u]
-    //   M  = T1^T C_w               wc x wc, lower tiles, same K bound (T1^T by a tile transpose: the LDS-DMA GEMM takes no
-    //                               operand stored [k][m]), mirrored
+    //   M  = T1^T C_w               wc x wc, lower tiles, same K bound (T1 as it lies: gemm_f64_dma's A [k][m] form), mirrored
     //   Y[cmin:, :] = M X[cmin:, :] + X[cmin:, :]          K = wc from the first non-zero row of each column tile of X
-    //   S[0:rmax, 0:rmax] = X^T[0:rmax, :] Y[:, 0:rmax]    lower tiles, K from each row tile's diagonal (X^T by a tile transpose)
+    //   S[0:rmax, 0:rmax] = X^T[0:rmax, :] Y[:, 0:rmax]    lower tiles, K from each row tile's diagonal (X as it lies, [k][m])
     //   diag(S)[n] = sum_k X[k][n] Y[k][n]                  (coldot_lower)
     // 1.9 GF per 1024-block instead of 5.7 (two full 1024^3 products, two of them on the register-staged kernel that the
     // [k][m] operand forced), every product on gemm_f64_dma.
@@ -3632,10 +3634,9 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
     }
     double* Sg = h->d_S;     // leading block of Sigma_{i+1,i+1} (full, mirrored)
     double* Sn = h->d_W;
-    double* Xt = h->d_B;     // rows 0 .. rmax of Linv_i^T
     double* Y = h->d_T;
-    double* V1 = h->d_V;                                 // T1, then M
-    double* V2 = h->d_V + bstride * h->B;                // T1^T
+    double* V1 = h->d_V;                                 // T1
+    double* V2 = h->d_V + bstride * h->B;                // M
     const int nt = bsp / 64, trm = rm / 64, twc = wc / 64;
     for (int64_t i = h->N - 1; i >= 0; --i) {
         const double* X = h->d_Linv + i * bstride;
@@ -3645,15 +3646,13 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
             // T1 = S' C_w
             GCHK(gemm(h, false, true, rm, wc, rm, 0, 0, 1.0, Sg, ld, C, c_ld(h), 0.0, V1, ld, pW, pCm, pW,
                       1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * rm * h->c_streamed * (double)h->B, nullptr, nullptr, h->d_mend));
-            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(trm * twc), nb), dim3(256), 0, h->stream, V1, ld, V2, ld, pW, pW, trm, twc, 0);
-            HIPCHK(hipGetLastError());
-            // M = T1^T C_w (lower tiles), mirrored
-            GCHK(gemm(h, false, true, wc, wc, rm, 0, 1, 1.0, V2, ld, C, c_ld(h), 0.0, V1, ld, pW, pCm, pW,
+            // M = T1^T C_w (lower tiles; T1 taken as it lies, [k][m]), mirrored
+            GCHK(gemm(h, true, true, wc, wc, rm, 0, 1, 1.0, V1, ld, C, c_ld(h), 0.0, V2, ld, pW, pCm, pW,
                       1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, nullptr, nullptr, h->d_mend));
-            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(twc * (twc + 1) / 2), nb), dim3(256), 0, h->stream, V1, ld, V1, ld, pW, pW, twc, twc, 2);
+            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(twc * (twc + 1) / 2), nb), dim3(256), 0, h->stream, V2, ld, V2, ld, pW, pW, twc, twc, 2);
             HIPCHK(hipGetLastError());
             // Y[cmin:, :] = M X[cmin:, :] + X[cmin:, :]   (column tile u of X[cmin:, :] starts at row max(0, 64 u - cmin))
-            GCHK(gemm(h, false, true, wc, bsp, wc, 0, 0, 1.0, V1, ld, X + (int64_t)cm * ld, ld, 1.0, Y + (int64_t)cm * ld, ld, pW, pX, pW,
+            GCHK(gemm(h, false, true, wc, bsp, wc, 0, 0, 1.0, V2, ld, X + (int64_t)cm * ld, ld, 1.0, Y + (int64_t)cm * ld, ld, pW, pX, pW,
                       1, 0, 0, 0, X + (int64_t)cm * ld, ld, pX, 0, -1.0, nullptr, h->d_kbx, nullptr));
         }
         // diag(S_ii): of the last block processed (i = 0) and of the columns >= rmax by column dot products; the columns below
@@ -3665,20 +3664,14 @@ static gmrf_status var_exact(gmrf_handle* h, double* d_out) {
             HIPCHK(hipGetLastError());
         }
         if (i == 0) break;                               // nobody needs the leading block of S_00
-        // leading block of S_ii for the next step: rows 0 .. rmax of X^T, then the product on its lower tiles, mirrored
-        {
-            int tiles = 0;
-            for (int c = 0; c < trm; ++c) tiles += nt - c;
-            hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)tiles, nb), dim3(256), 0, h->stream, X, ld, Xt, ld, pX, pW, nt, trm, 1);
-            HIPCHK(hipGetLastError());
-        }
+        // leading block of S_ii for the next step: the product X^T Y on its lower tiles (X taken as it lies, [k][m]), mirrored
         if (coupled) {
             if (cm > 0)
-                GCHK(gemm(h, false, true, rm, rm, cm, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, Xt, ld, X, ld, 0.0, Sn, ld, pW, pX, pW));
-            GCHK(gemm(h, false, true, rm, rm, wc, 0, 1, 1.0, Xt + cm, ld, Y + (int64_t)cm * ld, ld, cm > 0 ? 1.0 : 0.0, Sn, ld, pW, pW, pW,
+                GCHK(gemm(h, true, true, rm, rm, cm, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, X, ld, X, ld, 0.0, Sn, ld, pX, pX, pW));
+            GCHK(gemm(h, true, true, rm, rm, wc, 0, 1, 1.0, X + (int64_t)cm * ld, ld, Y + (int64_t)cm * ld, ld, cm > 0 ? 1.0 : 0.0, Sn, ld, pX, pW, pW,
                       1, 0, 0, 0, nullptr, 0, 0, 0, -1.0, h->d_kbx, nullptr, nullptr));
         } else {
-            GCHK(gemm(h, false, true, rm, rm, bsp, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, Xt, ld, X, ld, 0.0, Sn, ld, pW, pX, pW));
+            GCHK(gemm(h, true, true, rm, rm, bsp, TRI_A_UPPER | TRI_B_LOWER, 1, 1.0, X, ld, X, ld, 0.0, Sn, ld, pX, pX, pW));
         }
         hipLaunchKernelGGL(transpose_tiles, dim3((unsigned)(trm * (trm + 1) / 2), nb), dim3(256), 0, h->stream, Sn, ld, Sn, ld, pW, pW, trm, trm, 2);
         HIPCHK(hipGetLastError());

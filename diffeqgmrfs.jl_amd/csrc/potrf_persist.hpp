@@ -46,7 +46,7 @@ struct PersistArgs {
     int tail_panel;         // 1 (larger blocks): the workgroups of the last column also form L[r, j1-1] for the rows below the panel
     int* info; int blk;
     int64_t pS, pL, pX; int blk_per_problem;
-    unsigned* flags;        // [problems][flag_stride]; zeroed by a memset node ahead of the launch
+    unsigned* flags;        // [problems][flag_stride]; zero at the start of a launch (left so by the last workgroup out of the previous one)
     int flag_stride;
     unsigned* abort_word;   // zeroed at the start of a factorisation, read by the host at its end
     unsigned spin_limit;
@@ -55,7 +55,12 @@ struct PersistArgs {
 
 // flag words of one problem: D[j] (L_jj, X_jj stored) | F[r][c] (tile (r,c) of S final) | PL[r][c] (L[r,c] stored) |
 // XF[r][c] (X[r,c] stored)
-__host__ __device__ inline int persist_flag_words(int nt) { return (nt + 3 * nt * nt + 3) & ~3; }
+// followed by ONE more word: the count of workgroups of this problem that have left the launch.  The last one out zeroes every
+// word again (nobody is left to read them), so the words are zero when the next launch starts: the memset node that used to
+// precede every launch (4.5 - 4.9 us each, 8 192 per C5 factorisation = 40 of its 1 604 ms) is gone.  Zeroed once, by the
+// host, when they are allocated.
+__host__ __device__ inline int persist_flag_count(int nt) { return nt + 3 * nt * nt; }
+__host__ __device__ inline int persist_flag_words(int nt) { return (persist_flag_count(nt) + 1 + 3) & ~3; }
 
 // tiles owned by worker workgroups, column by column: column j0 (inverse only, when xrows), then c = j0+1 .. j1-1 with the
 // rows r = c+1 .. nt-1 and, from c = j0+2 on, the diagonal tile (c, c) (steps j0 .. c-2; step c-1 is the chain's)
@@ -303,8 +308,7 @@ struct ChainSide {
     __device__ __forceinline__ void ak(int, int) const {}
 };
 
-template <bool UNUSED>
-__global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
+__device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
     pa.S += (int64_t)blockIdx.y * pa.pS;
     pa.L += (int64_t)blockIdx.y * pa.pL;
     pa.X += (int64_t)blockIdx.y * pa.pX;
@@ -579,6 +583,24 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
     strip_tri_nn_w(wave, As + (16 * wave + li) * TLD, Bs, res, li, lq);           // X_rr lower triangular: the k groups 0 .. 2 wave + 1
     strip_store_sc1(pa.X + (int64_t)r * 64 * ld + (int64_t)c * 64, ld, res, 4, true, wave, li, lq);
     wg_publish(fXF + r * nt + c, nullptr, tid);
+}
+
+template <bool UNUSED>
+__global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
+    potrf_persist_body(pa);                               // (every return in there is taken by the whole workgroup)
+    // The last workgroup of a problem to get here leaves the flag words zero for the next launch: all its own stores are
+    // acknowledged (vmcnt(0)), then one lane counts the workgroup out; whoever counts gridDim.x - 1 others before it knows that
+    // nobody will look at a word of this launch again.
+    __shared__ int last_out;
+    unsigned* const flags = pa.flags + (int64_t)blockIdx.y * pa.flag_stride;
+    const int nflags = persist_flag_count(pa.nt);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+        last_out = __hip_atomic_fetch_add(flags + nflags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+    __syncthreads();
+    if (last_out)
+        for (int i = threadIdx.x; i <= nflags; i += 256) st_flag(flags + i, 0u);
 }
 
 }  // namespace gmrf

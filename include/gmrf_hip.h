@@ -85,7 +85,8 @@ typedef struct {
      * 14 / 15 gemm_f64_dma<.., B [n][k]> / <.., B [k][n]> (LDS-DMA staged GEMM: the batches' products since round 3)
      * 16 potrf_diag128 (128 x 128 diagonal block of a batch: two tile Choleskys + the block's inverse)
      * 17 potrf_panel256 (the 128^3 products of a 256-column panel of a batch, one workgroup per problem: round 4)
-     * work = algorithmic flops (0-2, 6-9, 11-17) or algorithmic bytes (3-5, 10). */
+     * 18 gemm_f64_dma<.., A [k][m]> (the A^T B products of selected inversion: round 4)
+     * work = algorithmic flops (0-2, 6-9, 11-18) or algorithmic bytes (3-5, 10). */
 #define GMRF_KERNEL_CLASSES 24
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];

@@ -217,6 +217,32 @@ def test_gemm_dma_lower_only(lib, pkg, shape, tb):
                 assert np.array_equal(out[blk], c0[blk])
 
 
+@pytest.mark.parametrize("tb", [0, 1])
+@pytest.mark.parametrize("tri", [0, 2, 2 | 4, 8])
+def test_gemm_dma_a_stored_k_by_m(lib, pkg, tb, tri):
+    """Round 4: the LDS-DMA GEMM with A stored [k][m] (the products A^T B of selected inversion, both operands lying [k][.]):
+    against NumPy, and bitwise against the register-staged kernel's A-transposed form (same k order per output element), on
+    full and triangular K ranges, both B layouts, with an addend; a lower-only launch leaves the upper tiles alone."""
+    M, N, K = (256, 256, 256) if tri else (192, 320, 208)
+    a, ref, _ = _gemm(lib, pkg, M, N, K, 1, tb, tri=tri | DMA["64x64"], alpha=-0.75, beta=1.0, seed=400 + tri + tb)
+    b, _, _ = _gemm(lib, pkg, M, N, K, 1, tb, tri=tri, alpha=-0.75, beta=1.0, seed=400 + tri + tb)
+    assert np.max(np.abs(a - ref)) < 1e-12 * 256
+    assert np.array_equal(a, b)
+    out, ref, c0 = _gemm(lib, pkg, 384, 384, 96, 1, tb, tri=DMA["64x64"], lower=1, alpha=-1.0, beta=1.0, seed=416 + tb)
+    old, _, _ = _gemm(lib, pkg, 384, 384, 96, 1, tb, tri=0, lower=1, alpha=-1.0, beta=1.0, seed=416 + tb)
+    for bm in range(6):
+        for bn in range(6):
+            blk = (slice(bm * 64, bm * 64 + 64), slice(bn * 64, bn * 64 + 64))
+            if bn <= bm:
+                assert np.max(np.abs(out[blk] - ref[blk])) < 1e-11 and np.array_equal(out[blk], old[blk])
+            else:
+                assert np.array_equal(out[blk], c0[blk])
+    if tri == 0:          # the staging pipeline under load (64 K steps per workgroup)
+        a, ref, _ = _gemm(lib, pkg, 1024, 1024, 1024, 1, tb, tri=DMA["64x64"], seed=430 + tb)
+        b, _, _ = _gemm(lib, pkg, 1024, 1024, 1024, 1, tb, tri=0, seed=430 + tb)
+        assert np.max(np.abs(a - ref)) < 1e-12 * 1024 and np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("shape", list(DMA))
 def test_gemm_dma_long_k_every_cu_busy(lib, pkg, shape):
     """1024^3: 128 - 256 workgroups, 64 K steps each -- the staging pipeline (counted vmcnt waits, one barrier per step,
