@@ -697,13 +697,21 @@ class TridiagonalCholeskyFactor:
         return view
 
     def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None,
-                     q_values=None):
+                     q_values=None, out=None):
         """diag(Q^-1).  "exact" (selected inversion), "rbmc" (the reference's RBMCStrategy(k); needs Q)
         or "mc".  A batch returns (batch, n); its sampled estimators take Q for the pattern and
         `q_values` (batch, nnz): every problem's values in Q's CSR order (for a symmetric matrix the
-        nzval arrays the factor was given)."""
+        nzval arrays the factor was given).  `out`: a contiguous float64 array of that shape to fill -- NumPy, or a
+        torch tensor on the handle's device (the variances then never leave the device); default: a new NumPy array."""
         m = {"exact": _cabi.VAR_EXACT, "rbmc": _cabi.VAR_RBMC, "mc": _cabi.VAR_MC}[method]
-        out = np.empty(self.N if self.batch == 1 else (self.batch, self.N), dtype=np.float64)
+        shape = (self.N,) if self.batch == 1 else (self.batch, self.N)
+        if out is None:
+            out = np.empty(shape, dtype=np.float64)
+        else:
+            ok = tuple(out.shape) == shape and (out.is_contiguous() and str(out.dtype) == "torch.float64" if _is_torch(out)
+                                                else out.flags.c_contiguous and out.dtype == np.float64)
+            if not ok:
+                raise ValueError(f"out must be a contiguous float64 array of shape {shape}")
         if self.batch > 1 and m != _cabi.VAR_EXACT:
             qv = None
             if q_values is not None:

@@ -90,6 +90,11 @@ def test_exact_marginal_variances(case, pkg):
     v = F.marginal_var("exact")
     vo = O.marginal_variances_exact(Fo)
     assert np.max(np.abs(v - vo) / vo) < 1e-9          # exact variances rel <= 1e-9
+    import torch
+    vd_out = torch.empty(w.n, dtype=torch.float64, device="cuda")       # `out=` on the device: the same numbers, no host array
+    assert F.marginal_var("exact", out=vd_out) is vd_out and np.array_equal(vd_out.cpu().numpy(), v)
+    with pytest.raises(ValueError):
+        F.marginal_var("exact", out=np.empty(w.n + 1))
     if w.n <= 1024:
         vd = np.diag(np.linalg.inv(w.Q.toarray()))
         assert np.max(np.abs(v - vd) / vd) < 1e-7
