@@ -82,7 +82,7 @@ def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
     """HBM bytes per launch of kernel symbols from the committed rocprofv3 --pmc snapshot profiles/<round>_<file_stem>.json
     (newest round present; FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py).  A snapshot, not a live counter read: the
     source string names the commit it was taken at.  Returns ({symbol: bytes}, source) or (None, None)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")
         try:
             prof = json.load(open(path))
@@ -104,7 +104,7 @@ def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
 def pmc_traffic_weighted(file_stem: str, prefix: str, batch=None):
     """Launch-weighted HBM bytes per launch over every kernel symbol that starts with `prefix` in the newest committed
     snapshot (see pmc_traffic).  Returns (bytes, source) or (None, None)."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")))
         except Exception:
