@@ -4052,6 +4052,14 @@ gmrf_status gmrf_test_persist_stamps(double* out, int32_t n) {
     return GMRF_OK;
 }
 
+// How often a factorisation of this handle saw the abort word of its persistent launches (a bounded wait gave up) and was
+// repeated with the launch-per-step form (tests force it with GMRF_PERSIST_SPIN_MS=0).
+gmrf_status gmrf_test_persist_aborts(gmrf_handle* h, int32_t* n) {
+    if (!h || !n) return bad_shape("null argument");
+    *n = h->persist_aborts;
+    return GMRF_OK;
+}
+
 gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double* Linv, int32_t* info) {
     if (bs % 64 || next_pow2(bs / 64) != bs / 64) return bad_shape("bs must be 64 * 2^p");
     gmrf_handle* h = nullptr;

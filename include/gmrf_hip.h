@@ -483,6 +483,9 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/ou
 /* s_memtime stamps of the chain workgroup of the last gmrf_test_potrf_block that took the persistent form
  * (csrc/potrf_persist.hpp): out[0] = tile 0 done, then eight per step (tools/persist_stamps.py names them); cycles relative to out[0], -1 = not written. */
 gmrf_status gmrf_test_persist_stamps(double* out, int32_t n);
+/* factorisations of this handle that were repeated with the launch-per-step form because a bounded wait inside a persistent
+ * launch gave up (GMRF_PERSIST_SPIN_MS, default 2000) */
+gmrf_status gmrf_test_persist_aborts(gmrf_handle* h, int32_t* n);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
 /* Shader clock under load: _start launches a bounded probe (8 waves stamping s_memtime / s_memrealtime every ~3.4 us x sleeps,
  * n samples) on a stream of its own and returns; run the load under test; _finish waits and returns n - 1 interval clocks in GHz

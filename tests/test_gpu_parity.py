@@ -1137,6 +1137,26 @@ def test_left_looking_panels_of_batches(pkg):
     assert np.max(np.abs(np.tril(Fb.chos[2]) - Fo.chos[2])) / np.max(np.abs(Fo.chos[2])) < TOL_FACTOR
 
 
+def test_persistent_launch_abort_falls_back(pkg):
+    """The safety net of the persistent launches (potrf_persist.hpp): every wait is bounded; a wait that gives up raises the abort
+    word, every workgroup drains, `factor_finish` sees the word and repeats the numeric phase with the launch-per-step form, which
+    the handle then keeps.  Forced here in a child process with GMRF_PERSIST_SPIN_MS=0 (the first wait that has to wait gives up):
+    one problem (a launch per block) and a batch of two (a launch per 256-column panel) must report the abort once and return
+    bitwise what the other form returns -- and the flag words must be clean for whatever runs next (the last workgroup out
+    zeroes them also when the launch was aborted)."""
+    import json
+    import subprocess
+    import sys
+    env = dict(_os.environ, GMRF_PERSIST_SPIN_MS="0")
+    r = subprocess.run([sys.executable, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "persist_abort_child.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["single_aborts_after_first"] == 1 and out["single_aborts_after_second"] == 1, out
+    assert out["single_aborts_of_the_step_form"] == 0 and out["single_equal"] and out["single_logdet_equal"], out
+    assert out["batch_aborts"] == 1 and out["batch_equal"] and out["batch_block_equal"], out
+
+
 def test_inverse_rows_inside_the_fused_steps(pkg):
     """One problem, blocks of up to 16 tiles: the inverse Linv_i is assembled row by row by extra workgroups of
     the fused panel-step launches (block forward substitution, X[r,c] = -X_rr sum_p L[r,p] X[p,c]) instead of by
