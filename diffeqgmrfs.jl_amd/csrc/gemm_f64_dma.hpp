@@ -30,6 +30,7 @@
 namespace gmrf {
 
 constexpr int DMA_BK = 16;
+constexpr int DMA_ROWS_ASCENDING = 1024;     // GemmArgs::tri bit set by the launcher: triangular grid walked from row tile 0 on
 #ifndef GMRF_DMA_READS_FIRST
 #define GMRF_DMA_READS_FIRST 0      // 1: a K step issues its fragment reads before the next tile's LDS-DMA requests (measured: see DESIGN.md)
 #endif
@@ -61,7 +62,9 @@ __device__ __forceinline__ void gemm_dma_tile_order(const GemmArgs& g, int& bm, 
         zq = q / tpp;
         // tiles of row bm: R (bm + 1); before it: R bm (bm + 1) / 2.  Longest rows first does not matter here (K is
         // the same for all tiles of a rank-k update; G2's staircase bounds grow with bm): rows in descending order.
-        const int tr = tpp - 1 - tile;
+        // (round 4) with staircase bounds K shrinks as bm grows -- K(bm, bn) = W - kst[bm] for bn <= bm -- so ascending rows ARE
+        // longest first, and the descending order used to leave every problem group's longest tile, (0, 0), for the very end
+        const int tr = (g.tri & DMA_ROWS_ASCENDING) ? tile : tpp - 1 - tile;
         int b = (int)((sqrtf(8.0f * (float)(tr / R) + 1.0f) - 1.0f) * 0.5f);
         while (R * b * (b + 1) / 2 > tr) --b;
         while (R * (b + 1) * (b + 2) / 2 <= tr) ++b;
@@ -373,6 +376,8 @@ inline bool gemm_try_dma(hipStream_t st, bool a_t, bool b_n, const GemmArgs& g, 
     const bool tri_grid = g.lower_only && g.M == g.N;
     GemmArgs gs = g;
     gs.lower_only = tri_grid ? 1 : (g.lower_only ? 2 : 0);
+    static const bool asc_off = [] { const char* e = getenv("GMRF_GEMM_G2_ORDER"); return e && atoi(e) == 0; }();   // tuning aid
+    if (tri_grid && (g.kb_m || g.kb_n) && !asc_off) gs.tri |= DMA_ROWS_ASCENDING;
     const int stages = gemm_dma_stages();
     const dim3 block(256);
 #define GMRF_DMA_GO(BM, BN)                                                                                       \
