@@ -150,7 +150,9 @@ gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int
  * EXACT: block-tridiagonal selected inversion (deterministic); serves a batch too, var_out is then
  *        [batch][n].
  * RBMC:  Rao-Blackwellised Monte Carlo over k Philox samples, needs Q (the factored matrix).
- * MC:    plain Monte Carlo over k samples. */
+ * MC:    plain Monte Carlo over k samples.
+ * var_out (here and in the batch call below): host or DEVICE memory -- a device pointer keeps the variances on the device (no
+ * copy out; the call still returns after the handle's stream has finished). */
 gmrf_status gmrf_bt_marginal_var(gmrf_handle* h, int32_t method, int64_t k, uint64_t seed,
                                  const gmrf_csr* Q, double* var_out);
 
