@@ -327,16 +327,17 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
             vs[pa + j + 2 * row] = ok ? vals[e0 + ea + j] : 0.0;
         }
     }
-    // Two chunks of X are in flight (round 4: one was -- a chunk's multiply is ~300 cycles, far less than the latency of the
-    // gather issued just before it, so every chunk still waited ~1.5 us for its operands): g0 / g1 alternate; a buffer is
-    // requested again as soon as its chunk has been written to LDS.
-    double g0[16], g1[16];
-    auto gather = [&](int c0, double (&g)[16]) {
+    // (Round 4 tried TWO chunks of X in flight -- g0 / g1 alternating, a buffer requested again as soon as its chunk is in LDS --
+    //  on the theory that a chunk's ~300-cycle multiply cannot cover the latency of the gather issued just before it: 112.9 ->
+    //  118.4 us per launch of 64 problems in the same 1-stream trace, 144 VGPRs.  The gather is not latency-bound; not kept.)
+    double g[16];
+    auto gather = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc)      // X = L^-1 is lower triangular: entries right of the diagonal are exact zeros, not fetched
             g[cc] = (ucol >= 0 && ucol <= c0 + cc) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
     };
-    auto chunk = [&](int c0, double (&g)[16]) {
+    gather(cbeg);
+    for (int c0 = cbeg; c0 < cend; c0 += 16) {
         if (t < U) {
             // row t of the staged image: slot s (columns 2 s, 2 s + 1 of the chunk = lane kq = s >> 1, half s & 1 ->
             // logical slot (half << 2 | kq)) at position logical ^ swizzle(t); swizzle keeps both the 16 rows a
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         int live = 1 << 30;
         if (a.skip_dead) live = __syncthreads_count(t < U && ucol <= c0 + 15);
         else __syncthreads();
-        if (c0 + 32 < cend) gather(c0 + 32, g);              // this buffer's next chunk: in flight over two multiplies
+        if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
         v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
         for (int e = pp[row]; e < pp[row + 1]; e += 4) {
             const uint2 q = *reinterpret_cast<const uint2*>(ls + e);
@@ -380,12 +381,6 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         *reinterpret_cast<v2d*>(cp) = a01;
         *reinterpret_cast<v2d*>(cp + 2) = a23;
         __syncthreads();
-    };
-    gather(cbeg, g0);
-    if (cbeg + 16 < cend) gather(cbeg + 16, g1);
-    for (int c0 = cbeg; c0 < cend; c0 += 32) {
-        chunk(c0, g0);
-        if (c0 + 16 < cend) chunk(c0 + 16, g1);
     }
 }
 
