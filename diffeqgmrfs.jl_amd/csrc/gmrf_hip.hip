@@ -816,8 +816,12 @@ static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* 
     pa.pS = h->bsp * h->bsp; pa.pL = stride_pL(h); pa.pX = stride_pX(h); pa.blk_per_problem = (int)h->N;
     pa.flags = h->d_pflags; pa.flag_stride = words;
     pa.abort_word = reinterpret_cast<unsigned*>(h->d_info + 1);
-    static const unsigned limit = [] { const char* e = getenv("GMRF_PERSIST_SPIN_MS"); return (unsigned)(e ? atoi(e) : 2000) * 100000u; }();   // 100 MHz ticks
-    pa.spin_limit = limit;
+    // Bound of every wait, in ticks of the 100 MHz clock: 2 s for one problem; 200 ms for a batch -- several handles' launches
+    // can ask for more workgroups than the chip has CUs (each must be resident as a whole), and if they ever hold each other's
+    // CUs the handles should learn it soon, drain, and go on with the other route (a launch lasts 60 us; a wait that is
+    // honest ends within a few GEMM launches of another stream).
+    static const int limit_ms = [] { const char* e = getenv("GMRF_PERSIST_SPIN_MS"); return e ? atoi(e) : -1; }();
+    pa.spin_limit = (unsigned)(limit_ms >= 0 ? limit_ms : (h->B > 1 ? 200 : 2000)) * 100000u;
     pa.stamps = h->dbg_stamps;
     ProfScope ps(h, 1, flops);
     hipLaunchKernelGGL(potrf_persist<false>, dim3(1 + persist_tiles(nt, j0, j1, xrows), (unsigned)h->B), dim3(256), POTRF_PERSIST_LDS,
@@ -948,18 +952,18 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
             return GMRF_OK;
         }
-        // Small batches (round 4): 9 workgroups per problem fit the chip up to a batch of 28, and then the panel's whole
+        // Small batches (round 4): 8 workgroups per problem fit the chip up to a batch of 32, and then the panel's whole
         // 256 x 256 diagonal block -- two potrf_diag128 launches and the four 128^3 products -- is ONE persistent launch
-        // (potrf_persist on the 4 x 4 tiles of the block, inverse rows included): 55 us instead of ~109 us per panel, on
-        // 9 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
-        // the one-workgroup kernels: their chain hides behind the other problems, and 9 B workgroups of 140 KB would not fit.
+        // (potrf_persist on the 4 x 4 tiles of the block, inverse rows included): 62 us instead of ~100 us per panel, on
+        // 8 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
+        // the one-workgroup kernels: their chain hides behind the other problems, and 8 B workgroups of 140 KB would not fit.
         static const bool no_small = [] { const char* e = getenv("GMRF_PERSIST_PANELS"); return e && atoi(e) == 0; }();   // tuning aid
-        const bool persist_panels = !no_small && !h->no_persist_panels && h->gemm128 && persist_fits(h, 4, 0, 4, 1);
+        const bool persist_panels = !no_small && !h->no_persist_panels && h->gemm128 && persist_fits(h, 4, 0, 4, 2);
         for (int j = 0; j < nt; j += 4) {
             const int64_t oa = (int64_t)j * 64, ob = oa + 128, oc = oa + 256;
             if (persist_panels) {
                 const double fl = (4.0 * t3 / 3.0 + 2.0 * t3 * (6.0 * 0.625 + 10.0 + 10.0 + 6.0 * 0.625)) * nb;
-                GCHK(launch_persist(h, S + oa * ld + oa, L + oa * ld + oa, X + oa * ld + oa, 4, 0, 4, 1, blk_id, fl));
+                GCHK(launch_persist(h, S + oa * ld + oa, L + oa * ld + oa, X + oa * ld + oa, 4, 0, 4, 2, blk_id, fl));
             } else {
             GCHK(diag128(j));
             // The four 128^3 products of the panel -- L_BA = S_BA X_A^T, S_BB -= L_BA L_BA^T before the second diagonal block,

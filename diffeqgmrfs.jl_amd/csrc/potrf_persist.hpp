@@ -42,7 +42,7 @@ struct PersistArgs {
     int64_t ld;
     int nt;                 // tiles per dimension of the block
     int j0, j1;             // column tiles [j0, j1) of this launch (blocks of up to 16 tiles: 0, nt)
-    int xrows;              // 1: the rows of the block inverse are assembled here too (j0 = 0, j1 = nt)
+    int xrows;              // 1, 2: the rows of the block inverse are assembled here too (j0 = 0, j1 = nt); 2: column j0's tiles by the diagonal tiles' workgroups
     int tail_panel;         // 1 (larger blocks): the workgroups of the last column also form L[r, j1-1] for the rows below the panel
     int* info; int blk;
     int64_t pS, pL, pX; int blk_per_problem;
@@ -62,15 +62,33 @@ struct PersistArgs {
 __host__ __device__ inline int persist_flag_count(int nt) { return nt + 3 * nt * nt; }
 __host__ __device__ inline int persist_flag_words(int nt) { return (persist_flag_count(nt) + 1 + 3) & ~3; }
 
-// tiles owned by worker workgroups, column by column: column j0 (inverse only, when xrows), then c = j0+1 .. j1-1 with the
-// rows r = c+1 .. nt-1 and, from c = j0+2 on, the diagonal tile (c, c) (steps j0 .. c-2; step c-1 is the chain's)
+// tiles owned by worker workgroups, column by column: column j0 (inverse only, when xrows), then c = j0+1 .. j1-1 with the rows
+// r = c+1 .. nt-1 and, from c = j0+2 on, the diagonal tile (c, c) (steps j0 .. c-2; step c-1 is the chain's).
+// xrows == 2 (the 4 x 4 panel blocks of small batches): column j0 gets ONE workgroup, for the last row -- the inverse tiles
+// (c-1, j0) of the rows above are assembled by the workgroups of the diagonal tiles (c, c) once those are final (they have no
+// inverse tile of their own): 8 workgroups per problem instead of 9, so that four handles x batch 8 ask for exactly the 256 CUs
+// and not for 288 (elliptic512 4 x 8: 6.54 k -> 6.74 k solves/s).  Not for the blocks of one problem: there the sums of column
+// j0 are the long ones (c - 1 terms), and a workgroup that starts them only after its diagonal tile's last step ends the
+// launch late (darcy256: factor 16.1 -> 17.5 ms, measured).
 __host__ __device__ inline int persist_tiles(int nt, int j0, int j1, int xrows) {
     int n = 0;
-    for (int c = xrows ? j0 : j0 + 1; c < j1; ++c) n += nt - 1 - c + ((c >= j0 + 2) ? 1 : 0);
+    if (xrows == 2) n = (nt - 1 > j0) ? 1 : 0;
+    else if (xrows) n = nt - 1 - j0;
+    for (int c = j0 + 1; c < j1; ++c) n += nt - 1 - c + ((c >= j0 + 2) ? 1 : 0);
     return n;
 }
 __device__ __forceinline__ void persist_tile_of(int t, int nt, int j0, int j1, int xrows, int& r, int& c) {
-    for (c = xrows ? j0 : j0 + 1; c < j1; ++c) {
+    if (xrows == 2) {
+        if (nt - 1 > j0) {
+            if (t == 0) { r = nt - 1; c = j0; return; }
+            t -= 1;
+        }
+    } else if (xrows) {
+        const int cnt = nt - 1 - j0;
+        if (t < cnt) { r = j0 + 1 + t; c = j0; return; }
+        t -= cnt;
+    }
+    for (c = j0 + 1; c < j1; ++c) {
         const int first = (c >= j0 + 2) ? c : c + 1;
         const int cnt = nt - first;
         if (t < cnt) { r = first + t; return; }
@@ -546,7 +564,12 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             for (int q = 0; q < 4; ++q) Lg[(int64_t)(16 * wave + lq + 4 * q) * ld + 16 * Jb + li] = lr[Jb][q];
         return;
     }
-    if (!pa.xrows || r == c) return;
+    if (!pa.xrows) return;
+    if (r == c) {
+        if (pa.xrows != 2) return;
+        r = c - 1;                                         // a diagonal tile's workgroup: the inverse tile (c - 1, j0) is its second job
+        c = pa.j0;
+    }
 
     // ---------------------------------------------------------------------- tile (r, c) of the block inverse
     //   T = sum_{p = c}^{r-1} L[r, p] X[p, c]  (p ascending, k in the slot order of xrow_strip), X[r, c] = -X_rr T
