@@ -952,11 +952,11 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
             return GMRF_OK;
         }
-        // Small batches (round 4): 8 workgroups per problem fit the chip up to a batch of 32, and then the panel's whole
+        // Small batches (round 4): 7 workgroups per problem fit the chip up to a batch of 36, and then the panel's whole
         // 256 x 256 diagonal block -- two potrf_diag128 launches and the four 128^3 products -- is ONE persistent launch
         // (potrf_persist on the 4 x 4 tiles of the block, inverse rows included): 62 us instead of ~100 us per panel, on
-        // 8 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
-        // the one-workgroup kernels: their chain hides behind the other problems, and 8 B workgroups of 140 KB would not fit.
+        // 7 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
+        // the one-workgroup kernels: their chain hides behind the other problems, and 7 B workgroups of 140 KB would not fit.
         static const bool no_small = [] { const char* e = getenv("GMRF_PERSIST_PANELS"); return e && atoi(e) == 0; }();   // tuning aid
         const bool persist_panels = !no_small && !h->no_persist_panels && h->gemm128 && persist_fits(h, 4, 0, 4, 2);
         for (int j = 0; j < nt; j += 4) {

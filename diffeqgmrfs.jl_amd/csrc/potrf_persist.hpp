@@ -66,7 +66,7 @@ __host__ __device__ inline int persist_flag_words(int nt) { return (persist_flag
 // r = c+1 .. nt-1 and, from c = j0+2 on, the diagonal tile (c, c) (steps j0 .. c-2; step c-1 is the chain's).
 // xrows == 2 (the 4 x 4 panel blocks of small batches): column j0 gets ONE workgroup, for the last row -- the inverse tiles
 // (c-1, j0) of the rows above are assembled by the workgroups of the diagonal tiles (c, c) once those are final (they have no
-// inverse tile of their own): 8 workgroups per problem instead of 9, so that four handles x batch 8 ask for exactly the 256 CUs
+// inverse tile of their own): 7 workgroups per problem instead of 9, so that four handles x batch 8 ask for 224 of the 256 CUs
 // and not for 288 (elliptic512 4 x 8: 6.54 k -> 6.74 k solves/s).  Not for the blocks of one problem: there the sums of column
 // j0 are the long ones (c - 1 terms), and a workgroup that starts them only after its diagonal tile's last step ends the
 // launch late (darcy256: factor 16.1 -> 17.5 ms, measured).

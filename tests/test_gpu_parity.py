@@ -644,7 +644,7 @@ def test_two_level_panel_factor_of_batches(pkg):
     Fr.select_problem(0)
     assert 0 < np.max(np.abs(Fr.chos[63] - Fb.chos[63])) / np.max(np.abs(Fo.chos[63])) < 1e-12
     assert rel(Fr.solve_batch(rhs[:, None, :])[0, 0], O.ldiv(Fo, w.rhs)) < solve_tol(w)
-    # round 4: a batch this small (8 workgroups per problem fit the chip) factors the 256 x 256 diagonal block of every panel in
+    # round 4: a batch this small (7 workgroups per problem fit the chip) factors the 256 x 256 diagonal block of every panel in
     # ONE persistent launch (potrf_persist on the block's 4 x 4 tiles) instead of two potrf_diag128 launches and four 128^3
     # GEMMs; set_eager bit 15 keeps those, bit 14 then swaps the GEMMs for potrf_panel256 (one workgroup per problem; measured
     # slower).  Same factor and inverse up to rounding (the two one-workgroup / GEMM routes: bitwise -- the same k order in every
