@@ -14,6 +14,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <iterator>
 #include <cmath>
 #include <map>
 #include <chrono>
@@ -151,7 +152,8 @@ struct gmrf_handle {
     bool c_dirty = false;              // C must be re-zeroed (new pattern)
     int* d_lo_rowptr = nullptr;
     // tile plan of the sparse C = B X^T (spmm_bxt_tiles): per lower block and 64-row tile the distinct columns, per entry its index into them
-    int* d_bxt_uptr = nullptr; int* d_bxt_ucols = nullptr; uint16_t* d_bxt_lidx = nullptr;
+    int* d_bxt_uptr = nullptr; int* d_bxt_ucols = nullptr; uint16_t* d_bxt_lidx = nullptr; int* d_bxt_gtiles = nullptr;
+    std::vector<int> bxt_ng;           // groups of row tiles per lower block (host copy: the launch's grid)
     int bxt_ecap = 0; int bxt_nrt = 0; bool bxt_plan_ok = false;        // [N][bsp + 1] row-wise view of the lower blocks' entry lists
     int64_t lo_row_max = 0;            // most entries in one row of a lower block
     bool sparse_b = false;             // lower blocks are sparse enough for C = B X^T by spmm_bxt
@@ -521,7 +523,10 @@ struct SymbolicPlan {
     std::vector<int> rowptr;               // [N][bsp + 1]
     int64_t max_row = 0;
     bool sparse_b = false, bxt_ok = false;
-    std::vector<int> uptr, ucols;
+    // tile plan of spmm_bxt_tiles, by GROUPS of up to three 64-row tiles of a lower block whose entries meet (mostly) the same
+    // columns of X (round 4): per block the groups' tiles gtiles[N][nrt][3] (-1: none) and their count ng[N]; per group the
+    // distinct columns (uptr[N][nrt + 1] into ucols), per entry its index into its group's list
+    std::vector<int> uptr, ucols, gtiles, ng;
     std::vector<uint16_t> lidx;
     int ecap = 0, nrt = 0;
 };
@@ -574,32 +579,66 @@ static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector
     sp.sparse_b = keys.size() < ((size_t)1 << 31) && max_row <= 32 && bsp >= 64;
     // tile plan for spmm_bxt_tiles (rows of the lower blocks are sorted by (row, column): a 64-row tile is a contiguous
     // range of entries)
-    sp.bxt_ok = false; sp.uptr.clear(); sp.ucols.clear(); sp.lidx.clear();
+    sp.bxt_ok = false; sp.uptr.clear(); sp.ucols.clear(); sp.lidx.clear(); sp.gtiles.clear(); sp.ng.clear();
     if (sp.sparse_b && N > 1) {
+        // Row tiles whose entries meet the same columns share ONE gathered chunk of X inside a workgroup (a stencil block: the
+        // tiles of mesh rows 2 and 3 of a block meet subsets of the columns the tile of mesh row 1 above them meets -- darcy256:
+        // 195 + 129 + 64 gathered columns become 195).  Greedy: a tile joins the group of an earlier tile when at least half of
+        // its columns are already there and the union still fits one thread per column.
+        static const bool no_groups = [] { const char* e = getenv("GMRF_BXT_GROUPS"); return e && atoi(e) == 0; }();   // tuning aid: every tile alone
         const int nrt = (int)(sp.rmax / 64);
         sp.uptr.assign((size_t)(N * (nrt + 1)), 0);
+        sp.gtiles.assign((size_t)(N * nrt * 3), -1);
+        sp.ng.assign((size_t)N, 0);
         sp.lidx.assign(std::max<size_t>(keys.size(), 1), 0);
-        std::vector<int> tmp;
+        std::vector<std::vector<int>> cols((size_t)nrt);
+        std::vector<int> uni, tmp;
         bool ok = true;
         int64_t pmax = 0;
         for (int64_t i = 1; i < N && ok; ++i) {
             const int* rp = sp.rowptr.data() + i * (bsp + 1);
-            for (int rt = 0; rt < nrt && ok; ++rt) {
-                const int ea = rp[rt * 64], eb = rp[rt * 64 + 64];
-                tmp.clear();
-                for (int e = ea; e < eb; ++e) tmp.push_back((int)(keys[(size_t)e] & 0xffffffffu));
-                std::sort(tmp.begin(), tmp.end());
-                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-                if ((int)tmp.size() > BXT_UCAP) { ok = false; break; }
-                for (int e = ea; e < eb; ++e)
-                    sp.lidx[(size_t)e] = (uint16_t)(std::lower_bound(tmp.begin(), tmp.end(), (int)(keys[(size_t)e] & 0xffffffffu)) - tmp.begin());
-                sp.uptr[(size_t)(i * (nrt + 1) + rt)] = (int)sp.ucols.size();
-                sp.ucols.insert(sp.ucols.end(), tmp.begin(), tmp.end());
-                int64_t padded = 0;
-                for (int r = rt * 64; r < rt * 64 + 64; ++r) padded += (rp[r + 1] - rp[r] + 7) / 8 * 8;
-                pmax = std::max(pmax, padded);
+            for (int rt = 0; rt < nrt; ++rt) {
+                auto& c = cols[(size_t)rt];
+                c.clear();
+                for (int e = rp[rt * 64]; e < rp[rt * 64 + 64]; ++e) c.push_back((int)(keys[(size_t)e] & 0xffffffffu));
+                std::sort(c.begin(), c.end());
+                c.erase(std::unique(c.begin(), c.end()), c.end());
+                if ((int)c.size() > BXT_UCAP) ok = false;
             }
-            sp.uptr[(size_t)(i * (nrt + 1) + nrt)] = (int)sp.ucols.size();
+            if (!ok) break;
+            std::vector<char> taken((size_t)nrt, 0);
+            int g = 0;
+            for (int rt = 0; rt < nrt; ++rt) {
+                if (taken[(size_t)rt]) continue;
+                int* gt = sp.gtiles.data() + ((size_t)i * nrt + g) * 3;
+                int cnt = 0;
+                gt[cnt++] = rt; taken[(size_t)rt] = 1;
+                uni = cols[(size_t)rt];
+                for (int u = rt + 1; u < nrt && cnt < 3 && !no_groups; ++u) {
+                    if (taken[(size_t)u] || cols[(size_t)u].empty()) continue;
+                    tmp.clear();
+                    std::set_union(uni.begin(), uni.end(), cols[(size_t)u].begin(), cols[(size_t)u].end(), std::back_inserter(tmp));
+                    const size_t common = uni.size() + cols[(size_t)u].size() - tmp.size();
+                    if (2 * common >= cols[(size_t)u].size() && tmp.size() <= (size_t)BXT_UCAP) {
+                        gt[cnt++] = u; taken[(size_t)u] = 1;
+                        uni.swap(tmp);
+                    }
+                }
+                int64_t padded = 0;
+                for (int q = 0; q < cnt; ++q) {
+                    const int t = gt[q];
+                    for (int e = rp[t * 64]; e < rp[t * 64 + 64]; ++e)
+                        sp.lidx[(size_t)e] = (uint16_t)(std::lower_bound(uni.begin(), uni.end(), (int)(keys[(size_t)e] & 0xffffffffu)) - uni.begin());
+                    for (int r = t * 64; r < t * 64 + 64; ++r) padded += (rp[r + 1] - rp[r] + 3) / 4 * 4;     // (the kernel pads a row to turns of 4 entries)
+                }
+                pmax = std::max(pmax, padded);
+                sp.uptr[(size_t)(i * (nrt + 1) + g)] = (int)sp.ucols.size();
+                sp.ucols.insert(sp.ucols.end(), uni.begin(), uni.end());
+                ++g;
+            }
+            sp.uptr[(size_t)(i * (nrt + 1) + g)] = (int)sp.ucols.size();
+            for (int q = g + 1; q <= nrt; ++q) sp.uptr[(size_t)(i * (nrt + 1) + q)] = (int)sp.ucols.size();
+            sp.ng[(size_t)i] = g;
         }
         const int ecap = (int)std::max<int64_t>(64, (pmax + 63) / 64 * 64);
         if (ok && bxt_tile_lds_bytes(ecap) <= 53 * 1024) { sp.bxt_ok = true; sp.ecap = ecap; sp.nrt = nrt; }
@@ -638,9 +677,12 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
     HIPCHK(hipStreamSynchronize(h->stream));
     h->lo_row_max = sp.max_row;
     h->sparse_b = sp.sparse_b;
-    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
-    h->d_bxt_uptr = nullptr; h->d_bxt_ucols = nullptr; h->d_bxt_lidx = nullptr; h->bxt_plan_ok = false;
+    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx); free_dev(h->d_bxt_gtiles);
+    h->d_bxt_uptr = nullptr; h->d_bxt_ucols = nullptr; h->d_bxt_lidx = nullptr; h->d_bxt_gtiles = nullptr; h->bxt_plan_ok = false;
     if (sp.bxt_ok) {
+        HIPCHK(hipMalloc(&h->d_bxt_gtiles, sp.gtiles.size() * sizeof(int)));
+        HIPCHK(hipMemcpyAsync(h->d_bxt_gtiles, sp.gtiles.data(), sp.gtiles.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+        h->bxt_ng = sp.ng;
         HIPCHK(hipMalloc(&h->d_bxt_uptr, sp.uptr.size() * sizeof(int)));
         HIPCHK(hipMalloc(&h->d_bxt_ucols, std::max<size_t>(sp.ucols.size(), 1) * sizeof(int)));
         HIPCHK(hipMalloc(&h->d_bxt_lidx, sp.lidx.size() * sizeof(uint16_t)));
@@ -1214,14 +1256,29 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                     BxtTileArgs ta;
                     ta.rowptr = ba.rowptr; ta.lidx = h->d_bxt_lidx; ta.vals = h->d_vals; ta.n_entries = h->n_entries;
                     ta.uptr = h->d_bxt_uptr + i * (h->bxt_nrt + 1); ta.ucols = h->d_bxt_ucols;
+                    ta.gtiles = h->d_bxt_gtiles + i * h->bxt_nrt * 3; ta.ng = h->bxt_ng[(size_t)i];
                     ta.X = Xp; ta.C = C; ta.ld = ld; ta.ldc = ldc; ta.pX = pX; ta.pC = pC; ta.kst = h->d_kst;
                     ta.cm = cm; ta.rm = rm; ta.bsp = bsp; ta.ecap = h->bxt_ecap;
                     static const bool live_skip = [] { const char* e = getenv("GMRF_BXT_LIVE"); return e && atoi(e) != 0; }();   // tuning aid (measured: 4.1 vs 3.9 ms per step, off)
                     ta.skip_dead = live_skip ? 1 : 0;
-                    const int chunks = W / 16, nrt = rm / 64;
-                    ta.nch = (int)std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)chunks * nrt * nb / 512));
+                    const int chunks = W / 16, ng = ta.ng;
+                    // 16-column chunks per workgroup: the launch should be a whole number of rounds over the 3 workgroups a CU
+                    // holds (measured, darcy256 x 64, 4 groups x 48 chunks: 16 chunks = 768 workgroups = one round 85 us; 8 =
+                    // two rounds 96 us; 12 = 1.33 rounds 108 us; 24 = 2/3 round 99 us): rounds x (chunks + ~2 for the prologue)
+                    static const int nch_env = [] { const char* e = getenv("GMRF_BXT_NCH"); return e ? atoi(e) : 0; }();   // tuning aid
+                    {
+                        const int64_t slots = 3 * (int64_t)std::max(h->cu_count, 1);
+                        int best = 1; int64_t best_cost = INT64_MAX;
+                        for (int c : {1, 2, 3, 4, 6, 8, 12, 16, 24, 48}) {
+                            if (c > chunks) break;
+                            const int64_t wgs = (int64_t)((chunks + c - 1) / c) * ng * nb;
+                            const int64_t cost = ((wgs + slots - 1) / slots) * (c + 2);
+                            if (cost < best_cost || (cost == best_cost && c < best)) { best = c; best_cost = cost; }
+                        }
+                        ta.nch = nch_env > 0 ? std::min(nch_env, chunks) : best;
+                    }
                     const int ncg = (chunks + ta.nch - 1) / ta.nch;
-                    hipLaunchKernelGGL(spmm_bxt_tiles, dim3((unsigned)(ncg * nrt * (int)nb)), dim3(256), bxt_tile_lds_bytes(h->bxt_ecap),
+                    hipLaunchKernelGGL(spmm_bxt_tiles, dim3((unsigned)(ncg * ng * (int)nb)), dim3(256), bxt_tile_lds_bytes(h->bxt_ecap),
                                        h->stream, ta);
                 }
                 else if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);
@@ -1619,7 +1676,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     free_dev(h->d_lo_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
-    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx);
+    free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx); free_dev(h->d_bxt_gtiles);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
@@ -4137,6 +4194,7 @@ gmrf_status gmrf_test_symbolic_csc(int64_t n, int64_t n_blocks, const int64_t* c
     for (int64_t v : sp.src) mix((uint64_t)v);
     for (int v : sp.rowptr) mix((uint64_t)(uint32_t)v);
     for (int v : sp.uptr) mix((uint64_t)(uint32_t)v);
+    for (int v : sp.gtiles) mix((uint64_t)(uint32_t)v);
     for (int v : sp.ucols) mix((uint64_t)(uint32_t)v);
     for (uint16_t v : sp.lidx) mix(v);
     for (int64_t v : sp.first) mix((uint64_t)v);

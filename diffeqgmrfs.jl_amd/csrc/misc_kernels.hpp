@@ -247,94 +247,122 @@ __global__ __launch_bounds__(256) void spmm_bxt(BxtArgs a) {
 // swizzled 128-byte LDS rows [u][16] and then runs the multiply phase of csr_spmm_tiles_pad: lane (row, kq) owns the
 // columns 4 kq .. 4 kq + 3 of the chunk, entries padded to multiples of 4 per row (aligned 8-byte index / 16-byte value
 // reads), fixed CSR summation order -- the results are bitwise those of spmm_bxt.  C leaves as 128-byte lines.
+// Round 4: a workgroup serves a GROUP of up to three row tiles of the block that meet (mostly) the same columns of X -- in a
+// stencil block the tiles of the second and third mesh row of a block meet subsets of what the tile of the first mesh row above
+// them meets -- so ONE gathered chunk is multiplied by up to 192 rows instead of 64 (darcy256: 388 gathered columns per chunk
+// position become 195: half the L2 -> CU traffic the round-3 review measured, 620 MB per launch).  Every tile keeps its own
+// staircase start (a chunk left of it is skipped for that tile) and its rows' entry order: bitwise the results of spmm_bxt.
 struct BxtTileArgs {
     const int* rowptr;        // this block's [bsp + 1] row pointers (absolute entry indices)
-    const uint16_t* lidx;     // per entry (absolute index): position of its column in the tile's list
+    const uint16_t* lidx;     // per entry (absolute index): position of its column in its GROUP's list
     const double* vals;       // [problems][n_entries]
     int64_t n_entries;
-    const int* uptr;          // this block's [nrt + 1] offsets into ucols
-    const int* ucols;         // distinct columns (0-based inside the block), ascending per tile
+    const int* gtiles;        // this block's [ng][3] row tiles of every group (-1: none)
+    int ng;                   // groups of this block
+    const int* uptr;          // this block's [ng + 1] offsets into ucols
+    const int* ucols;         // distinct columns (0-based inside the block), ascending per group
     const double* X;
     double* C;
     int64_t ld, ldc, pX, pC;
     const int* kst;
     int cm, rm, bsp;
     int nch;                  // 16-column chunks per workgroup
-    int ecap;                 // padded entries per tile (LDS capacity, multiple of 8)
+    int ecap;                 // padded entries per group (LDS capacity, multiple of 8)
     int skip_dead;            // leave a row's multiply loop at the first turn that only meets zero rows of the staged image
 };
 
-constexpr int BXT_UCAP = 256;             // distinct columns per tile (one per thread)
+constexpr int BXT_UCAP = 256;             // distinct columns per group (one per thread)
+constexpr int BXT_GT = 3;                 // row tiles per group
 
 inline size_t bxt_tile_lds_bytes(int ecap) {
-    return (size_t)BXT_UCAP * 16 * 8 + (size_t)ecap * 10 + 128 * 8 + (size_t)BXT_UCAP * 4 + (size_t)(2 * 64 + 2) * 4 + 16;
+    return (size_t)BXT_UCAP * 16 * 8 + (size_t)ecap * 10 + BXT_GT * 128 * 8 + (size_t)BXT_UCAP * 4 + (size_t)BXT_GT * (2 * 64 + 2) * 4 + 16;
 }
 
 __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* xs = smem;                                       // [BXT_UCAP][16], swizzled
-    double* vs = xs + BXT_UCAP * 16;                         // [ecap + 128]  (row r skewed by 2 r doubles, see csr_spmm_tiles_pad)
-    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + a.ecap + 128); // [ecap]
+    double* vs = xs + BXT_UCAP * 16;                         // [ecap + 3 * 128]  (row r of tile slot s skewed by 2 r + 128 s doubles, see csr_spmm_tiles_pad)
+    uint16_t* ls = reinterpret_cast<uint16_t*>(vs + a.ecap + BXT_GT * 128); // [ecap]
     int* uc = reinterpret_cast<int*>(ls + a.ecap);           // [BXT_UCAP]
-    int* rp = uc + BXT_UCAP;                                 // [65]
-    int* pp = rp + 65;                                       // [65]
+    int* rp = uc + BXT_UCAP;                                 // [3][65]: a row's first entry, relative to its tile's first
+    int* pp = rp + BXT_GT * 65;                              // [3][65]: a row's first PADDED entry in the group's staged list
     const int t = threadIdx.x;
-    const int nrt = a.rm / 64;
     const int W = a.bsp - a.cm;
     const int ncg = (W / 16 + a.nch - 1) / a.nch;
-    const int nprob = (int)gridDim.x / (ncg * nrt);
-    int cg, rt, prob;
+    const int nprob = (int)gridDim.x / (ncg * a.ng);
+    int cg, g, prob;
     {
         const int groups = (nprob % 8 == 0) ? 8 : 1;
         const int xg = (int)blockIdx.x % groups, q = (int)blockIdx.x / groups;
-        rt = q % nrt;
-        cg = (q / nrt) % ncg;
-        prob = xg + groups * (q / (nrt * ncg));
+        g = q % a.ng;
+        cg = (q / a.ng) % ncg;
+        prob = xg + groups * (q / (a.ng * ncg));
     }
-    const int r0 = rt * 64;
-    const int cfirst = a.cm + (a.kst ? a.kst[rt] : 0);
+    int tile[BXT_GT], cst[BXT_GT], e0s[BXT_GT];
+    int nT = 0, cmin_g = 1 << 30;
+#pragma unroll
+    for (int s = 0; s < BXT_GT; ++s) {
+        tile[s] = a.gtiles[g * BXT_GT + s];
+        if (tile[s] >= 0) nT = s + 1;
+        const int ts = tile[s] >= 0 ? tile[s] : 0;
+        // first chunk of tile s: the one its staircase start lies in (uniform per workgroup)
+        cst[s] = tile[s] >= 0 ? ((a.cm + (a.kst ? a.kst[ts] : 0)) / 16) * 16 : (1 << 30);
+        e0s[s] = a.rowptr[ts * 64];
+        cmin_g = min(cmin_g, cst[s]);
+    }
     int cbeg = a.cm + cg * a.nch * 16;
     const int cend = min(a.cm + W, cbeg + a.nch * 16);
-    cbeg = max(cbeg, (cfirst / 16) * 16);
-    if (cbeg >= cend) return;                                // whole column group left of the staircase (uniform per workgroup)
+    cbeg = max(cbeg, cmin_g);
+    if (cbeg >= cend) return;                                // whole column group left of every tile's staircase (uniform per workgroup)
     const double* __restrict__ X = a.X + (int64_t)prob * a.pX;
     double* __restrict__ C = a.C + (int64_t)prob * a.pC;
     const double* __restrict__ vals = a.vals + (int64_t)prob * a.n_entries;
-    const int e0 = a.rowptr[r0];
-    if (t < 64) {                                            // padded row starts: one wave scans
-        const int ea = a.rowptr[r0 + t] - e0, eb = a.rowptr[r0 + t + 1] - e0;
-        int x = (eb - ea + 3) & ~3;                          // rows padded to turns of 4 entries (FEM coupling rows are short: 9 / 4 / 1 entries on the darcy mesh)
+    if (t < 64 * BXT_GT) {                                   // padded row starts: wave s scans tile slot s
+        const int s = t >> 6, r = t & 63;
+        if (s < nT && tile[s] >= 0) {
+            const int r0 = tile[s] * 64;
+            const int ea = a.rowptr[r0 + r] - e0s[s], eb = a.rowptr[r0 + r + 1] - e0s[s];
+            int x = (eb - ea + 3) & ~3;                      // rows padded to turns of 4 entries (FEM coupling rows are short: 9 / 4 / 1 entries on the darcy mesh)
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int y = __shfl_up(x, d, 64);
-            if (t >= d) x += y;
+            for (int d = 1; d < 64; d <<= 1) {
+                const int y = __shfl_up(x, d, 64);
+                if (r >= d) x += y;
+            }
+            rp[s * 65 + r] = ea; pp[s * 65 + r + 1] = x;     // (pp: inclusive scan inside the tile; the tiles' bases are added below)
+            if (r == 63) rp[s * 65 + 64] = eb;
+            if (r == 0) pp[s * 65] = 0;
         }
-        rp[t] = ea; pp[t + 1] = x;
-        if (t == 63) rp[64] = eb;
-        if (t == 0) pp[0] = 0;
     }
-    const int u0 = a.uptr[rt];
-    const int U = a.uptr[rt + 1] - u0;
+    const int u0 = a.uptr[g];
+    const int U = a.uptr[g + 1] - u0;
     const int ucol = (t < U) ? a.ucols[u0 + t] : -1;
     __syncthreads();
+    int base[BXT_GT];                                        // first padded entry of tile slot s in the staged list
+    base[0] = 0;
+#pragma unroll
+    for (int s = 1; s < BXT_GT; ++s) base[s] = base[s - 1] + ((s - 1 < nT && tile[s - 1] >= 0) ? pp[(s - 1) * 65 + 64] : 0);
     const int kq = t & 3, row = t >> 2;
-    {   // entries of this thread's row, 4 lanes per row, padded with (value 0, the row's first index)
-        const int ea = rp[row], len = rp[row + 1] - ea, pa = pp[row], plen = pp[row + 1] - pa;
-        const uint16_t first = (len > 0) ? a.lidx[e0 + ea] : (uint16_t)0;
-        for (int j = kq; j < plen; j += 4) {
-            const bool ok = j < len;
-            ls[pa + j] = ok ? a.lidx[e0 + ea + j] : first;
-            vs[pa + j + 2 * row] = ok ? vals[e0 + ea + j] : 0.0;
+#pragma unroll
+    for (int s = 0; s < BXT_GT; ++s) {
+        if (s < nT && tile[s] >= 0) {   // entries of this thread's row of tile s, 4 lanes per row, padded with (value 0, the row's first index)
+            const int ea = rp[s * 65 + row], len = rp[s * 65 + row + 1] - ea;
+            const int pa = base[s] + pp[s * 65 + row], plen = pp[s * 65 + row + 1] - pp[s * 65 + row];
+            const uint16_t first = (len > 0) ? a.lidx[e0s[s] + ea] : (uint16_t)0;
+            for (int j = kq; j < plen; j += 4) {
+                const bool ok = j < len;
+                ls[pa + j] = ok ? a.lidx[e0s[s] + ea + j] : first;
+                vs[pa + j + 2 * row + 128 * s] = ok ? vals[e0s[s] + ea + j] : 0.0;
+            }
         }
     }
     // (Round 4 tried TWO chunks of X in flight -- g0 / g1 alternating, a buffer requested again as soon as its chunk is in LDS --
     //  on the theory that a chunk's ~300-cycle multiply cannot cover the latency of the gather issued just before it: 112.9 ->
     //  118.4 us per launch of 64 problems in the same 1-stream trace, 144 VGPRs.  The gather is not latency-bound; not kept.)
-    double g[16];
+    double gx[16];
     auto gather = [&](int c0) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc)      // X = L^-1 is lower triangular: entries right of the diagonal are exact zeros, not fetched
-            g[cc] = (ucol >= 0 && ucol <= c0 + cc) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
+            gx[cc] = (ucol >= 0 && ucol <= c0 + cc) ? X[(int64_t)(c0 + cc) * a.ld + ucol] : 0.0;
     };
     gather(cbeg);
     for (int c0 = cbeg; c0 < cend; c0 += 16) {
@@ -346,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {
                 const int logical = ((s2 & 1) << 2) | (s2 >> 1);
-                *reinterpret_cast<v2d*>(xs + t * 16 + 2 * (logical ^ swz)) = (v2d){g[2 * s2], g[2 * s2 + 1]};
+                *reinterpret_cast<v2d*>(xs + t * 16 + 2 * (logical ^ swz)) = (v2d){gx[2 * s2], gx[2 * s2 + 1]};
             }
         }
         // (first chunk: also the staged entries.)  live = distinct columns <= c0 + 15, i.e. staged rows that are not all zero:
@@ -355,31 +383,36 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         if (a.skip_dead) live = __syncthreads_count(t < U && ucol <= c0 + 15);
         else __syncthreads();
         if (c0 + 16 < cend) gather(c0 + 16);                 // in flight while this chunk is multiplied
-        v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
-        for (int e = pp[row]; e < pp[row + 1]; e += 4) {
-            const uint2 q = *reinterpret_cast<const uint2*>(ls + e);
-            if ((int)(q.x & 0xffffu) >= live) break;
-            const double* ve = vs + e + 2 * row;
-            const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
-            const int ii[4] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16)};
-            const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
-            v2d xa[4], xb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int swz = (((ii[u] >> 1) & 1) << 2) ^ ((ii[u] >> 2) & 3);
-                const int o = (ii[u] << 4) + 2 * (kq ^ swz);                 // in doubles: row * 16 + 2 * slot(kq, half 0)
-                xa[u] = *reinterpret_cast<const v2d*>(xs + o);
-                xb[u] = *reinterpret_cast<const v2d*>(xs + (o ^ 8));
-            }
+        for (int s = 0; s < BXT_GT; ++s) {
+            if (s >= nT || tile[s] < 0 || c0 < cst[s]) continue;      // (uniform per workgroup: this tile is zero left of its staircase)
+            v2d a01 = (v2d){0.0, 0.0}, a23 = (v2d){0.0, 0.0};
+            const int eb = base[s] + pp[s * 65 + row], ee = base[s] + pp[s * 65 + row + 1];
+            for (int e = eb; e < ee; e += 4) {
+                const uint2 q = *reinterpret_cast<const uint2*>(ls + e);
+                if ((int)(q.x & 0xffffu) >= live) break;
+                const double* ve = vs + e + 2 * row + 128 * s;
+                const v2d v01 = *reinterpret_cast<const v2d*>(ve), v23 = *reinterpret_cast<const v2d*>(ve + 2);
+                const int ii[4] = {(int)(q.x & 0xffffu), (int)(q.x >> 16), (int)(q.y & 0xffffu), (int)(q.y >> 16)};
+                const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+                v2d xa[4], xb[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a01.x = fma(vv[u], xa[u].x, a01.x); a01.y = fma(vv[u], xa[u].y, a01.y);
-                a23.x = fma(vv[u], xb[u].x, a23.x); a23.y = fma(vv[u], xb[u].y, a23.y);
+                for (int u = 0; u < 4; ++u) {
+                    const int swz = (((ii[u] >> 1) & 1) << 2) ^ ((ii[u] >> 2) & 3);
+                    const int o = (ii[u] << 4) + 2 * (kq ^ swz);                 // in doubles: row * 16 + 2 * slot(kq, half 0)
+                    xa[u] = *reinterpret_cast<const v2d*>(xs + o);
+                    xb[u] = *reinterpret_cast<const v2d*>(xs + (o ^ 8));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a01.x = fma(vv[u], xa[u].x, a01.x); a01.y = fma(vv[u], xa[u].y, a01.y);
+                    a23.x = fma(vv[u], xb[u].x, a23.x); a23.y = fma(vv[u], xb[u].y, a23.y);
+                }
             }
+            double* cp = C + (int64_t)(tile[s] * 64 + row) * a.ldc + (c0 - a.cm) + 4 * kq;
+            *reinterpret_cast<v2d*>(cp) = a01;
+            *reinterpret_cast<v2d*>(cp + 2) = a23;
         }
-        double* cp = C + (int64_t)(r0 + row) * a.ldc + (c0 - a.cm) + 4 * kq;
-        *reinterpret_cast<v2d*>(cp) = a01;
-        *reinterpret_cast<v2d*>(cp + 2) = a23;
         __syncthreads();
     }
 }

@@ -404,6 +404,27 @@ def test_sparse_and_dense_coupling_product_agree(pkg, name):
     assert rel(pkg.ldiv(F, wd.rhs), O.ldiv(O.tridiagonal_cholesky(wd.Q, wd.n_blocks), wd.rhs)) < 1e-12
 
 
+@pytest.mark.parametrize("name", ["darcy256", "burgers512x64"])
+def test_coupling_product_by_tile_groups(pkg, name):
+    """Round 4: spmm_bxt_tiles serves GROUPS of up to three 64-row tiles of a lower block that meet the same columns of X (one
+    gathered chunk multiplied by up to 192 rows).  The coupling blocks C_i of a batch must be bitwise what the same kernel gives
+    with every tile alone (GMRF_BXT_GROUPS=0) and what the row kernel gives (GMRF_BXT_TILES=0) -- a row's entries are summed in
+    the same order whoever gathers its operands.  The switches are read once per process: child processes."""
+    import json
+    import subprocess
+    import sys
+    child = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "bxt_child.py")
+
+    def run(**env):
+        r = subprocess.run([sys.executable, child, name], env=dict(_os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    grouped, alone, rows = run(), run(GMRF_BXT_GROUPS="0"), run(GMRF_BXT_TILES="0")
+    assert grouped == alone == rows
+    assert len(set(grouped.values())) == len(grouped)          # (six different blocks, not six times the same digest)
+
+
 def test_export_import_factor_round_trip(pkg):
     w = pkg.workloads.random_block_tridiagonal(5, 40, seed=9)      # bs 40: padded to 64 inside
     F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
