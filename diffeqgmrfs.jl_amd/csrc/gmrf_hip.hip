@@ -532,7 +532,7 @@ struct SymbolicPlan {
 };
 
 static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector<HostEntry>>& dg,
-                           const std::vector<std::vector<HostEntry>>& lo, bool no_staircase, SymbolicPlan& sp) {
+                           const std::vector<std::vector<HostEntry>>& lo, bool no_staircase, SymbolicPlan& sp, bool group_tiles = true) {
     sp.diag_first.assign((size_t)N, 0); sp.diag_count.assign((size_t)N, 0);
     sp.low_first.assign((size_t)N, 0); sp.low_count.assign((size_t)N, 0);
     auto& keys = sp.keys; auto& src = sp.src;
@@ -614,7 +614,7 @@ static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector
                 int cnt = 0;
                 gt[cnt++] = rt; taken[(size_t)rt] = 1;
                 uni = cols[(size_t)rt];
-                for (int u = rt + 1; u < nrt && cnt < 3 && !no_groups; ++u) {
+                for (int u = rt + 1; u < nrt && cnt < 3 && !no_groups && group_tiles; ++u) {
                     if (taken[(size_t)u] || cols[(size_t)u].empty()) continue;
                     tmp.clear();
                     std::set_union(uni.begin(), uni.end(), cols[(size_t)u].begin(), cols[(size_t)u].end(), std::back_inserter(tmp));
@@ -649,7 +649,9 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
                                   const std::vector<std::vector<HostEntry>>& lo, int64_t nnz_in) {
     const int64_t N = h->N;
     SymbolicPlan sp;
-    build_symbolic(N, h->bsp, dg, lo, h->no_staircase, sp);
+    // (tile groups for batches: one problem alone has too few workgroups as it is -- 48 chunks x 12 tiles = 576 of 768 slots -- and
+    //  a third of them doing three tiles' rows each is slower: 7.1 -> 9.7 us per block on darcy256)
+    build_symbolic(N, h->bsp, dg, lo, h->no_staircase, sp, h->B >= 8);
     h->diag_first = sp.diag_first; h->diag_count = sp.diag_count; h->low_first = sp.low_first; h->low_count = sp.low_count;
     const auto& keys = sp.keys; const auto& src = sp.src;
     GCHK(set_layout(h, sp.cmin, sp.rmax, sp.first));
