@@ -838,8 +838,8 @@ static int planned_xsplit(const gmrf_handle* h) {
     return (h->cmin >= 256 && p < bsp) ? p : 0;
 }
 
-// One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles: the flag words are zeroed by
-// a memset node ahead of it (re-initialised on every graph replay).  false: this shape does not fit the chip (every workgroup
+// One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles (its flag words are zero
+// between launches: the last workgroup out of a launch leaves them so).  false: this shape does not fit the chip (every workgroup
 // must be resident: 140 KB of LDS = one per CU) or the form is switched off.
 static bool persist_fits(const gmrf_handle* h, int nt, int j0, int j1, int xrows) {
     if (h->no_persist || h->cu_count <= 0) return false;
