@@ -39,7 +39,7 @@ EXPORTS = [
     "gmrf_shallow_water_p1_create", "gmrf_shallow_water_p1_destroy", "gmrf_shallow_water_p1_pattern", "gmrf_shallow_water_p1_qpoints",
     "gmrf_shallow_water_p1_assemble", "gmrf_shallow_water_p1_operators",
     "gmrf_assemble_create", "gmrf_assemble_destroy", "gmrf_assemble_pattern", "gmrf_assemble_precision", "gmrf_assemble_rhs",
-    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_gemm_shapes", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing", "gmrf_test_persist_stamps", "gmrf_test_persist_aborts", "gmrf_test_clock_probe_start", "gmrf_test_clock_probe_finish",
+    "gmrf_test_gemm", "gmrf_test_gemm_rate", "gmrf_test_gemm_shapes", "gmrf_test_potrf_tile", "gmrf_test_potrf_block", "gmrf_test_tile_timing", "gmrf_test_persist_stamps", "gmrf_test_persist_aborts", "gmrf_test_persist_budget", "gmrf_test_clock_probe_start", "gmrf_test_clock_probe_finish",
     "gmrf_test_mfma_f64_rate", "gmrf_test_hbm_rate", "gmrf_test_microbench", "gmrf_test_symbolic_csc",
 ]
 
@@ -56,6 +56,7 @@ class Stats(C.Structure):
         ("block_size_padded", C.c_int64), ("factor_bytes", C.c_int64),
         ("kernel_ms", C.c_double * 24), ("kernel_work", C.c_double * 24), ("kernel_launches", C.c_int64 * 24),
         ("sweep_bytes_streamed", C.c_double),
+        ("persist_route", C.c_int32), ("persist_aborts", C.c_int32), ("persist_cus", C.c_int32), ("persist_refused", C.c_int32),
     ]
 
 
@@ -178,6 +179,7 @@ def load() -> C.CDLL:
         "gmrf_test_tile_timing": [vp, i32],
         "gmrf_test_persist_stamps": [vp, i32],
         "gmrf_test_persist_aborts": [vp, vp],
+        "gmrf_test_persist_budget": [i32, i32, vp, vp],
         "gmrf_test_clock_probe_start": [i32, i32, i32, P(vp)],
         "gmrf_test_clock_probe_finish": [vp, vp, vp],
         "gmrf_test_mfma_f64_rate": [i32, P(dbl)],

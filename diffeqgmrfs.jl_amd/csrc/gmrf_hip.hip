@@ -32,7 +32,6 @@
 #include "misc_kernels.hpp"
 #include "potrf_step.hpp"
 #include "potrf_persist.hpp"
-#include "potrf_panel256.hpp"
 #include "sweep.hpp"
 #include "swe_assemble.hpp"
 #include "fem_assemble_p2.hpp"
@@ -41,7 +40,7 @@ using namespace gmrf;
 
 static thread_local std::string g_last_error;
 static double g_tile_us = 0.0;
-static unsigned long long g_tile_stamps[32];
+static unsigned long long g_tile_stamps[64];
 static unsigned long long g_persist_stamps[128];    // chain workgroup of the last gmrf_test_potrf_block (potrf_persist.hpp)
 
 #define HIPCHK(expr)                                                                        \
@@ -189,7 +188,6 @@ struct gmrf_handle {
     unsigned long long* dbg_stamps = nullptr;   // test hook: phase stamps of the fused panel step
     bool fork_graph = false;           // second branch in the captured factor graph (experiment, see potrf_block)
     bool no_staircase = false;         // treat the coupling window as dense (comparison; takes effect at the next analysis)
-    bool left_looking = false;         // batches: left-looking in-panel steps (tile + potrf_panel_ll) instead of tile, panel, update
     bool doubling_x = false;           // one problem: assemble Linv by recursive doubling after the steps (comparison) instead of row by row inside them
     // Split representation of the block inverses (batches whose coupling blocks are zero left of column cmin >= 256):
     // with p = xsplit, a = [0, p), b = [p, bsp), the storage of Linv_i holds X_aa, X_bb and -- in the place of
@@ -199,19 +197,20 @@ struct gmrf_handle {
     int adopt_xsplit = 0;              // what the layout record of an adopted factor said (committed by gmrf_bt_adopt_commit)
     bool no_xsplit = false;            // set_eager bit 12: always assemble the full inverse (comparison)
     bool no_lookahead = false;         // one problem: every fused step re-factors its diagonal tile (comparison) instead of the look-ahead chain
-    bool update_via_gemm = false;      // batches: in-panel rank-64 updates on the GEMM kernel (experiment)
-    bool panels128 = false;            // batches: rows below a diagonal block meet the 128 x 128 inverses one by one (K = 128 products; comparison)
     // One problem: the in-block Cholesky as ONE persistent launch per block / per 256-column panel (potrf_persist.hpp) instead of a
     // launch per 64-column step.  Needs every workgroup resident (1 + tiles <= CUs); a wait that gives up sets d_info[1], and
     // factor_finish then repeats the factorisation with the launch-per-step form and keeps it for this handle.
-    bool no_persist = false;           // set_eager bit 13, or a persistent launch gave up
+    bool no_persist = false;           // set_eager bit 13 / GMRF_PERSIST=0
+    bool persist_gave_up = false;      // a bounded wait inside a persistent launch gave up: this handle keeps the launch-per-step forms for good (set_eager cannot clear it)
+    bool persist_launched = false;     // a persistent launch was enqueued since the abort word was last looked at
+    int persist_cus = 0;               // CUs held of the device's budget (persist_plan); 0: no persistent launches
+    int info_checked = 0;              // d_info[0] as the host last saw it (restored when an aborted range is repeated)
+    int factor_graph_route = 0;        // stats.persist_route of the captured factor graph
     int persist_aborts = 0;
     int cu_count = 0;
     unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zero between launches: potrf_persist cleans up after itself)
     int64_t pflags_words = 0;
     bool no_persist_panels = false;    // batches small enough for it keep potrf_diag128 + the 128^3 products instead of one persistent launch per panel (set_eager bit 15)
-    bool gemm128 = true;               // batches: the 128^3 products of a 256-column panel as GEMM launches (default); false (set_eager bit 14): potrf_panel256, measured slower
-    bool rank64_panels = false;        // batches: the round-2 in-block Cholesky (tile, potrf_panel, potrf_update per 64 columns) instead of 128-column diagonal blocks (comparison)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
@@ -825,27 +824,105 @@ static gmrf_status fork_event(gmrf_handle* h, hipEvent_t* out) {
     return GMRF_OK;
 }
 
+// Which in-block Cholesky the next factorisation of this handle takes: the ONE route predicate (potrf_block follows it,
+// planned_xsplit asks it; round 5 -- the comparison routes that lost twice, left-looking panels, rank-64 panel steps of batches,
+// 128-column panels and the one-workgroup potrf_panel256, are gone, and with them four flags both places had to agree on by hand).
+enum PotrfRoute {
+    ROUTE_FUSED = 1,       // one problem, blocks of up to 16 tiles: ONE persistent launch per block, else one launch per 64-column step
+    ROUTE_BIG_ONE = 2,     // one problem, larger blocks: 256-column panels, each a persistent launch (or fused steps) + a rank-256 GEMM
+    ROUTE_PANELS256 = 3,   // batches: 256-column panels -- potrf_diag128 x 2 + 128^3 GEMMs, or one persistent launch per diagonal block -- + GEMM
+    ROUTE_STEPS = 4        // what is left (blocks of fewer than 4 tiles, tile counts not divisible by 4, the forked graph): tile, panel, update
+};
+static int potrf_route(const gmrf_handle* h) {
+    const int nt = (int)(h->bsp / 64);
+    if (h->B == 1 && !h->split_step) return nt <= 16 ? ROUTE_FUSED : ROUTE_BIG_ONE;
+    if (h->fork_graph && nt >= 8) return ROUTE_STEPS;
+    return (nt >= 4 && nt % 4 == 0) ? ROUTE_PANELS256 : ROUTE_STEPS;
+}
+
 // The split the next factorisation of this handle will use (0: none): only the 256-column panel route of batches
 // assembles the inverse level by level, and only a coupling window that starts at cmin >= 256 leaves a first block
 // column nobody multiplies with.  p = the largest power of two <= cmin (the doubling tree splits at powers of two).
 static int planned_xsplit(const gmrf_handle* h) {
     const int bsp = (int)h->bsp, nt = bsp / 64;
-    if (h->no_xsplit || h->N <= 0 || nt < 8 || nt % 4 != 0) return 0;
-    const bool lone_fused = (h->B == 1 && !h->split_step);
-    if (lone_fused || h->left_looking || h->rank64_panels || h->panels128 || h->fork_graph) return 0;
+    if (h->no_xsplit || h->N <= 0 || nt < 8 || potrf_route(h) != ROUTE_PANELS256) return 0;
     int p = 256;
     while (2 * p <= (int)h->cmin) p *= 2;
     return (h->cmin >= 256 && p < bsp) ? p : 0;
 }
 
-// One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles (its flag words are zero
-// between launches: the last workgroup out of a launch leaves them so).  false: this shape does not fit the chip (every workgroup
-// must be resident: 140 KB of LDS = one per CU) or the form is switched off.
-static bool persist_fits(const gmrf_handle* h, int nt, int j0, int j1, int xrows) {
-    if (h->no_persist || h->cu_count <= 0) return false;
+// ---- the device's budget of CUs for persistent launches (round 5) --------------------------------------------------------
+// Every workgroup of a potrf_persist launch must be resident at once (140 KB of LDS: one per CU).  One handle alone checks its
+// launch against the CU count; several handles' launches in flight together -- a StreamSet of batched handles, two one-problem
+// handles on two threads -- can together ask for more than the chip has, end up partially resident and starve each other until
+// their bounded waits give up (0.2 - 2 s each).  So a handle CLAIMS the CUs its widest persistent launch needs when it plans a
+// factorisation, the claims of a device never exceed its CU count, and a handle whose claim does not fit takes the launch-per-
+// step routes up front (stats: persist_refused).  A claim is held until the handle is destroyed, gives a launch up, or
+// re-plans with another shape: the route of a handle does not depend on what other handles happen to be doing at the moment.
+static std::mutex g_persist_mu;
+static std::map<int, std::map<const void*, int>> g_persist_claims;     // device -> handle -> CUs
+
+// `who` asks for `want` CUs of a device with `cus`: true and recorded when it fits beside the others' claims (want = 0 releases)
+static bool persist_budget_claim(std::map<const void*, int>& claims, const void* who, int want, int cus, int margin) {
+    int others = 0;
+    for (const auto& kv : claims) if (kv.first != who) others += kv.second;
+    if (want <= 0 || others + want + margin > cus) { claims.erase(who); return false; }
+    claims[who] = want;
+    return true;
+}
+
+static int potrf_route(const gmrf_handle* h);
+static const int& persist_margin() {
     static const int margin = [] { const char* e = getenv("GMRF_PERSIST_CU_MARGIN"); return e ? atoi(e) : 0; }();   // tuning aid
-    // (a batch: every problem brings its own set of workgroups and flag words; all of them must fit the chip at once)
-    return (int64_t)(1 + persist_tiles(nt, j0, j1, xrows)) * h->B + margin <= h->cu_count;
+    return margin;
+}
+// CUs the widest persistent launch of this handle's next factorisation needs at once (0: its route launches none)
+static int persist_demand(const gmrf_handle* h) {
+    if (h->no_persist || h->persist_gave_up || h->cu_count <= 0 || h->bsp < 128 || h->fork_graph) return 0;
+    const int nt = (int)(h->bsp / 64);
+    int64_t wgs = 0;
+    switch (potrf_route(h)) {
+        case 1 /* ROUTE_FUSED */: if (!h->no_lookahead && !h->doubling_x) wgs = 1 + persist_tiles(nt, 0, nt, 1); break;
+        case 2 /* ROUTE_BIG_ONE */: if (!h->no_lookahead) wgs = 1 + persist_tiles(nt, 0, std::min(nt, 4), 0); break;      // (the first panel is the widest)
+        case 3 /* ROUTE_PANELS256 */: {
+            static const bool no_small = [] { const char* e = getenv("GMRF_PERSIST_PANELS"); return e && atoi(e) == 0; }();   // tuning aid
+            if (!no_small && !h->no_persist_panels) wgs = 1 + persist_tiles(4, 0, 4, 2);
+            break;
+        }
+        default: break;
+    }
+    wgs *= h->B;
+    return wgs > 0 && wgs <= h->cu_count ? (int)wgs : 0;
+}
+// plan the persistent launches of the next factorisation: claim (or release) this handle's CUs
+static void persist_plan(gmrf_handle* h) {
+    const int want = persist_demand(h);
+    bool ok;
+    {
+        std::lock_guard<std::mutex> lock(g_persist_mu);
+        ok = persist_budget_claim(g_persist_claims[h->device], h, want, h->cu_count, persist_margin());
+    }
+    const int got = ok ? want : 0;
+    if (got != h->persist_cus) destroy_graphs(h);              // (a captured factor graph holds the launches of the old plan)
+    h->persist_cus = got;
+    h->stats.persist_cus = got;
+    h->stats.persist_refused = (want > 0 && !ok) ? 1 : 0;
+}
+static void persist_release(gmrf_handle* h) {
+    std::lock_guard<std::mutex> lock(g_persist_mu);
+    auto it = g_persist_claims.find(h->device);
+    if (it != g_persist_claims.end()) it->second.erase(h);
+    h->persist_cus = 0;
+    h->stats.persist_cus = 0;
+}
+
+// One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles (its flag words are zero
+// between launches: the last workgroup out of a launch leaves them so).  false: the handle holds no claim that covers this
+// shape (it does not fit the chip beside the other handles' launches, or the form is switched off).
+static bool persist_fits(const gmrf_handle* h, int nt, int j0, int j1, int xrows) {
+    if (h->no_persist || h->persist_gave_up || h->persist_cus <= 0) return false;
+    // (a batch: every problem brings its own set of workgroups and flag words; all of them must fit the claim at once)
+    return (int64_t)(1 + persist_tiles(nt, j0, j1, xrows)) * h->B <= h->persist_cus;
 }
 
 static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* X, int nt, int j0, int j1, int xrows, int blk_id,
@@ -867,8 +944,10 @@ static gmrf_status launch_persist(gmrf_handle* h, double* S, double* L, double* 
     static const int limit_ms = [] { const char* e = getenv("GMRF_PERSIST_SPIN_MS"); return e ? atoi(e) : -1; }();
     pa.spin_limit = (unsigned)(limit_ms >= 0 ? limit_ms : (h->B > 1 ? 200 : 2000)) * 100000u;
     pa.stamps = h->dbg_stamps;
-    ProfScope ps(h, 1, flops);
-    hipLaunchKernelGGL(potrf_persist<false>, dim3(1 + persist_tiles(nt, j0, j1, xrows), (unsigned)h->B), dim3(256), POTRF_PERSIST_LDS,
+    h->persist_launched = true;
+    h->stats.persist_route = xrows == 1 ? 1 : (xrows == 0 ? 2 : 3);
+    ProfScope ps(h, 17, flops);                        // (its own class: the rocprof symbol is potrf_persist, not potrf_step)
+    hipLaunchKernelGGL(potrf_persist<false>, dim3(1 + persist_tiles(nt, j0, j1, xrows), (unsigned)h->B), dim3(POTRF_PERSIST_THREADS), POTRF_PERSIST_LDS,
                        h->stream, pa);
     HIPCHK(hipGetLastError());
     return GMRF_OK;
@@ -884,13 +963,14 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     // one rounding at |S| instead of four).  A lone problem with blocks up to 1024 keeps the fused
     // one-launch step (43 ms against 48 ms on darcy256); beyond that the fused step's redundant
     // tile factorisations lose (bs = 4096: 4.45 s fused, 2.93 s two-level).
-    const bool fused = (h->B == 1 && !h->split_step && nt <= 16);
-    if (h->xsplit > 0 && (h->B == 1 && !h->split_step)) return bad_shape("internal: split inverse planned for the one-problem route");
+    const int route = potrf_route(h);
+    const bool fused = route == ROUTE_FUSED;
+    if (h->xsplit > 0 && route != ROUTE_PANELS256) return bad_shape("internal: split inverse planned off the 256-column panel route");
     static const int pw_env = [] { const char* e = getenv("GMRF_PANEL_TILES"); return e ? atoi(e) : 4; }();   // tuning aid
     const int pw = (!fused && nt >= 8) ? ((pw_env == 2 || pw_env == 8) ? pw_env : 4) : nt;           // panel width in tiles
     // a lone problem with larger blocks: two-level, with the fused kernel restricted to the panel's
     // own columns as the in-panel step (one launch instead of three where the panel has columns left)
-    const bool fused_in_panel = (h->B == 1 && !h->split_step && nt > 16);
+    const bool fused_in_panel = route == ROUTE_BIG_ONE;
     // Opt-in (set_eager bit 4): inside a captured graph the block forks once its first half is
     // factored: a second branch assembles the inverse of that half and the top-level product
     // T21 = L21 X11 (everything they read is final) while this branch runs the latency-bound panel
@@ -903,7 +983,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     if (overlap) { GCHK(fork_event(h, &ev_fork)); GCHK(fork_event(h, &ev_join)); }
     if (fused && !h->no_lookahead && !h->doubling_x && !overlap && nt >= 2 && persist_fits(h, nt, 0, nt, 1)) {
         // One problem, ONE launch per block: the look-ahead chain below with flags in place of its launch boundaries
-        // (potrf_persist.hpp; same arithmetic, bitwise the same factor and inverse)
+        // (potrf_persist.hpp)
         const double t3 = 64.0 * 64.0 * 64.0;
         double fl = t3 / 3.0 * nt;
         for (int j = 0; j + 1 < nt; ++j) {
@@ -952,9 +1032,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
     //   X_BA = -X_B (L_BA X_A)                        (the level-128 doubling step of this pair: X_P = [X_A 0; X_BA X_B])
     //   L[below, P] = S[below, P] X_P^T               (K = 256, X_P lower triangular)
     //   S[below, below] -= L[below, P] L[below, P]^T  (rank-256 update)
-    // (set_eager bit 11: the rows below meet the two 128 x 128 inverses one after the other instead -- three K = 128 products
-    //  of full height per panel; measured slower: the short-K launches run at ~32 TF/s.)
-    if (!fused && !fused_in_panel && !h->left_looking && !h->rank64_panels && !overlap && nt >= 4 && nt % 4 == 0) {
+    if (route == ROUTE_PANELS256 && !overlap) {
         StepArgs sa;
         sa.S = S; sa.L = L; sa.X = X; sa.ld = ld; sa.nt = nt; sa.cend = nt;
         sa.info = h->d_info; sa.blk = blk_id; sa.dbg = nullptr;
@@ -972,75 +1050,36 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             HIPCHK(hipGetLastError());
             return GMRF_OK;
         };
-        if (h->panels128) {
-            if (h->xsplit > 0) return bad_shape("internal: split inverse planned for the 128-column panel variant");
-            for (int j = 0; j < nt; j += 2) {
-                GCHK(diag128(j));
-                const int m2 = nt - j - 2;                         // row tiles below the diagonal block
-                if (m2 <= 0) continue;
-                const int64_t oj = (int64_t)j * 64, ob = oj + 128;
-                double* Lb = L + ob * ld + oj;
-                // L21 = S21 X_A^T: b(k, n) = X_A[n][k] (stored [n][k]), zero for k > n
-                GCHK(gemm(h, false, false, 64 * m2, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oj, ld, X + oj * ld + oj, ld, 0.0, Lb, ld,
-                          sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * m2 * nb));
-                if ((j / 2) % 2 == 0) {
-                    // first half of a 256-column panel: its second half S[j+2.., j+2..j+3] -= L21 L21[0:128]^T
-                    GCHK(gemm(h, false, false, 64 * m2, 128, 128, 0, 1, -1.0, Lb, ld, Lb, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL, sa.pS,
-                              1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * (2.0 * m2 - 1.0) * nb));
-                } else {
-                    const double* Lp = L + ob * ld + (oj - 128);
-                    GCHK(gemm(h, false, false, m2 * 64, m2 * 64, 256, 0, 1, -1.0, Lp, ld, Lp, ld, 1.0, S + ob * ld + ob, ld, sa.pL, sa.pL,
-                              sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 4.0 * (m2 * (m2 + 1) / 2) * nb));
-                }
-            }
-            GCHK(doubling_levels(h, L, X, T, 128, bsp / 2, -1));
-            return GMRF_OK;
-        }
         // Small batches (round 4): 7 workgroups per problem fit the chip up to a batch of 36, and then the panel's whole
         // 256 x 256 diagonal block -- two potrf_diag128 launches and the four 128^3 products -- is ONE persistent launch
         // (potrf_persist on the 4 x 4 tiles of the block, inverse rows included): 62 us instead of ~100 us per panel, on
         // 7 B CUs instead of B (C4 elliptic512 at batch 8: 8 of 256 CUs were busy in the diagonal chain).  Larger batches keep
         // the one-workgroup kernels: their chain hides behind the other problems, and 7 B workgroups of 140 KB would not fit.
         static const bool no_small = [] { const char* e = getenv("GMRF_PERSIST_PANELS"); return e && atoi(e) == 0; }();   // tuning aid
-        const bool persist_panels = !no_small && !h->no_persist_panels && h->gemm128 && persist_fits(h, 4, 0, 4, 2);
+        const bool persist_panels = !no_small && !h->no_persist_panels && persist_fits(h, 4, 0, 4, 2);
         for (int j = 0; j < nt; j += 4) {
             const int64_t oa = (int64_t)j * 64, ob = oa + 128, oc = oa + 256;
             if (persist_panels) {
                 const double fl = (4.0 * t3 / 3.0 + 2.0 * t3 * (6.0 * 0.625 + 10.0 + 10.0 + 6.0 * 0.625)) * nb;
                 GCHK(launch_persist(h, S + oa * ld + oa, L + oa * ld + oa, X + oa * ld + oa, 4, 0, 4, 2, blk_id, fl));
             } else {
-            GCHK(diag128(j));
-            // The four 128^3 products of the panel -- L_BA = S_BA X_A^T, S_BB -= L_BA L_BA^T before the second diagonal block,
-            // X_BA = -X_B (L_BA X_A) after it -- are four GEMM launches of 256 workgroups (13 % of a step's GEMM time at 20.7 TF/s).
-            // Round 4 built the alternative, ONE workgroup per problem in two launches (potrf_panel256.hpp, set_eager bit 14):
-            // bitwise the same results, the time-weighted GEMM fraction rises to 0.66 -- and the job is SLOWER (45.6 k against
-            // 48.1 k solves/s in one gpurun call: twelve dependent 64^3 products take one CU 57 us, the four launches 39 us).
-            Panel256Args pp;
-            pp.S = S; pp.L = L; pp.X = X; pp.ld = ld; pp.j = j; pp.pS = sa.pS; pp.pL = sa.pL; pp.pX = sa.pX;
-            pp.Lba = L + ob * ld + oa; pp.ldl = ld; pp.pLba = sa.pL;
-            if (!h->gemm128) {
-                ProfScope ps(h, 17, (2.0 * t3 * 3.0 * 2.0 + 2.0 * t3 * 2.0 * 3.0) * nb);
-                hipLaunchKernelGGL(potrf_panel256<0>, dim3(1, (unsigned)h->B), dim3(256), PANEL256_LDS, h->stream, pp);
-                HIPCHK(hipGetLastError());
-            } else {
+                GCHK(diag128(j));
+                // The four 128^3 products of the panel -- L_BA = S_BA X_A^T, S_BB -= L_BA L_BA^T before the second diagonal block,
+                // X_BA = -X_B (L_BA X_A) after it -- are four GEMM launches of 256 workgroups (13 % of a step's GEMM time at 20.7 TF/s).
+                // (Round 4 built and measured the alternative, ONE workgroup per problem in two launches, bitwise the same results:
+                //  the time-weighted GEMM fraction rose to 0.66 and the job got SLOWER, 45.6 k against 48.1 k solves/s -- twelve
+                //  dependent 64^3 products take one CU 57 us, the four launches 39 us.  Removed in round 5.)
                 // L_BA = S_BA X_A^T (X_A lower triangular, stored [n][k]);  S_BB -= L_BA L_BA^T (lower tiles)
                 GCHK(gemm(h, false, false, 128, 128, 128, TRI_B_UPPER, 0, 1.0, S + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, L + ob * ld + oa, ld,
                           sa.pS, sa.pX, sa.pL, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 3.0 * 2.0 * nb));
                 GCHK(gemm(h, false, false, 128, 128, 128, 0, 1, -1.0, L + ob * ld + oa, ld, L + ob * ld + oa, ld, 1.0, S + ob * ld + ob, ld,
                           sa.pL, sa.pL, sa.pS, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * t3 * 2.0 * 3.0 * nb));
-            }
-            GCHK(diag128(j + 2));
-            // X_BA = -X_B (L_BA X_A): the level-128 doubling step of this pair (T is the work block doubling_levels uses)
-            if (!h->gemm128) {
-                ProfScope ps(h, 17, 2.0 * (2.0 * 128.0 * 128.0 * 128.0 * 0.75) * nb);
-                hipLaunchKernelGGL(potrf_panel256<1>, dim3(1, (unsigned)h->B), dim3(256), PANEL256_LDS, h->stream, pp);
-                HIPCHK(hipGetLastError());
-            } else {
+                GCHK(diag128(j + 2));
+                // X_BA = -X_B (L_BA X_A): the level-128 doubling step of this pair (T is the work block doubling_levels uses)
                 GCHK(gemm(h, false, true, 128, 128, 128, TRI_B_LOWER, 0, 1.0, L + ob * ld + oa, ld, X + oa * ld + oa, ld, 0.0, T + ob * ld + oa, ld,
                           sa.pL, sa.pX, pW));
                 GCHK(gemm(h, false, true, 128, 128, 128, TRI_A_LOWER, 0, -1.0, X + ob * ld + ob, ld, T + ob * ld + oa, ld, 0.0, X + ob * ld + oa, ld,
                           sa.pX, pW, sa.pX));
-            }
             }
             const int m3 = nt - j - 4;                             // row tiles below the panel
             if (m3 <= 0) continue;
@@ -1067,7 +1106,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
         }
         return GMRF_OK;
     }
-    // (only the 256-column panel route above leaves the split form: planned_xsplit mirrors its conditions)
+    // (only the 256-column panel route above leaves the split form: planned_xsplit asks the same predicate)
     if (h->xsplit > 0) return bad_shape("internal: split inverse planned off the 256-column panel route");
     for (int j = 0; j < nt; ++j) {
         StepArgs sa;
@@ -1113,26 +1152,6 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
             // the workgroups of column j+1 write the whole panel L[j+1.., j]
             ProfScope ps(h, 1, f_tile + f_panel + f_upd);
             hipLaunchKernelGGL(potrf_step<false>, dim3(1 + utiles, 1), dim3(256), POTRF_STEP_LDS, h->stream, sa);
-        } else if (!fused_in_panel && h->left_looking) {
-            // opt-in (set_eager bit 6): tile, then the LEFT-LOOKING panel (potrf_panel_ll): the panel's earlier columns
-            // are applied to column j when it is formed, the tiles right of it are left alone until the panel-end GEMM.
-            // Half the S traffic and two launches per step instead of three, but measured SLOWER on darcy256 / batch 32
-            // (30.4 ms per factor against 10.2 + 15.1 ms for panel + update: m workgroups per problem with up to four
-            // dependent 64-wide products each, against 3 m one-product workgroups) -- kept for comparison
-            {
-                ProfScope ps(h, 1, f_tile);
-                hipLaunchKernelGGL(potrf_step<false>, dim3(1, (unsigned)h->B), dim3(256), POTRF_TILE_LDS, h->stream, sa);
-            }
-            PanelLLArgs pa;
-            pa.S = S; pa.L = L; pa.X = X; pa.ld = ld; pa.pS = sa.pS; pa.pL = sa.pL; pa.pX = sa.pX;
-            pa.j = j; pa.j0 = cend - pw; pa.nt = nt;
-            pa.update_next_diag = (j + 1 < cend) ? 1 : 0;
-            const double jj = (double)(j - pa.j0);
-            // executed flops: per row tile 2 * 64^3 * jj (left-looking sum) + 2 * 64^3 * 20/32 (T X^T, triangular);
-            // the next diagonal tile: 10 of 16 sub-blocks x (jj + 1) columns
-            const double f_ll = 2.0 * 64.0 * 64.0 * 64.0 * (m * (jj + 0.625) + (pa.update_next_diag ? 0.625 * (jj + 1.0) : 0.0)) * nb;
-            ProfScope ps(h, 8, f_ll);
-            hipLaunchKernelGGL(potrf_panel_ll, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, pa);
         } else {
             // factor the B diagonal tiles once, then panel and update without the redundant tile work
             {
@@ -1143,14 +1162,7 @@ static gmrf_status potrf_block(gmrf_handle* h, double* S, double* L, double* X, 
                 ProfScope ps(h, 8, f_panel);
                 hipLaunchKernelGGL(potrf_panel, dim3(m, (unsigned)h->B), dim3(256), 0, h->stream, sa);
             }
-            if (utiles > 0 && h->update_via_gemm) {
-                // experiment (set_eager bit 9): the in-panel rank-64 update on the LDS-staged GEMM kernel instead of the
-                // L2-fed potrf_update: tiles (r, c), j < c < cend, r >= c, of  S -= L[:, j] L[:, j]^T
-                const double* Lj = L + (int64_t)(j + 1) * 64 * ld + (int64_t)j * 64;
-                double* Sj = S + (int64_t)(j + 1) * 64 * ld + (int64_t)(j + 1) * 64;
-                GCHK(gemm(h, false, false, 64 * m, 64 * (cend - j - 1), 64, 0, 1, -1.0, Lj, ld, Lj, ld, 1.0, Sj, ld, sa.pL, sa.pL, sa.pS,
-                          1, 0, 0, 0, nullptr, 0, 0, 9, f_upd));
-            } else if (utiles > 0) {
+            if (utiles > 0) {
                 ProfScope ps(h, 9, f_upd);
                 hipLaunchKernelGGL(potrf_update, dim3(utiles, (unsigned)h->B), dim3(256), 0, h->stream, sa);
             }
@@ -1345,15 +1357,17 @@ static gmrf_status ensure_full_inverse(gmrf_handle* h) {
 static std::mutex g_capture_mu;
 
 static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
-    if (h->eager || h->profiling) return factor_blocks_range(h, i0, i1);
+    if (h->eager || h->profiling) { h->stats.persist_route = 0; return factor_blocks_range(h, i0, i1); }
     if (!h->factor_graph || h->factor_graph_i0 != i0 || h->factor_graph_i1 != i1) {
         std::lock_guard<std::mutex> capture_lock(g_capture_mu);
         if (h->factor_graph) { (void)hipGraphExecDestroy(h->factor_graph); h->factor_graph = nullptr; }
         hipGraph_t graph = nullptr;
         HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
         h->capturing = true; h->fork_next = 0;
+        h->stats.persist_route = 0;
         gmrf_status s = factor_blocks_range(h, i0, i1);
         h->capturing = false;
+        h->factor_graph_route = h->stats.persist_route;
         hipError_t e = hipStreamEndCapture(h->stream, &graph);
         if (s != GMRF_OK) { if (graph) (void)hipGraphDestroy(graph); return s; }
         HIPCHK(e);
@@ -1362,26 +1376,46 @@ static gmrf_status run_factor(gmrf_handle* h, int64_t i0, int64_t i1) {
         h->factor_graph_i0 = i0; h->factor_graph_i1 = i1;
     }
     h->xsplit = planned_xsplit(h);                     // (what the captured launches produce)
+    h->stats.persist_route = h->factor_graph_route;
+    if (h->factor_graph_route) h->persist_launched = true;
     HIPCHK(hipGraphLaunch(h->factor_graph, h->stream));
     return GMRF_OK;
 }
 
-static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
+// The blocks [i0, i1) have been enqueued; if a persistent launch was among them, wait for the range and look at the abort word:
+// a bounded wait inside such a launch gave up (its workgroups were not all resident, or starved) -- every such launch has drained
+// and left garbage.  The range is then repeated at once with the launch-per-step forms (its inputs, the value lists and the
+// previous block's inverse, are untouched), which the handle keeps for good; the event is counted in stats.persist_aborts.
+// Called per range by gmrf_bt_factor_step_async, BEFORE the caller packs / shares the range (a range shared before
+// gmrf_bt_factor_end looked at the word carried garbage to the other ranks), and for the whole chain by factor_finish.
+static gmrf_status persist_check_range(gmrf_handle* h, int64_t i0, int64_t i1, int* hinfo_out) {
     int hinfo2[2] = {0, 0};
     HIPCHK(hipMemcpyAsync(hinfo2, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->persist_launched = false;
     if (hinfo2[1] != 0) {
-        // a wait inside a persistent launch gave up (its workgroups were not all resident, or starved): every such launch
-        // has drained; repeat the numeric phase with the launch-per-step form, which this handle keeps from now on
-        h->no_persist = true; h->persist_aborts++;
+        h->persist_gave_up = true; h->persist_aborts++;
+        h->stats.persist_aborts = h->persist_aborts;
+        persist_release(h);
         destroy_graphs(h);
-        HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
+        const int restore[4] = {h->info_checked, 0, 0, 0};     // (what the aborted range wrote into the info word means nothing)
+        HIPCHK(hipMemcpyAsync(h->d_info, restore, 4 * sizeof(int), hipMemcpyHostToDevice, h->stream));
         if (h->d_pflags) HIPCHK(hipMemsetAsync(h->d_pflags, 0, sizeof(unsigned) * (size_t)h->pflags_words, h->stream));   // (belt and braces: the drained launches cleaned up themselves)
-        GCHK(factor_blocks_range(h, 0, h->N));
+        h->stats.persist_route = 0;
+        GCHK(factor_blocks_range(h, i0, i1));
         HIPCHK(hipMemcpyAsync(hinfo2, h->d_info, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
+        h->persist_launched = false;
     }
-    int hinfo = hinfo2[0];
+    h->info_checked = hinfo2[0];
+    if (hinfo_out) *hinfo_out = hinfo2[0];
+    return GMRF_OK;
+}
+
+static gmrf_status factor_finish(gmrf_handle* h, int32_t* info) {
+    // (stepwise factorisations have looked at every range that held a persistent launch already; the monolithic one is one range)
+    int hinfo = 0;
+    GCHK(persist_check_range(h, 0, h->N, &hinfo));
     if (info) *info = hinfo;
     if (hinfo != 0) {
         h->factored = false;
@@ -1403,9 +1437,11 @@ static gmrf_status numeric_factor(gmrf_handle* h, const double* nzval, int32_t* 
         HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
         h->c_dirty = false;
     }
+    persist_plan(h);
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     GCHK(load_values(h, nzval));
     HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
+    h->info_checked = 0; h->persist_launched = false;
     GCHK(run_factor(h, 0, h->N));
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     gmrf_status s = factor_finish(h, info);
@@ -1659,9 +1695,6 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_STEP_LDS));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(hipFuncSetAttribute((const void*)potrf_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_PERSIST_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_panel256<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL256_LDS));
-    HIPCHK(hipFuncSetAttribute((const void*)potrf_panel256<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PANEL256_LDS));
-    { const char* e = getenv("GMRF_GEMM128"); if (e && atoi(e) == 0) h->gemm128 = false; }      // tuning aid: potrf_panel256 instead of the 128^3 GEMM launches
     HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
     { const char* e = getenv("GMRF_PERSIST"); if (e && atoi(e) == 0) h->no_persist = true; }      // tuning aid
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128_slim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1675,6 +1708,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (!h) return GMRF_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    persist_release(h);
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
     free_dev(h->d_lo_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
@@ -1731,15 +1765,10 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 8) != 0) != h->dense_g1) { destroy_graphs(h); h->dense_g1 = (eager & 8) != 0; }
     if (((eager & 16) != 0) != h->fork_graph) { destroy_graphs(h); h->fork_graph = (eager & 16) != 0; }
     h->no_staircase = (eager & 32) != 0;
-    if (((eager & 64) != 0) != h->left_looking) { destroy_graphs(h); h->left_looking = (eager & 64) != 0; }
     if (((eager & 128) != 0) != h->doubling_x) { destroy_graphs(h); h->doubling_x = (eager & 128) != 0; }
     if (((eager & 256) != 0) != h->no_lookahead) { destroy_graphs(h); h->no_lookahead = (eager & 256) != 0; }
-    if (((eager & 512) != 0) != h->update_via_gemm) { destroy_graphs(h); h->update_via_gemm = (eager & 512) != 0; }
-    if (((eager & 1024) != 0) != h->rank64_panels) { destroy_graphs(h); h->rank64_panels = (eager & 1024) != 0; }
-    if (((eager & 2048) != 0) != h->panels128) { destroy_graphs(h); h->panels128 = (eager & 2048) != 0; }
     if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
     if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
-    if (((eager & 16384) == 0) != h->gemm128) { destroy_graphs(h); h->gemm128 = (eager & 16384) == 0; }
     if (((eager & 32768) != 0) != h->no_persist_panels) { destroy_graphs(h); h->no_persist_panels = (eager & 32768) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
@@ -1778,8 +1807,10 @@ gmrf_status gmrf_bt_factor_begin_csc(gmrf_handle* h, int64_t n, int64_t n_blocks
         HIPCHK(hipMemsetAsync(h->d_C, 0, sizeof(double) * stride_pC(h) * h->B, h->stream));
         h->c_dirty = false;
     }
+    persist_plan(h);
     GCHK(load_values(h, nzval));
     HIPCHK(hipMemsetAsync(h->d_info, 0, 4 * sizeof(int), h->stream));
+    h->info_checked = 0; h->persist_launched = false; h->stats.persist_route = 0;
     h->factored = false;
     return GMRF_OK;
 }
@@ -1789,7 +1820,11 @@ gmrf_status gmrf_bt_factor_step_async(gmrf_handle* h, int64_t i0, int64_t i1) {
     if (i0 < 0 || i1 > h->N || i0 > i1) return bad_shape("bad block range");
     HIPCHK(hipSetDevice(h->device));
     // block ranges are launched directly (a graph per range would have to be re-captured)
-    return factor_blocks_range(h, i0, i1);
+    GCHK(factor_blocks_range(h, i0, i1));
+    // A range that holds persistent launches is waited for here and repeated launch-per-step if one of them gave up, so that
+    // what the caller packs / broadcasts next is the factor (the call is asynchronous only for handles without such launches)
+    if (h->persist_launched) GCHK(persist_check_range(h, i0, i1, nullptr));
+    return GMRF_OK;
 }
 
 gmrf_status gmrf_bt_factor_end(gmrf_handle* h, int32_t* info) {
@@ -4064,25 +4099,27 @@ gmrf_status gmrf_test_potrf_tile(int32_t device, double* tile64, double* inv64, 
     HIPCHK(hipMalloc(&dinfo, sizeof(int)));
     HIPCHK(hipMemset(dinfo, 0, sizeof(int)));
     HIPCHK(hipMemcpy(dS, tile64, sizeof(double) * 4096, hipMemcpyHostToDevice));
-    (void)hipFuncSetAttribute((const void*)potrf_tile_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_TILE_LDS);
+    auto kern = potrf_tile_kernel;
+    const dim3 tpb(256);
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_TILE_LDS);
     unsigned long long* dstamps;
-    HIPCHK(hipMalloc(&dstamps, 32 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(dstamps, 0, 32 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
+    HIPCHK(hipMalloc(&dstamps, 64 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(dstamps, 0, 64 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(kern, dim3(1), tpb, POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
     HIPCHK(hipDeviceSynchronize());
     {   // timing: 200 back-to-back launches without stamps, then one stamped launch
         hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
         HIPCHK(hipEventRecord(e0, nullptr));
         for (int i = 0; i < 200; ++i)
-            hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
+            hipLaunchKernelGGL(kern, dim3(1), tpb, POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, (unsigned long long*)nullptr);
         HIPCHK(hipEventRecord(e1, nullptr)); HIPCHK(hipEventSynchronize(e1));
         float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
         g_tile_us = ms * 1e3 / 200.0;
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
-    hipLaunchKernelGGL(potrf_tile_kernel, dim3(1), dim3(256), POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, dstamps);
+    hipLaunchKernelGGL(kern, dim3(1), tpb, POTRF_TILE_LDS, nullptr, dS, dL, dX, dinfo, dstamps);
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(g_tile_stamps, dstamps, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(g_tile_stamps, dstamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     hipFree(dstamps);
     HIPCHK(hipGetLastError());
     HIPCHK(hipDeviceSynchronize());
@@ -4102,6 +4139,9 @@ gmrf_status gmrf_test_tile_timing(double* out, int32_t n) {
     for (int i = 0; i < 17; ++i) out[1 + i] = (double)(g_tile_stamps[i] - g_tile_stamps[15]);
     if (n >= 24) for (int i = 0; i < 3; ++i) out[18 + i] = (double)(g_tile_stamps[20 + i] - g_tile_stamps[15]);
     if (n >= 30) for (int i = 0; i < 6; ++i) out[24 + i] = (double)(g_tile_stamps[24 + i] - g_tile_stamps[24]);   // fused step phases (gmrf_test_potrf_block)
+    // round 5: per panel p (up to 8) three stamps of its owner wave: its column chain begins / is done / its columns are stored
+    if (n >= 62) for (int i = 0; i < 8; ++i) out[54 + i] = g_tile_stamps[56 + i] ? (double)(g_tile_stamps[56 + i] - g_tile_stamps[15]) : -1.0;   // panel i: its owner has applied every earlier column
+    if (n >= 54) for (int i = 0; i < 24; ++i) out[30 + i] = g_tile_stamps[32 + i] ? (double)(g_tile_stamps[32 + i] - g_tile_stamps[15]) : -1.0;
     return GMRF_OK;
 }
 
@@ -4123,6 +4163,15 @@ gmrf_status gmrf_test_persist_aborts(gmrf_handle* h, int32_t* n) {
     return GMRF_OK;
 }
 
+// The budget of CUs for persistent launches on a device with `cus` CUs, host only: `n` handles claim demands[i] CUs one after
+// the other; granted[i] = 1 if the claim fitted beside the earlier ones (gmrf_handle::persist_cus), 0 if it was refused.
+gmrf_status gmrf_test_persist_budget(int32_t cus, int32_t n, const int32_t* demands, int32_t* granted) {
+    if (n < 0 || (n > 0 && (!demands || !granted))) return bad_shape("null argument");
+    std::map<const void*, int> claims;
+    for (int i = 0; i < n; ++i) granted[i] = persist_budget_claim(claims, (const void*)(demands + i), demands[i], cus, 0) ? 1 : 0;
+    return GMRF_OK;
+}
+
 gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double* Linv, int32_t* info) {
     if (bs % 64 || next_pow2(bs / 64) != bs / 64) return bad_shape("bs must be 64 * 2^p");
     gmrf_handle* h = nullptr;
@@ -4137,6 +4186,7 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S, double*
     }
     if (s == GMRF_OK) {
         hipError_t e = hipMemcpyAsync(h->d_S, S, sizeof(double) * bs * bs, hipMemcpyHostToDevice, h->stream);
+        persist_plan(h);
         if (e == hipSuccess) s = potrf_block(h, h->d_S, h->d_L, h->d_Linv, h->d_T, 1);
         if (s == GMRF_OK) {
             int hi = 0;

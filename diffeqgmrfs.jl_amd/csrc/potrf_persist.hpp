@@ -254,29 +254,26 @@ __device__ __forceinline__ void diag_update_balanced_w(int w, const double* Ls, 
     }
 }
 
-// What waves 1 and 2 of the chain workgroup do in the shadow of wave 0's panel factorisations (tile_potrf_inv<Side>):
-//   a0        store L[j+1, j] (in As since the last product): 628 cycles of store issue off the chain;
-//   b(kb)     at the START of their part of panels 1 .. 3 (their own deferred work there is short), never waiting for a flag:
-//             one relaxed look at the two flags of the NEXT step's operands; once both are up, this wave's half of
-//             S'[j+2, j+1] -> As in the same panel and its half of tile (j+2, j+2) -> Bs in the next one (the last panel: both),
-//             then `tag` into its LDS words.  The chain takes a prefetched operand only if both waves' words for it carry
-//             the step's tag after the factorisation; what is missing it waits for and loads as before (1 450 + 2 400 cycles
-//             a step when it has to do both).
-// (Measured against this, one gpurun call each: loads issued in b() and moved to LDS after the wave's deferred work, flag looks
-//  issued one call ahead -- nothing blocks, but an operand then needs two more panels after its flags are seen and every second
-//  step fell back: 36.0 k cycles per step against 34.3 k; the tile stores drained behind the next product instead of X_jj
-//  flagged at once: the workers start 3 500 cycles later and the prefetch misses every second step: 34.3 k against 33.6 k.)
+// The chain workgroup has EIGHT waves (round 5): waves 0 - 3 compute (the tile factorisation keeps all four busy now: every one owns
+// a panel), waves 4 - 7 move tiles beside them, between the two barriers of tile_potrf_inv (`extra`), each for itself:
+//   waves 4, 5   store their half of L[j+1, j] (in As since the last product), then wait for the flag of the NEXT step's panel tile
+//                S'[j+2, j+1] and bring their half of it into As;
+//   waves 6, 7   wait for the flag of tile (j+2, j+2) and bring their half into Bs;
+// each leaves `tag` in its LDS word when its half is there.  A wait ends when the flag is up or when the tile is done (X_33 is
+// flagged: tile_potrf_inv's word TF_I + 3) -- the chain takes a prefetched operand only if both words for it carry the step's tag
+// after the factorisation; what is missing it waits for and loads as before (1 450 + 2 400 cycles a step when it has to do both).
+// (Round 4 did this on waves 1 and 2 in the shadow of wave 0's panels, with looks that never waited.)
 struct ChainSide {
     const double* sL; double* gL;             // LDS tile -> global (nullptr: nothing to store)
     const unsigned* f1; const unsigned* f2;   // flags the prefetch needs (nullptr: none)
     const double* gA; double* sA;             // nullptr: no next step
     const double* gN; double* sN;
     int64_t ld;
-    lds_word* done;                           // LDS: [0], [1] As halves of waves 1, 2;  [2], [3] Bs halves
+    lds_word* done;                           // LDS: [0], [1] As halves;  [2], [3] Bs halves
     int tag;
-    int state;                                // per wave: 0 flags not seen, 1 As half loaded, 2 both halves loaded
     unsigned long long* stamps;
-    unsigned long long* dbg;                  // diagnostic: the panel in which wave 1 saw the flags (tools/persist_stamps.py), else nullptr
+    unsigned long long* dbg;                  // diagnostic: 1 + the 64-column quarter of the tile in which As was there (tools/persist_stamps.py), else nullptr
+    __device__ __forceinline__ void idle(int, int, int) {}
     __device__ __forceinline__ void half_load(const double* g, double* s, int half, int lane) const {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
         v4u v[16];
@@ -293,37 +290,40 @@ struct ChainSide {
             *reinterpret_cast<v4u*>(s + r * TLD + c) = v[it];
         }
     }
-    __device__ __forceinline__ void a0(int tid) {
-        if (gL && tid < 192) {
-            const __amdgpu_buffer_rsrc_t rs = tile_rsrc(gL);
-            const int t128 = tid - 64;
+    // one wave: true when `f` is up; false when the tile factorisation is over first (or a bound of looks is reached)
+    __device__ __forceinline__ bool wait_flag(const unsigned* f, tile_word* fl, int lane) const {
+        if (!f) return true;
+        for (int n = 0; n < (1 << 14); ++n) {
+            unsigned v = 0u;
+            if (lane == 0) v = ld_flag(f);
+            if (__builtin_amdgcn_readfirstlane(v)) return true;
+            if (fl[TF_I + 3] != 0) return false;
+            __builtin_amdgcn_s_sleep(4);
+        }
+        return false;
+    }
+    __device__ __forceinline__ void extra(int w, int lane, tile_word* fl) {
+        const int half = w & 1;
+        if (w < 2) {
+            if (gL) {
+                const __amdgpu_buffer_rsrc_t rs = tile_rsrc(gL);
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const int idx = t128 + it * 128;
-                const int r = idx >> 5, c = (idx & 31) * 2;
-                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(sL + r * TLD + c), rs, (int)((r * ld + c) * 8), 0, 16);
+                for (int it = 0; it < 16; ++it) {
+                    const int idx = half * 1024 + lane + it * 64;
+                    const int r = idx >> 5, c = (idx & 31) * 2;
+                    __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(sL + r * TLD + c), rs, (int)((r * ld + c) * 8), 0, 16);
+                }
             }
-        }
-    }
-    __device__ __forceinline__ void b(int kb, int tid) {
-        if (!gA || tid >= 192 || state >= 2) return;
-        const int half = __builtin_amdgcn_readfirstlane(tid >> 6) - 1, lane = tid & 63;
-        if (state == 0) {
-            unsigned ok = 1u;
-            if (f1) ok &= ld_flag(f1);
-            if (f2) ok &= ld_flag(f2);
-            if (!__builtin_amdgcn_readfirstlane(ok)) return;
-            half_load(gA, sA, half, lane);
-            state = 1;
+            if (!gA || !wait_flag(f1, fl, lane)) return;
+            half_load(gA, sA, half, lane);             // (behind this wave's own reads of its half of As: the LDS serves them in order)
             if (lane == 0) done[half] = tag;
-            if (dbg && half == 0 && lane == 0) *dbg = (unsigned long long)kb;
-            if (kb < 3) return;                          // (the last panel: no later call -- both halves now)
+            if (dbg && half == 0 && lane == 0) *dbg = 1ull + (fl[TF_CS + 0] != 0) + (fl[TF_CS + 1] != 0) + (fl[TF_CS + 2] != 0);
+        } else {
+            if (!gN || !wait_flag(f2, fl, lane)) return;
+            half_load(gN, sN, half, lane);
+            if (lane == 0) done[2 + half] = tag;
         }
-        half_load(gN, sN, half, lane);
-        state = 2;
-        if (lane == 0) done[2 + half] = tag;
     }
-    __device__ __forceinline__ void ak(int, int) const {}
 };
 
 __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
@@ -353,17 +353,16 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
     unsigned* const fXF = fPL + nt * nt;
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
     bool bad = false;
-    SideLoad none;
-    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
 
     if (blockIdx.x == 0) {
-        // ------------------------------------------------------------------ the chain
+        // ------------------------------------------------------------------ the chain (eight waves: see ChainSide)
+        const bool cw = wave < 4;                            // the waves that compute; the others only join the barriers out here
         lds_word* done = okw + 2;
         if (tid < 4) done[tid] = 0;
         ChainSide cs;
         cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.dbg = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
         auto prefetch_for = [&](int jn) {                    // operands of step jn (tile jn + 1) -> cs, or none past the last step
-            cs.state = 0; cs.tag = jn + 1;
+            cs.tag = jn + 1;
             if (jn + 1 < pa.j1) {
                 const int64_t oj = (int64_t)jn * 64, o1 = oj + 64;
                 cs.gA = pa.S + o1 * ld + oj; cs.gN = pa.S + o1 * ld + o1;
@@ -374,15 +373,15 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             }
         };
         const int64_t o0 = (int64_t)pa.j0 * 64;
-        tile_g2s(pa.S + o0 * ld + o0, ld, Ts, tid);
+        if (cw) tile_g2s(pa.S + o0 * ld + o0, ld, Ts, tid);
         cs.gL = nullptr;
         prefetch_for(pa.j0);
         __syncthreads();
         tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
         if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
-        tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
+        if (cw) tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
         wg_publish(fD + pa.j0, nullptr, tid);
-        tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
+        if (cw) tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
         // The write-through stores of L_jj drain BEHIND the next step's first product: whatever `pend1` / `pend2` name goes up at
         // that step's first barrier, after every wave's vmcnt(0).  (The step's prefetch words were written before
         // tile_potrf_inv's last barrier.)
@@ -391,7 +390,7 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
         if (pa.stamps && tid == 0) pa.stamps[0] = __builtin_amdgcn_s_memtime();
         for (int j = pa.j0; j + 1 < pa.j1; ++j) {
             const int64_t oj = (int64_t)j * 64, o1 = oj + 64;
-            // (the publish above was a barrier: the two words are what waves 1, 2 left during the last factorisation)
+            // (the publish above was a barrier: the words are what waves 4 - 7 left during the last factorisation)
             const bool pre_a = done[0] == j + 1 && done[1] == j + 1, pre_n = done[2] == j + 1 && done[3] == j + 1;
             if (pre_a && pre_n) {
                 if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
@@ -402,8 +401,8 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
                 const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
                 if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
                 if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
-                if (!pre_a) tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
-                if (!pre_n) tile_g2s_sc1(pa.S + o1 * ld + o1, ld, Bs, tid);
+                if (cw && !pre_a) tile_g2s_sc1(pa.S + o1 * ld + oj, ld, As, tid);
+                if (cw && !pre_n) tile_g2s_sc1(pa.S + o1 * ld + o1, ld, Bs, tid);
                 __syncthreads();
             }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 2] = __builtin_amdgcn_s_memtime();
@@ -411,15 +410,17 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             v4d lr[4];
 #pragma unroll
             for (int Jb = 0; Jb < 4; ++Jb) lr[Jb] = zero;
+            if (cw) {
 #pragma unroll
-            for (int kg = 0; kg < 8; ++kg) {
-                const int k = 8 * kg + 2 * lq;
-                const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
+                for (int kg = 0; kg < 8; ++kg) {
+                    const int k = 8 * kg + 2 * lq;
+                    const v2d av = *reinterpret_cast<const v2d*>(As + (16 * wave + li) * TLD + k);
 #pragma unroll
-                for (int Jb = kg / 2; Jb < 4; ++Jb) {
-                    const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
-                    lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
-                    lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+                    for (int Jb = kg / 2; Jb < 4; ++Jb) {
+                        const v2d xv = *reinterpret_cast<const v2d*>(Xs + (16 * Jb + li) * TLD + k);
+                        lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, xv.x, lr[Jb], 0, 0, 0);
+                        lr[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, xv.y, lr[Jb], 0, 0, 0);
+                    }
                 }
             }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 3] = __builtin_amdgcn_s_memtime();
@@ -430,15 +431,17 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
                 if (pend2) st_flag(pend2, 1u);
             }
             pend1 = nullptr; pend2 = nullptr;
+            if (cw) {
 #pragma unroll
-            for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+                for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+            }
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 4] = __builtin_amdgcn_s_memtime();
-            // (L[j+1, j] leaves for global memory in the shadow of the first panel below: ChainSide::a0)
+            // (L[j+1, j] leaves for global memory beside the tile factorisation below: ChainSide::extra)
             // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
             // (the ten lower blocks dealt evenly over the waves; L_jj has left Ts: its stores were drained by wg_publish; the tile
             //  (j+1, j+1) waits in Bs, prefetched or just loaded)
-            diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
+            if (cw) diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();
             cs.gL = pa.L + o1 * ld + oj;
             prefetch_for(j + 1);
@@ -449,9 +452,9 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
             // X_{j+1,j+1} is what every workgroup of the next step waits for: stored, drained and flagged at once; L_{j+1,j+1}
             // (read by nobody inside the launch) and the flag of L[j+1, j] drain behind the next step's first product
-            tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
+            if (cw) tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
             wg_publish(fD + j + 1, nullptr, tid);
-            tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
+            if (cw) tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
             pend1 = fPL + (j + 1) * nt + j; pend2 = nullptr;
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();
         }
@@ -608,8 +611,11 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
     wg_publish(fXF + r * nt + c, nullptr, tid);
 }
 
+constexpr int POTRF_PERSIST_THREADS = 512;
 template <bool UNUSED>
-__global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
+__global__ __launch_bounds__(POTRF_PERSIST_THREADS, 2) void potrf_persist(PersistArgs pa) {
+    // (only the chain workgroup uses its waves 4 - 7; a barrier counts the waves that have not ended)
+    if (blockIdx.x != 0 && threadIdx.x >= 256) return;
     potrf_persist_body(pa);                               // (every return in there is taken by the whole workgroup)
     // The last workgroup of a problem to get here leaves the flag words zero for the next launch: all its own stores are
     // acknowledged (vmcnt(0)), then one lane counts the workgroup out; whoever counts gridDim.x - 1 others before it knows that
@@ -622,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void potrf_persist(PersistArgs pa) {
     if (threadIdx.x == 0)
         last_out = __hip_atomic_fetch_add(flags + nflags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
     __syncthreads();
-    if (last_out)
+    if (last_out && threadIdx.x < 256)                     // (a worker workgroup has only its first four waves left)
         for (int i = threadIdx.x; i <= nflags; i += 256) st_flag(flags + i, 0u);
 }
 

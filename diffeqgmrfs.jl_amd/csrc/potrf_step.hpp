@@ -8,12 +8,7 @@
 // The redundant tile factorisation costs nothing in wall time (the other CUs would idle) and
 // removes two dependent launches per panel.
 //
-// tile_potrf_inv: 64x64 tile in LDS, four 16-column panels.  Wave 0 factors a panel with one
-// row per lane (pivot broadcast by v_readlane, rsqrt + 2 Newton steps, rank-1 updates kept in
-// registers); the 16x16 trailing sub-tiles are updated with v_mfma_f64_16x16x4_f64 by all four
-// waves, the sub-tiles the next panel does not need are deferred and overlap with it
-// (look-ahead); the 16x16 diagonal inverses are built by wave 3 off the critical path and the
-// full 64x64 inverse is assembled by two levels of recursive doubling with MFMA products.
+// tile_potrf_inv: 64x64 tile in LDS, four 16-column panels, each owned by one wave (see below, round 5).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -38,13 +33,6 @@ constexpr int TLD = GMRF_TLD;           // LDS row stride (doubles) of a 64x64 t
                                         // (68 = 8 mod 64 put rows r and r + 8 on the same banks: SQ_LDS_BANK_CONFLICT was
                                         // 0.34 of the tile kernel's LDS-active cycles)
 constexpr int TILE_ELEMS = 64 * TLD;
-// scratch of the tile factorisation: TWO copies (panels alternate) of {the panel's 16 columns, one row of the tile per lane:
-// lcol[jj * 64 + row]; the 16 reciprocal pivots rv[jj]} -- the second copy lets a follower wave read panel 3 while it is being
-// written (inv16_follow) after that copy's rv slots were cleared during panel 2; the 16 x 18 strips of the inverse assembly's
-// tail (Wm, waves 0 .. 2) lie in the first copy, which the last panel no longer uses
-constexpr int LCOL_ELEMS = 16 * 64 + 16;
-constexpr int WK_ELEMS = 2 * LCOL_ELEMS;
-
 __device__ __forceinline__ double bcast_lane(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -195,99 +183,203 @@ __device__ __forceinline__ double rcp_nr(double p) {
     return y;
 }
 
-// Wave 0: factor the 16 columns [c0, c0+16) of the tile for rows >= c0 (one row per lane).
+// ------------------------------------------------------------------------------------------------------------------
+// Round 5: the 64 x 64 tile Cholesky as a STREAMING factorisation -- every wave owns one 16-column panel for the whole tile:
+//
+//   wave k   waits with its panel as MFMA accumulators: while panel p < k is being factored it adds, four columns at a time as
+//            they appear in the panel scratch (pcol_p[jj][row], then the reciprocal pivot rv[column] != 0: a wave's LDS stores land
+//            in order), the products L[r][j] L[c][j] of those columns to a sum that starts at ZERO; when panel k - 1 is done it
+//            subtracts the sum ONCE from its columns of the tile (one rounding at the magnitude of S for all 16 k earlier columns
+//            -- what LAPACK's dot-product forms do, and what round 2 found worth two digits on ill-conditioned Schur complements),
+//            turns them into the one-row-per-lane form through its own columns of Ts and LEADS panel k from registers (the column
+//            chain of round 2: pivot by v_readlane, rsqrt + one Halley step, in-panel rank-1 updates dealt between the chain's
+//            instructions), stores its columns of L (zeros above the diagonal included) and goes on to inverse work.
+//
+// No barrier and no all-wave sub-tile update between two panels: the hand-over from panel k to panel k + 1 is the follower's
+// last rank-4 update and its turn through LDS, ~600 cycles (round 4: per panel 240 cycles of loads + 360 .. 620 of stores + two
+// barriers + 850 of sub-tile updates, and a tail of 2 700 -- a third of the tile's 22 k cycles, on the chain of every potrf
+// kernel).  The 16 x 16 diagonal inverses follow the panels too (inv16_follow, round 4's form for the last block) where a wave is
+// free to watch, the block rows of the 64 x 64 inverse are summed as their inputs arrive; waves meet through words in LDS, and at
+// ONE barrier at the end.  Same arithmetic per entry as round 4 up to the grouping of the sums (one subtraction per owner wave
+// instead of one per panel): not bitwise the round-4 tile, same error bound, and every route shares this one routine.
+//
+// Measured on the way (tools/tile_timing.py, cycles per tile; round 4: 22.3 k): followers that apply every column as a rank-1
+// update with scalar fma -- four waves x 16-column panels 20.7 k, eight waves x 8-column panels 22.4 k, with the multiplicands
+// by ds_read_b128 or by v_readlane alike: a lone wave issues about one instruction per 8 cycles, so a follower's column (16 fma +
+// its operand reads) takes ~300 cycles against the leader's ~200 and every hand-over waits 700 - 1 700 cycles for the next leader
+// to catch up; and a chain of such fma starting from S rounds at |S| once per column (darcy64's forward error 2.1e-11 against the
+// oracle's 7.7e-12).  The rank-4 MFMA follower needs ~10 instructions per four columns: 18.3 k, then the rest below.
+// ------------------------------------------------------------------------------------------------------------------
+
+// scratch (doubles): panel p keeps its 16 columns for the rows >= 16 p, column-major, pcol_p[jj * W_p + (row - 16 p)], W_p = 64 - 16 p
+__host__ __device__ constexpr int pcol_off(int p) { return p == 0 ? 0 : (p == 1 ? 1024 : (p == 2 ? 1792 : 2304)); }
+constexpr int RV_OFF = 2560;            // 64 reciprocal pivots, by column of the tile; 0.0 = column not there yet
+constexpr int TFLAG_OFF = 2624;         // 32 ints: words the waves of a tile pass to each other (below)
+constexpr int WK_ELEMS = 2640;
+typedef __attribute__((address_space(3))) volatile int tile_word;
+enum { TF_CS = 0 /* +p: the columns of panel p are in Ts */, TF_I = 4 /* +k: X_kk is in Xs */, TF_X10 = 8, TF_X21 = 9, TF_X20 = 10, TF_S32 = 11,
+       TF_BAD = 12 /* +wave: a non-positive pivot, or a wait that gave up */, TF_SIDE = 16 /* .. 23: the Side's own words */, TF_WORDS = 24 };
+constexpr int TILE_SPIN_LIMIT = 1 << 16;    // polls (>= 64 cycles each) of one wave over one tile: past it the waits fall through, the tile is wrong and flagged `bad`
+
+__device__ __forceinline__ void tile_wait(tile_word* w, int& spins) {
+#pragma clang loop unroll(disable)
+    while (*w == 0 && spins < TILE_SPIN_LIMIT) {
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+    }
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void tile_set(tile_word* w, int lane) {
+    asm volatile("" ::: "memory");          // (after this wave's LDS stores in program order; the LDS serves a wave's operations in order)
+    if (lane == 0) *w = 1;
+}
+
+// The wave that owns panel KB factors it: columns [16 KB, 16 KB + 16), rows >= 16 KB, one row per lane, from registers.
 //
 // A single wave issues one fp64 VALU instruction every ~8 cycles whatever the dependencies
 // (measured, tools/mb2.hip), so this routine is written for instruction count:
 //   * square-root-free (LDL^T) elimination, columns scaled by rsqrt(p_j) at the end, one rsqrt
 //     per lane instead of one per step;
-//   * no row masks: a finished row (r <= j) keeps "updating" only entries above its diagonal,
-//     which nobody reads (the strict upper triangle of the block is zeroed by the caller);
+//   * no row masks inside the panel: a finished row (r <= j) keeps "updating" only entries above its diagonal,
+//     which nobody reads (they are stored as zeros);
 //   * the pivot and the one multiplicand the next column needs travel lane -> SGPR by
-//     v_readlane; the other multiplicands of a step are re-read from an LDS copy of the column
+//     v_readlane; the other multiplicands of a step are re-read from the panel scratch
 //     as wave-uniform operands (one ds_read_b128 per two rank-1 updates).
-__device__ __forceinline__ void panel_factor16(double* Ts, double* rinvs, double* lcol_in, int c0, int lane,
-                                               bool& bad, unsigned long long* dbg = nullptr) {
-    const int r = lane;
-    // Make the LDS base opaque to the compiler: with a known constant address it materialises
-    // every broadcast read address with an s_add + v_mov pair; with a VGPR base the constant part
-    // goes into the instruction's offset field.
-    // (The opaque pointer is an LDS pointer, address space 3: left generic, every access of the chain below became a FLAT
-    // load / store -- 64-bit address arithmetic, both vmcnt and lgkmcnt to wait for, a longer round trip than ds_read.)
-#if GMRF_PANEL_FLAT_LDS
-    double* lcol = lcol_in;
-#else
+template <int KB>
+__device__ __forceinline__ void panel_lead(double (&a)[16], double* Ts, double* rinvs, double* Wk, int lane, bool& bad,
+                                           unsigned long long* dbg = nullptr) {
+    constexpr int PW = 16, c0 = PW * KB, W = 64 - c0;
     typedef __attribute__((address_space(3))) double lds_double;
-    lds_double* lcol = (lds_double*)lcol_in;
-#endif
-    asm volatile("" : "+v"(lcol));
-    double a[16];
+    typedef __attribute__((address_space(3))) v2d lds_v2d;
+    const int r = lane;
+    if (r >= c0) {                                         // (lanes above the panel hold nothing of it)
+        // Make the LDS bases opaque to the compiler: with a known constant address it materialises
+        // every broadcast read address with an s_add + v_mov pair; with a VGPR base the constant part
+        // goes into the instruction's offset field.  (LDS pointers, address space 3: left generic, every access became FLAT.)
+        lds_double* lrow = (lds_double*)(Wk + pcol_off(KB)) + (r - c0);
+        lds_double* lun = (lds_double*)(Wk + pcol_off(KB));
+        asm volatile("" : "+v"(lrow));
+        asm volatile("" : "+v"(lun));
+        // (the reciprocal pivots of this panel, wave-uniform values, addressed off the same opaque base: as a constant address each
+        //  store cost an s_add + v_mov on the chain -- 3 236 cycles per panel against 2 960, measured)
+        lds_double* rv = lun + (RV_OFF + c0 - pcol_off(KB));
+        if (dbg && lane == c0) dbg[0] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_setprio(3);          // (the column chain is what everybody waits for; a wave of the same SIMD must not delay its issue)
+        double up[PW];                          // multiplicands of the previous step (LDS broadcast); first used in step 1
+        double lprev = 0.0;
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = Ts[r * TLD + c0 + c];
-    if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memtime();
-    double up[16];                          // multiplicands of the previous step (LDS broadcast)
-    double lprev = 0.0;
-#pragma unroll
-    for (int c = 0; c < 16; ++c) up[c] = 0.0;
-    auto* rv = lcol + 16 * 64;              // rinv of the 16 pivots of this panel (wave-uniform values)
-#pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-        const int j = c0 + jj;
-        // A wave issues in order: work that does not depend on the pivot chain only overlaps the
-        // chain's latency (~16-20 cycles per dependent fp64 op, tools/mb4.hip) if it sits BETWEEN the
-        // chain's instructions in program order.  The rank-1 updates of the PREVIOUS step (their
-        // multiplicands were requested from LDS one step ago) are therefore dealt into four slots
-        // between the chain operations; sched_barrier keeps the compiler from regrouping them.
+        for (int jj = 0; jj < PW; ++jj) {
+            const int j = c0 + jj;
+            // A wave issues in order: work that does not depend on the pivot chain only overlaps the
+            // chain's latency (~16-20 cycles per dependent fp64 op, tools/mb4.hip) if it sits BETWEEN the
+            // chain's instructions in program order.  The rank-1 updates of the PREVIOUS step (their
+            // multiplicands were requested from LDS one step ago) are therefore dealt into four slots
+            // between the chain operations; sched_barrier keeps the compiler from regrouping them.
 #define GMRF_DELAYED_SLOT(S)                                                                        \
-        _Pragma("unroll") for (int cc = jj + 1 + (S); cc < 16; cc += 4) a[cc] = fma(-lprev, up[cc], a[cc]); \
-        __builtin_amdgcn_sched_barrier(0);
-        const double p = bcast_lane(a[jj], j);
-        if (!(p > 0.0)) bad = true;
-        const double y = __builtin_amdgcn_rsq(p);
-        __builtin_amdgcn_sched_barrier(0);
-        GMRF_DELAYED_SLOT(1)
-        const double e = fma(-p * y, y, 1.0);
-        __builtin_amdgcn_sched_barrier(0);
-        GMRF_DELAYED_SLOT(2)
-        const double cf = fma(0.375, e, 0.5);
-        const double rinv = fma(y * e, cf, y);
-        __builtin_amdgcn_sched_barrier(0);
-        GMRF_DELAYED_SLOT(3)
-        const double l = a[jj] * rinv;       // lane j: p * rinv = sqrt(p)
-        a[jj] = l;
-        lcol[jj * 64 + r] = l;
-        asm volatile("" ::: "memory");       // (the column BEFORE its reciprocal pivot: a wave's LDS stores land in order, and
-        rv[jj] = rinv;                       //  inv16_follow takes a non-zero rv[jj] as "column jj is there"); same value from every lane: no branch
-        __builtin_amdgcn_sched_barrier(0);
-        GMRF_DELAYED_SLOT(0)                 // includes column jj + 1, needed by the update below
-        if (jj < 15) {
-            const double lc1 = bcast_lane(l, j + 1);
-            a[jj + 1] = fma(-l, lc1, a[jj + 1]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // aligned 16-byte pieces only (the scratch is 16-byte aligned, c0 a multiple of 16): left to itself the
-        // compiler merges the reads from cc = jj + 2 on into ds_read_b128 at 8-byte boundaries for odd jj
-        // (SQ_LDS_UNALIGNED_STALL was 0.42 of this kernel's LDS-active cycles)
+            if (jj > 0) { _Pragma("unroll") for (int cc = jj + 1 + (S); cc < PW; cc += 4) a[cc] = fma(-lprev, up[cc], a[cc]); } \
+            __builtin_amdgcn_sched_barrier(0);
+            const double p = bcast_lane(a[jj], j);
+            if (!(p > 0.0)) bad = true;
+            const double y = __builtin_amdgcn_rsq(p);
+            __builtin_amdgcn_sched_barrier(0);
+            GMRF_DELAYED_SLOT(1)
+            const double e = fma(-p * y, y, 1.0);
+            __builtin_amdgcn_sched_barrier(0);
+            GMRF_DELAYED_SLOT(2)
+            const double cf = fma(0.375, e, 0.5);
+            const double rinv = fma(y * e, cf, y);
+            __builtin_amdgcn_sched_barrier(0);
+            GMRF_DELAYED_SLOT(3)
+            const double l = a[jj] * rinv;       // lane j: p * rinv = sqrt(p)
+            a[jj] = l;
+            lrow[jj * W] = l;
+            asm volatile("" ::: "memory");       // (the column BEFORE its reciprocal pivot: a wave's LDS stores land in order, and
+            rv[jj] = rinv;                       //  the followers take a non-zero rv as "the column is there"); same value from every lane: no branch
+            __builtin_amdgcn_sched_barrier(0);
+            GMRF_DELAYED_SLOT(0)                 // includes column jj + 1, needed by the update below
+            if (jj < PW - 1) {
+                const double lc1 = bcast_lane(l, j + 1);
+                a[jj + 1] = fma(-l, lc1, a[jj + 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // aligned 16-byte pieces only (the scratch is 16-byte aligned, W even): left to itself the
+            // compiler merges the reads from cc = jj + 2 on into ds_read_b128 at 8-byte boundaries for odd jj
+            // (SQ_LDS_UNALIGNED_STALL was 0.42 of the tile kernel's LDS-active cycles, round 2)
 #pragma unroll
-        for (int cc = (jj + 2) & ~1; cc < 16; cc += 2) {
-#if GMRF_PANEL_FLAT_LDS
-            const v2d q = *reinterpret_cast<const v2d*>(lcol + jj * 64 + c0 + cc);
-#else
-            typedef __attribute__((address_space(3))) v2d lds_v2d;
-            const v2d q = *reinterpret_cast<const lds_v2d*>(lcol + jj * 64 + c0 + cc);
-#endif
-            if (cc >= jj + 2) up[cc] = q.x;
-            up[cc + 1] = q.y;
-        }
-        lprev = l;
-        __builtin_amdgcn_sched_barrier(0);
+            for (int cc = (jj + 2) & ~1; cc < PW; cc += 2) {
+                const v2d q = *reinterpret_cast<const lds_v2d*>(lun + jj * W + cc);
+                if (cc >= jj + 2) up[cc] = q.x;
+                up[cc + 1] = q.y;
+            }
+            lprev = l;
+            __builtin_amdgcn_sched_barrier(0);
 #undef GMRF_DELAYED_SLOT
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (dbg && lane == c0) dbg[1] = __builtin_amdgcn_s_memtime();
     }
-    if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memtime();
+    // the panel's columns of L -> Ts, all 64 rows: zeros above the diagonal (the strict upper triangle is part of the output)
 #pragma unroll
-    for (int c = 0; c < 16; ++c) Ts[r * TLD + c0 + c] = a[c];
-    if (lane < 16) rinvs[c0 + lane] = rv[lane];
-    if (dbg && lane == 0) dbg[2] = __builtin_amdgcn_s_memtime();
+    for (int c = 0; c < PW; c += 2) {
+        v2d v;
+        v.x = (r >= c0 + c) ? a[c] : 0.0;
+        v.y = (r >= c0 + c + 1) ? a[c + 1] : 0.0;
+        *reinterpret_cast<v2d*>(Ts + r * TLD + c0 + c) = v;
+    }
+    if (lane < PW) rinvs[c0 + lane] = Wk[RV_OFF + c0 + lane];
+    tile_word* fl = (tile_word*)reinterpret_cast<int*>(Wk + TFLAG_OFF);
+    tile_set(fl + TF_CS + KB, lane);
+    if (dbg && lane == c0) dbg[2] = __builtin_amdgcn_s_memtime();
+}
+
+// A waiting wave keeps what the earlier panels owe its panel [CW, CW + 16) as MFMA accumulators, one 16 x 16 block per row block
+// I >= CW / 16 (rows above the panel's diagonal block are never read): acc[I] += L[16 I + i][j] L[CW + c][j] over the columns j of
+// the leading panel, four at a time.  Per four columns: one look at the pivot word of the fourth, one operand read per block and
+// one for the panel's own rows, one MFMA per block.  `idle` is called once per group of four columns, after its MFMAs are issued:
+// the Side's chance to do a bounded piece of work (the chain workgroup of potrf_persist stores and prefetches tiles there).
+template <int KB, int CW, bool NEXT, class Idle>
+__device__ __forceinline__ void panel_follow_mfma(v4d (&acc)[4], double* Wk, int li, int lq, int& spins, Idle&& idle) {
+    constexpr int c0 = 16 * KB, W = 64 - c0, IW = CW / 16;
+    typedef __attribute__((address_space(3))) const volatile double lds_cvd;
+    lds_cvd* rv = (lds_cvd*)(Wk + RV_OFF + c0);
+    lds_cvd* pc = (lds_cvd*)(Wk + pcol_off(KB)) + lq * W + li;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        double rk = rv[4 * g + 3];
+#pragma clang loop unroll(disable)
+        while (rk == 0.0 && spins < TILE_SPIN_LIMIT) {
+            if (!NEXT) __builtin_amdgcn_s_sleep(1);     // (the wave that leads the next panel does not sleep: its last wait here is the hand-over of the chain)
+            ++spins;
+            rk = rv[4 * g + 3];
+        }
+        const double b = pc[4 * g * W + (CW - c0)];
+#pragma unroll
+        for (int I = IW; I < 4; ++I) {
+            const double a = pc[4 * g * W + (16 * I - c0)];
+            acc[I] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[I], 0, 0, 0);
+        }
+        if (!(NEXT && g == 3)) idle(4 * KB + g);
+    }
+}
+// wave `CW / 16` follows the panels 0 .. CW / 16 - 1 one after the other
+template <int CW, int KB = 0, class Idle>
+__device__ __forceinline__ void panels_follow_mfma(v4d (&acc)[4], double* Wk, int li, int lq, int& spins, Idle&& idle) {
+    if constexpr (16 * KB < CW) {
+        panel_follow_mfma<KB, CW, CW == 16 * KB + 16>(acc, Wk, li, lq, spins, idle);
+        panels_follow_mfma<CW, KB + 1>(acc, Wk, li, lq, spins, idle);
+    }
+}
+// tile - sum (ONE subtraction) -> this wave's columns of Ts -> one row per lane
+template <int CW>
+__device__ __forceinline__ void panel_to_rows(const v4d (&s0)[4], const v4d (&acc)[4], double (&a)[16], double* Ts, int lane, int li, int lq) {
+#pragma unroll
+    for (int I = CW / 16; I < 4; ++I) store_d16(Ts + (16 * I) * TLD + CW, TLD, s0[I] - acc[I], li, lq);
+    asm volatile("" ::: "memory");          // (the same wave reads them back: its LDS operations are served in order)
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+        const v2d v = *reinterpret_cast<const v2d*>(Ts + lane * TLD + CW + c);
+        a[c] = v.x; a[c + 1] = v.y;
+    }
 }
 
 // value of quad lane J (lanes 4g .. 4g+3 form a quad) in every lane of the quad: two DPP moves, no LDS
@@ -303,11 +395,10 @@ __device__ __forceinline__ double quad_bcast(double v) {
 // every later row gets its update at once -- over all 64 lanes: lane 4 c + q owns rows q, q+4, q+8, q+12 of column c,
 // so a step is one multiply in the owner lane, a quad broadcast of x[k] (DPP) and at most four fma, with every
 // entry of L and every 1/l_kk in registers before the chain starts: ~60 cycles per step.  (16 lanes with one
-// column each, L re-read from LDS inside the chain: 2 900 cycles per call, measured -- and the call for the last
-// diagonal block sits on the tile's critical path.)
+// column each, L re-read from LDS inside the chain: 2 900 cycles per call, measured.)
 __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, double* Xs, int c0, int lane) {
     const int c = lane >> 2, q = lane & 3;
-    double lv[4][16];                      // lv[i][k] = L[4 i + q][k] for 4 i + q > k, else 0 (the block's upper part holds don't-cares)
+    double lv[4][16];                      // lv[i][k] = L[4 i + q][k] for 4 i + q > k, else 0
     double rv[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -339,15 +430,16 @@ __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, dou
     for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
 }
 
-// inv16 for the LAST diagonal block, run by another wave WHILE wave 0 still factors the panel (c0 = 48): step k needs column k of
-// the block and its reciprocal pivot, which panel_factor16 leaves in the panel scratch as it goes (lcol[k * 64 + row], then
-// rv[k]); this wave waits for rv[k] to turn non-zero (the slots were cleared one panel earlier), reads the column and does the
-// step of inv16 -- the same operations on the same values, so the same X_33 bitwise -- and is done a step after wave 0 instead of
-// 2 900 cycles after the panel (the call used to open the tile's tail, on the critical path of every tile).
-__device__ __forceinline__ void inv16_follow(const double* lcol_in, double* Xs, int c0, int lane) {
+// inv16 for the diagonal block KB (columns 16 KB ..), run by another wave WHILE those columns are being factored: step k needs
+// column k of the block and its reciprocal pivot, which panel_lead leaves in the panel scratch as it goes (pcol[k][row], then
+// rv[column]); this wave waits for the rv to turn non-zero, reads the column and does the step of inv16 -- the same operations
+// on the same values, so the same X_kk bitwise -- and is done a step after the block instead of 2 900 cycles after it.
+template <int KB>
+__device__ __forceinline__ void inv16_follow(double* Wk, double* Xs, int lane, int& spins) {
+    constexpr int c0 = 16 * KB;
     typedef __attribute__((address_space(3))) const volatile double lds_cvd;
-    lds_cvd* lcol = (lds_cvd*)lcol_in;
-    lds_cvd* rvp = lcol + 16 * 64;
+    lds_cvd* wk = (lds_cvd*)Wk;
+    lds_cvd* rvp = (lds_cvd*)(Wk + RV_OFF + c0);
     const int c = lane >> 2, q = lane & 3;
     double x[4];
 #pragma unroll
@@ -355,11 +447,17 @@ __device__ __forceinline__ void inv16_follow(const double* lcol_in, double* Xs, 
 #define GMRF_INV16F_STEP(K)                                                                       \
     {                                                                                              \
         constexpr int ik = (K) / 4, qk = (K) % 4;                                                  \
+        constexpr int base = pcol_off(KB) + (K) * (64 - c0);                                       \
         double rk = rvp[K];                                                                        \
-        while (rk == 0.0) { __builtin_amdgcn_s_sleep(1); rk = rvp[K]; }                            \
+        _Pragma("clang loop unroll(disable)")                                                      \
+        while (rk == 0.0 && spins < TILE_SPIN_LIMIT) {                                             \
+            __builtin_amdgcn_s_sleep(1);                                                           \
+            ++spins;                                                                               \
+            rk = rvp[K];                                                                           \
+        }                                                                                          \
         double lvk[4];                                                                             \
         _Pragma("unroll") for (int i = ik; i < 4; ++i) {                                           \
-            const double v = lcol[(K) * 64 + c0 + 4 * i + q];                                      \
+            const double v = wk[base + 4 * i + q];                                                 \
             lvk[i] = (4 * i + q > (K)) ? v : 0.0;                                                  \
         }                                                                                          \
         const double xs = x[ik] * rk;                                                              \
@@ -376,69 +474,45 @@ __device__ __forceinline__ void inv16_follow(const double* lcol_in, double* Xs, 
     for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
 }
 
-// Trailing sub-tile (I, J) of the tile: T[I][J] -= P_I P_J^T with the panel at columns c0..c0+15.
-__device__ __forceinline__ void subtile_update(double* Ts, int I, int J, int c0, int li, int lq) {
-    double* ct = Ts + (16 * I) * TLD + 16 * J;
-    const v4d cur = load_d16(ct, TLD, li, lq);
-    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    acc = mm16_nt(Ts + (16 * I) * TLD + c0, TLD, Ts + (16 * J) * TLD + c0, TLD, acc, false, li, lq);
-    store_d16(ct, TLD, cur - acc, li, lq);
-}
-
-// Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
-// Wk: scratch of 4 * 16 * 18 doubles.  All 256 threads of the workgroup must call this.
-__device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int64_t ld, double* s, int t192);
-
-// Work that waves 1-3 do in the shadow of wave 0's panel factorisations (tile_potrf_inv is a template on this type):
-//   a0(tid)      during the first 16-column panel, where they have nothing of their own to do;
-//   b(kb, tid) / ak(kb, tid)  during panels 1 .. 3, before / after their deferred updates and inverse pieces (wave 3 is busy for
-//                most of the panel, waves 1 and 2 are nearly free): loads issued in b() fly beside that work.
-struct SideLoad {          // global 64x64 tiles staged into LDS by waves 1-3 during the first panel
-    const double* gA; double* sA;
-    const double* gB; double* sB;
-    int64_t ld;
-    unsigned long long* stamps;     // diagnostic: s_memtime at phase boundaries (tests only)
-    __device__ __forceinline__ void a0(int tid) const {
-        if (gA) side_load_tile(gA, ld, sA, tid - 64);
-        if (gB) side_load_tile(gB, ld, sB, tid - 64);
-    }
-    __device__ __forceinline__ void b(int, int) const {}
-    __device__ __forceinline__ void ak(int, int) const {}
+// What the waiting waves of a tile factorisation can do for their caller (tile_potrf_inv<Side>):
+//   idle(tick, wave, lane)   waves 1 - 3, once per four columns of a panel they follow (tick = 4 panel + group, 0 .. 11; wave w
+//                            is called for the ticks < 4 w except its last): a bounded piece of work, never a wait.
+//   extra(w, lane, fl)       waves 4 + w of a workgroup with more than four waves, between the routine's two barriers: anything that
+//                            ends by itself (fl: the routine's hand-over words, e.g. fl[TF_I + 3] != 0: the tile is done).
+struct NoSide {
+    unsigned long long* stamps = nullptr;     // diagnostic: s_memtime at phase boundaries (tests only)
+    __device__ __forceinline__ void idle(int, int, int) {}
+    __device__ __forceinline__ void extra(int, int, tile_word*) {}
 };
 
-#define TILE_STAMP(i) do { if (side.stamps && tid == 0) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TILE_STAMP(i) do { if (side.stamps) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
 
-__device__ __forceinline__ void side_load_tile(const double* __restrict__ g, int64_t ld, double* s, int t192) {
-    // all 11 loads of a thread are in flight before the first LDS store (one memory latency, not 11)
-    v2d v[11];
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int idx = t192 + 192 * i;
-        if (idx < 2048) v[i] = *reinterpret_cast<const v2d*>(g + (int64_t)(idx >> 5) * ld + (idx & 31) * 2);
-    }
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-        const int idx = t192 + 192 * i;
-        if (idx < 2048) *reinterpret_cast<v2d*>(s + (idx >> 5) * TLD + (idx & 31) * 2) = v[i];
-    }
-}
-
+// Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
+// Wk: WK_ELEMS doubles of scratch.  All threads of the workgroup must call this (waves 0 - 3 factor; more waves run Side::extra);
+// Ts must be in LDS for everybody (a barrier behind its last store) and nobody may still read Xs, Wk or rinvs.
 template <class Side>
-__device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid,
-                                               bool& bad, Side& side) {
+__device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid, bool& bad, Side& side) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
-    // clear X (its strict upper part and the blocks the assembly does not write stay zero) and
-    // the 16x16 blocks of the input above the block diagonal (they are part of the output L)
-    TILE_STAMP(0);
-    // zero the six 16x16 blocks above the block diagonal of L (part of the output) and of X
-    for (int i = tid; i < 6 * 256; i += 256) {
-        const int b = i >> 8, e = i & 255;
-        const int I = (b < 3) ? 0 : ((b < 5) ? 1 : 2);
-        const int J = (b < 3) ? b + 1 : ((b < 5) ? b - 1 : 3);
-        const int off = (16 * I + (e >> 4)) * TLD + 16 * J + (e & 15);
-        Ts[off] = 0.0;
-        Xs[off] = 0.0;
+    tile_word* fl = (tile_word*)reinterpret_cast<int*>(Wk + TFLAG_OFF);
+    if (tid == 0) TILE_STAMP(0);
+    // the words of this call: reciprocal pivots (0 = not there) and hand-over flags
+    if (tid < 64) Wk[RV_OFF + tid] = 0.0;
+    else if (tid < 64 + TF_SIDE) fl[tid - 64] = 0;
+    double a[16];
+    v4d s0[4], acc[4];                                      // waves 1 - 3: the panel as it came, and what the earlier panels owe it
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; c += 2) {
+            const v2d v = *reinterpret_cast<const v2d*>(Ts + lane * TLD + c);
+            a[c] = v.x; a[c + 1] = v.y;
+        }
+    } else if (wave < 4) {
+#pragma unroll
+        for (int I = 0; I < 4; ++I) {
+            s0[I] = load_d16(Ts + (16 * I) * TLD + 16 * wave, TLD, li, lq);
+            acc[I] = (v4d){0.0, 0.0, 0.0, 0.0};
+        }
     }
     __syncthreads();
     // --- inverse of the tile by block forward substitution over the four 16-row blocks:
@@ -446,99 +520,95 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
     // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
     // eps * cond(16x16 block); the cheaper recursive doubling X21 = -X22 (L21 X11) multiplies two
     // computed inverses and was measured 20-100x less accurate for cond(tile) >= 1e5.
-    // Schedule: block rows 1 and 2 need nothing of the last panel, so waves 1 and 2 form their sums WHILE wave 0
-    // factors it and wave 3 inverts the third diagonal block (a 16x16 substitution is 2 900 cycles: it must not sit
-    // between two panels).  Wave 1 owns block column 0, wave 2 block (2,1): everything a sum reads was written by
-    // the same wave or before a barrier; their scratch is the part of Xs that block row 3 fills at the very end --
-    // Wk belongs to the panel factorisation until then.  After the last panel: X[2][J] = -X22 * sum (one product),
-    // then the sums of block row 3 beside the last diagonal inverse (wave 3), then one product per wave.
+    // A sum is formed in the block of Xs it belongs to and replaced there by its product with the diagonal inverse (one wave: its
+    // LDS operations are served in order, and the product's operands are in registers before its result is stored).
     const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
-    auto sum_ij = [&](int I, int J) {                    // sum_{K=J..I-1} L[I][K] X[K][J]
+    auto sum_ij = [&](int I, int J) {                    // Xs[I][J] <- sum_{K=J..I-1} L[I][K] X[K][J]
         v4d t = zero;
         for (int K = J; K < I; ++K)
             t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
-        return t;
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, t, li, lq);
     };
-    auto finish_ij = [&](int I, int J, const double* scratch, int lds) {      // X[I][J] = -X[I][I] * scratch
-        const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, scratch, lds, zero, true, li, lq);
+    auto finish_ij = [&](int I, int J) {                 // Xs[I][J] <- -X[I][I] * Xs[I][J]
+        const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Xs + (16 * I) * TLD + 16 * J, TLD, zero, true, li, lq);
         store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
     };
-    double* s30 = Xs + 48 * TLD;                          // scratch: blocks (3,0) and (3,1) of Xs (row stride TLD)
-    double* s31 = Xs + 48 * TLD + 16;
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
-        const int c0 = 16 * kb;
-        TILE_STAMP(1 + 3 * kb);
-        if (wave == 0) {
-            panel_factor16(Ts, rinvs, Wk + (kb & 1) * LCOL_ELEMS, c0, lane, bad, (side.stamps && kb == 0) ? side.stamps + 20 : nullptr);
-            TILE_STAMP(2 + 3 * kb);
-        } else if (kb == 0) {
-            side.a0(tid);
-        } else {
-            side.b(kb, tid);
-            // deferred work of the previous panel (columns c0-16..c0-1): sub-tiles (I, J >= kb+1)
-            const int pc0 = c0 - 16;
-            if (kb == 1) {
-                if (wave == 1) subtile_update(Ts, 2, 2, pc0, li, lq);
-                if (wave == 2) subtile_update(Ts, 3, 2, pc0, li, lq);
-                if (wave == 3) { subtile_update(Ts, 3, 3, pc0, li, lq); }
-            } else if (kb == 2) {
-                if (wave == 1) subtile_update(Ts, 3, 3, pc0, li, lq);
-            }
-            // diagonal inverse of the previous panel: wave 3 -- in the last panel wave 2 (after its one sum), because there wave 3
-            // follows wave 0 through the panel with the LAST diagonal inverse and must start with it
-            if (kb < 3 && wave == 3) inv16(Ts, rinvs, Xs, pc0, lane);
-            if (kb == 2 && wave == 2 && lane < 16) Wk[LCOL_ELEMS + 16 * 64 + lane] = 0.0;      // rv slots of the last panel's scratch (inv16_follow)
-            if (kb == 3) {
-                // block row 1 and the sums of block row 2 (diagonal inverses 0 and 1 are final)
-                if (wave == 1) {
-                    store_d16(s30, TLD, sum_ij(1, 0), li, lq);
-                    finish_ij(1, 0, s30, TLD);
-                    store_d16(s30, TLD, sum_ij(2, 0), li, lq);
-                } else if (wave == 2) {
-                    store_d16(s31, TLD, sum_ij(2, 1), li, lq);
-                    inv16(Ts, rinvs, Xs, pc0, lane);
-                } else if (wave == 3) {
-                    // the last diagonal inverse follows wave 0 through the last panel, a step behind (round 4; it used to open the tail)
-                    inv16_follow(Wk + LCOL_ELEMS, Xs, 48, lane);
-                }
-            }
-            side.ak(kb, tid);
+    int spins = 0;
+    auto need = [&](int w) { tile_wait(fl + w, spins); };
+    auto need_cols = [&](int c_end) {                    // the columns [0, c_end) of L are in Ts
+        for (int p = 0; p < c_end / 16; ++p) tile_wait(fl + TF_CS + p, spins);
+    };
+    auto zero_x_upper = [&]() {                          // the six 16x16 blocks above the block diagonal of X (nobody reads them in here)
+        for (int i = lane; i < 6 * 256; i += 64) {
+            const int b = i >> 8, e = i & 255;
+            const int I = (b < 3) ? 0 : ((b < 5) ? 1 : 2);
+            const int J = (b < 3) ? b + 1 : ((b < 5) ? b - 1 : 3);
+            Xs[(16 * I + (e >> 4)) * TLD + 16 * J + (e & 15)] = 0.0;
         }
-        __syncthreads();
-        TILE_STAMP(3 + 3 * kb);
-        if (kb < 3) {
-            // sub-tiles of the next panel's columns: (I, kb+1), I = kb+1 .. 3
-            const int I = kb + 1 + wave;
-            if (I <= 3) subtile_update(Ts, I, kb + 1, c0, li, lq);
-        }
-        __syncthreads();
-    }
-    TILE_STAMP(13);
-    double* Wm = Wk + wave * 16 * 18;
-    // after the last panel every diagonal inverse is there (the last one followed the panel: inv16_follow): wave 1 finishes
-    // X[2][0] and forms column 0 of block row 3 (it wrote X[1][0], X[2][0] itself), wave 2 the same for column 1, wave 0 column 2
-    // (needs X[2][2] only) -- sum, then at once the product with X[3][3] -- and wave 3 zeroes the strict upper triangles of the
-    // diagonal blocks of L (don't-care values above a panel's diagonal).  One barrier.
-    if (wave == 3) {
-        for (int i = lane; i < 4 * 256; i += 64) {
-            const int b = i >> 8, e = i & 255, rr = e >> 4, cc = e & 15;
-            if (cc > rr) Ts[(16 * b + rr) * TLD + 16 * b + cc] = 0.0;
-        }
+    };
+    auto dbgp = [&](int p) -> unsigned long long* { return side.stamps ? side.stamps + 32 + 3 * p : nullptr; };
+    auto idle = [&](int tick) { side.idle(tick, wave, lane); };
+    if (wave == 0) {
+        panel_lead<0>(a, Ts, rinvs, Wk, lane, bad, dbgp(0));
+        if (lane == 0) TILE_STAMP(1);
+        zero_x_upper();
+        inv16(Ts, rinvs, Xs, 0, lane);                       // (its own stores of panel 0: in order)
+        tile_set(fl + TF_I + 0, lane);
+        inv16_follow<2>(Wk, Xs, lane, spins);                // beside wave 2's panel, then beside wave 3's
+        tile_set(fl + TF_I + 2, lane);
+        if (lane == 0) TILE_STAMP(7);
+        inv16_follow<3>(Wk, Xs, lane, spins);
+        tile_set(fl + TF_I + 3, lane);
+        if (lane == 0) TILE_STAMP(8);
+        need(TF_S32);                                        // (the sum is wave 1's; the product closes the tile on this wave)
+        finish_ij(3, 2);
+    } else if (wave == 1) {
+        panels_follow_mfma<16>(acc, Wk, li, lq, spins, idle);
+        panel_to_rows<16>(s0, acc, a, Ts, lane, li, lq);
+        if (lane == 63) TILE_STAMP(57);
+        panel_lead<1>(a, Ts, rinvs, Wk, lane, bad, dbgp(1));
+        if (lane == 16) TILE_STAMP(2);
+        inv16(Ts, rinvs, Xs, 16, lane);
+        tile_set(fl + TF_I + 1, lane);
+        need(TF_I + 0); need_cols(16);
+        sum_ij(1, 0); finish_ij(1, 0);
+        tile_set(fl + TF_X10, lane);
+        need(TF_I + 2); need_cols(48);
+        sum_ij(3, 2);
+        tile_set(fl + TF_S32, lane);
+        need(TF_X21);
+        sum_ij(3, 1);
+        need(TF_I + 3);
+        finish_ij(3, 1);
+    } else if (wave == 2) {
+        panels_follow_mfma<32>(acc, Wk, li, lq, spins, idle);
+        panel_to_rows<32>(s0, acc, a, Ts, lane, li, lq);
+        if (lane == 63) TILE_STAMP(58);
+        panel_lead<2>(a, Ts, rinvs, Wk, lane, bad, dbgp(2));
+        if (lane == 32) TILE_STAMP(3);
+        need(TF_I + 1); need(TF_I + 2); need_cols(32);
+        sum_ij(2, 1); finish_ij(2, 1);
+        tile_set(fl + TF_X21, lane);
+        need(TF_I + 0); need(TF_X10);
+        sum_ij(2, 0); finish_ij(2, 0);
+        sum_ij(3, 0);
+        need(TF_I + 3);
+        finish_ij(3, 0);
+    } else if (wave == 3) {
+        panels_follow_mfma<48>(acc, Wk, li, lq, spins, idle);
+        panel_to_rows<48>(s0, acc, a, Ts, lane, li, lq);
+        if (lane == 63) TILE_STAMP(59);
+        panel_lead<3>(a, Ts, rinvs, Wk, lane, bad, dbgp(3));
+        if (lane == 48) TILE_STAMP(4);
     } else {
-        int J3 = 2;
-        if (wave == 1) {
-            finish_ij(2, 0, s30, TLD);
-            J3 = 0;
-        } else if (wave == 2) {
-            finish_ij(2, 1, s31, TLD);
-            J3 = 1;
-        }
-        store_d16(Wm, 18, sum_ij(3, J3), li, lq);
-        finish_ij(3, J3, Wm, 18);
+        side.extra(wave - 4, lane, fl);
     }
+    if (tid == 0) TILE_STAMP(13);
+    // a non-positive pivot (seen by the lanes of its panel) or a wait that gave up, in any wave, is everybody's verdict
+    if (wave < 4 && (__builtin_amdgcn_ballot_w64(bad) != 0ull || spins >= TILE_SPIN_LIMIT) && lane == 0) fl[TF_BAD + wave] = 1;
     __syncthreads();
-    TILE_STAMP(14);
+    bad = fl[TF_BAD + 0] != 0 || fl[TF_BAD + 1] != 0 || fl[TF_BAD + 2] != 0 || fl[TF_BAD + 3] != 0;
+    if (tid == 0) TILE_STAMP(14);
 }
 
 // 64x64 tile: global (row stride ld) -> LDS (row stride TLD), 256 threads.
@@ -702,10 +772,11 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
         __syncthreads();
     } else {
         tile_g2s(sa.S + oj * ld + oj, ld, Ts, tid);
-        SideLoad side;
-        side.gA = (w > 0) ? sa.S + (int64_t)r * 64 * ld + oj : nullptr; side.sA = As;
-        side.gB = (w > 0 && c != r) ? sa.S + (int64_t)c * 64 * ld + oj : nullptr; side.sB = Bs;
-        side.ld = ld; side.stamps = nullptr;
+        if (w > 0) {                                       // the two panel tiles (round 5: no longer staged beside the first panel -- every wave is busy there)
+            tile_g2s(sa.S + (int64_t)r * 64 * ld + oj, ld, As, tid);
+            if (c != r) tile_g2s(sa.S + (int64_t)c * 64 * ld + oj, ld, Bs, tid);
+        }
+        NoSide side;
         __syncthreads();
         if (stamp) sa.dbg[0] = __builtin_amdgcn_s_memtime();
         tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
@@ -777,8 +848,7 @@ __global__ __launch_bounds__(256, 2) void potrf_step(StepArgs sa) {
             }
         }
         __syncthreads();
-        SideLoad none;
-        none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+        NoSide none;
         tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
         if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
         const int64_t o1 = oj + 64;
@@ -868,136 +938,6 @@ __global__ __launch_bounds__(256, 2) void potrf_update(StepArgs sa) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Left-looking panel step for batches (replaces potrf_panel + potrf_update): inside a panel of `pw` column
-// tiles starting at j0, the tiles right of column j are not touched while column j is being formed;
-// each row tile r > j of column j receives what the panel's earlier columns owe it when its turn comes:
-//     T      = S[r,j] - sum_{p = j0}^{j-1} L[r,p] L[j,p]^T      (K = 64 (j - j0); product from zero, ONE subtraction)
-//     L[r,j] = T X_jj^T
-// and the workgroup of row r = j + 1 also brings the next diagonal tile up to date,
-//     S[j+1,j+1] -= sum_{p = j0}^{j} L[j+1,p] L[j+1,p]^T        (unless j + 1 starts the next panel: the rank-256
-//                                                                 GEMM of the panel end does it then),
-// so that a 64-column step is two launches (tile, panel) instead of three and every tile of S inside the
-// panel is read once instead of being read and re-written by up to three rank-64 updates.
-// grid (m, B), m = nt - j - 1 row tiles; 4 waves, each a 16-row strip; operands straight from L2 (no LDS
-// staging), except T, which turns from the MFMA result layout into an operand through a wave-private
-// strip of one LDS tile (34 KB per workgroup: four fit a CU).
-struct PanelLLArgs {
-    double* S; double* L; const double* X;
-    int64_t ld, pS, pL, pX;
-    int j, j0, nt;
-    int update_next_diag;          // 1: the workgroup of row j + 1 updates S[j+1,j+1]
-};
-
-__global__ __launch_bounds__(256, 2) void potrf_panel_ll(PanelLLArgs pa) {
-    double* S = pa.S + (int64_t)blockIdx.y * pa.pS;
-    double* L = pa.L + (int64_t)blockIdx.y * pa.pL;
-    const double* X = pa.X + (int64_t)blockIdx.y * pa.pX;
-    __shared__ __attribute__((aligned(16))) double Ts[TILE_ELEMS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
-    const int li = lane & 15, lq = lane >> 4;
-    const int64_t ld = pa.ld, oj = (int64_t)pa.j * 64;
-    const int r = pa.j + 1 + (int)blockIdx.x;
-    const int64_t R0 = (int64_t)r * 64 + 16 * wave;
-    const v4d zero = (v4d){0.0, 0.0, 0.0, 0.0};
-    // ---- T = S[r,j] - sum_p L[r,p] L[j,p]^T
-    v4d acc[4];
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb) acc[Jb] = zero;
-    for (int p = pa.j0; p < pa.j; ++p) {
-        const int64_t op = (int64_t)p * 64;
-        v2d a[8];
-#pragma unroll
-        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(L + (R0 + li) * ld + op + 8 * kg + 2 * lq);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-#pragma unroll
-            for (int kg = 0; kg < 8; ++kg) {
-                const v2d b = *reinterpret_cast<const v2d*>(L + (oj + 16 * Jb + li) * ld + op + 8 * kg + 2 * lq);
-                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, acc[Jb], 0, 0, 0);
-                acc[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, acc[Jb], 0, 0, 0);
-            }
-        }
-    }
-    double* tw = Ts + (16 * wave) * TLD;           // this wave's strip of the LDS tile
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            tw[(lq + 4 * q) * TLD + 16 * Jb + li] = S[(R0 + lq + 4 * q) * ld + oj + 16 * Jb + li] - acc[Jb][q];
-    // (LDS operations of one wave are served in order: the strip is read back by the wave that wrote it)
-    // ---- L[r,j] = T X_jj^T ; X lower triangular: column block Jb needs the k groups 0 .. 2 Jb + 1
-    v2d tf[8];
-#pragma unroll
-    for (int kg = 0; kg < 8; ++kg) tf[kg] = *reinterpret_cast<const v2d*>(tw + li * TLD + 8 * kg + 2 * lq);
-    v4d lo[4];
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb) {
-        lo[Jb] = zero;
-#pragma unroll
-        for (int kg = 0; kg < 2 * Jb + 2; ++kg) {
-            const v2d x = *reinterpret_cast<const v2d*>(X + (oj + 16 * Jb + li) * ld + oj + 8 * kg + 2 * lq);
-            lo[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kg].x, x.x, lo[Jb], 0, 0, 0);
-            lo[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(tf[kg].y, x.y, lo[Jb], 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) L[(R0 + lq + 4 * q) * ld + oj + 16 * Jb + li] = lo[Jb][q];
-    }
-    if (!(pa.update_next_diag && blockIdx.x == 0)) return;
-    // ---- S[j+1,j+1] -= sum_{p = j0}^{j} L[j+1,p] L[j+1,p]^T  (lower 16 x 16 blocks; r == j + 1 here)
-    // the fresh column p = j comes from LDS (every wave's strip of L[j+1,j]), the earlier ones from L2
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) tw[(lq + 4 * q) * TLD + 16 * Jb + li] = lo[Jb][q];
-    __syncthreads();
-    v4d d[4];
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb) d[Jb] = zero;
-    const int64_t C0 = (int64_t)r * 64;
-    for (int p = pa.j0; p < pa.j; ++p) {
-        const int64_t op = (int64_t)p * 64;
-        v2d a[8];
-#pragma unroll
-        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(L + (R0 + li) * ld + op + 8 * kg + 2 * lq);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-            if (Jb <= wave) {
-#pragma unroll
-                for (int kg = 0; kg < 8; ++kg) {
-                    const v2d b = *reinterpret_cast<const v2d*>(L + (C0 + 16 * Jb + li) * ld + op + 8 * kg + 2 * lq);
-                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, d[Jb], 0, 0, 0);
-                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, d[Jb], 0, 0, 0);
-                }
-            }
-        }
-    }
-    {
-        v2d a[8];
-#pragma unroll
-        for (int kg = 0; kg < 8; ++kg) a[kg] = *reinterpret_cast<const v2d*>(tw + li * TLD + 8 * kg + 2 * lq);
-#pragma unroll
-        for (int Jb = 0; Jb < 4; ++Jb) {
-            if (Jb <= wave) {
-#pragma unroll
-                for (int kg = 0; kg < 8; ++kg) {
-                    const v2d b = *reinterpret_cast<const v2d*>(Ts + (16 * Jb + li) * TLD + 8 * kg + 2 * lq);
-                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].x, b.x, d[Jb], 0, 0, 0);
-                    d[Jb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kg].y, b.y, d[Jb], 0, 0, 0);
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int Jb = 0; Jb < 4; ++Jb) {
-        if (Jb <= wave) {
-            double* cg = S + R0 * ld + C0 + 16 * Jb;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) cg[(int64_t)(lq + 4 * q) * ld + li] -= d[Jb][q];
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
 // Batches, round 3: the in-block Cholesky advances in 128-column DIAGONAL BLOCKS; everything below a diagonal block
 // is level-3 work on the GEMM kernel (K = 128 / 256) instead of rank-64 steps fed from HBM:
 //
@@ -1043,9 +983,8 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
             cpre[Jb][q] = (Jb <= wave) ? sa.S[(o1 + 16 * wave + lq + 4 * q) * ld + o1 + 16 * Jb + li] : 0.0;
     bool bad = false;
     tile_g2s(sa.S + o0 * ld + o0, ld, Ts, tid);
-    SideLoad side;
-    side.gA = sa.S + o1 * ld + o0; side.sA = As;          // S10, staged by waves 1-3 during the first 16-column panel
-    side.gB = nullptr; side.sB = nullptr; side.ld = ld; side.stamps = nullptr;
+    tile_g2s(sa.S + o1 * ld + o0, ld, As, tid);           // S10
+    NoSide side;
     __syncthreads();
     tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
     tile_s2g(Ts, sa.L + o0 * ld + o0, ld, tid);
@@ -1085,8 +1024,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128(StepArgs sa) {
         }
     }
     __syncthreads();
-    SideLoad none;
-    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+    NoSide none;
     tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
     if (bad && tid == 0) atomicCAS(sa.info, 0, sa.blk);
     tile_s2g(Ts, sa.L + o1 * ld + o1, ld, tid);
@@ -1136,8 +1074,7 @@ __global__ __launch_bounds__(256, 1) void potrf_diag128_slim(StepArgs sa) {
         s10[kg] = *reinterpret_cast<const v2d*>(sa.S + (o1 + 16 * wave + li) * ld + o0 + 8 * kg + 2 * lq);
     bool bad = false;
     tile_g2s(sa.S + o0 * ld + o0, ld, Ts, tid);
-    SideLoad none;
-    none.gA = nullptr; none.gB = nullptr; none.sA = nullptr; none.sB = nullptr; none.ld = 0; none.stamps = nullptr;
+    NoSide none;
     __syncthreads();
     tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, none);
     tile_s2g(Ts, sa.L + o0 * ld + o0, ld, tid);
@@ -1210,8 +1147,8 @@ __global__ __launch_bounds__(256, 2) void potrf_tile_kernel(const double* S, dou
     tile_g2s(S, 64, Ts, tid);
     __syncthreads();
     bool bad = false;
-    SideLoad side;
-    side.gA = nullptr; side.gB = nullptr; side.sA = nullptr; side.sB = nullptr; side.ld = 0; side.stamps = stamps;
+    NoSide side;
+    side.stamps = stamps;
     if (stamps && tid == 0) stamps[15] = __builtin_amdgcn_s_memtime();
     tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, side);
     if (bad && tid == 0) atomicCAS(info, 0, 1);

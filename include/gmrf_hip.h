@@ -84,7 +84,8 @@ typedef struct {
      * 10 spmm_bxt (sparse C = B X^T)          13 gemm_f64_ll (32 x 32 tile GEMM of small launches)
      * 14 / 15 gemm_f64_dma<.., B [n][k]> / <.., B [k][n]> (LDS-DMA staged GEMM: the batches' products since round 3)
      * 16 potrf_diag128 (128 x 128 diagonal block of a batch: two tile Choleskys + the block's inverse)
-     * 17 potrf_panel256 (the 128^3 products of a 256-column panel of a batch, one workgroup per problem: round 4)
+     * 17 potrf_persist (one problem: the in-block Cholesky of a block / a 256-column panel in ONE persistent launch; small
+     *    batches: the 256 x 256 diagonal block of a panel.  Round 4 booked these under class 1; class 17 was potrf_panel256, removed)
      * 18 gemm_f64_dma<.., A [k][m]> (the A^T B products of selected inversion: round 4)
      * work = algorithmic flops (0-2, 6-9, 11-18) or algorithmic bytes (3-5, 10). */
 #define GMRF_KERNEL_CLASSES 24
@@ -92,6 +93,16 @@ typedef struct {
     double kernel_work[GMRF_KERNEL_CLASSES];
     int64_t kernel_launches[GMRF_KERNEL_CLASSES];
     double sweep_bytes_streamed;  /* bytes the last sweep really read: Linv triangles + C inside the staircase + 16 n k */
+    /* persistent launches (potrf_persist: one launch per block / per 256-column panel / per panel diagonal block; round 4),
+     * made observable in round 5 (failure detection): */
+    int32_t persist_route;        /* form the LAST factorisation launched: 0 none (launch per step / potrf_diag128 + GEMM), 1 one launch per
+                                   * block (one problem, blocks of up to 16 tiles), 2 one per 256-column panel (one problem, larger
+                                   * blocks), 3 one per 256 x 256 diagonal block of a panel (small batches) */
+    int32_t persist_aborts;       /* times a bounded wait inside a persistent launch of this handle gave up: the range was repeated
+                                   * with the launch-per-step form, which the handle keeps until it is destroyed */
+    int32_t persist_cus;          /* CUs this handle holds of its device's budget for persistent launches (every workgroup of such a
+                                   * launch must be resident; the claims of all handles of a device never exceed its CU count) */
+    int32_t persist_refused;      /* 1: the budget refused this handle's claim (other handles hold the CUs): no persistent launches */
 } gmrf_stats;
 
 /* ------------------------------------------------------------------ life cycle */
@@ -325,14 +336,15 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * panel step also for batch 1; bit 2: keep 64-multiples of right-hand sides on sweep_mm;
  * bit 3: C = B X^T by the dense GEMM even when the lower blocks are sparse; bit 4: second
  * branch in the captured factor graph (inverse assembly beside the panel chain; experiment); bit 5:
- * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc); bit 6:
- * batches factor a panel left-looking (tile + potrf_panel_ll launches; measured slower, kept for comparison); bit 7:
+ * ignore the staircase of the coupling blocks (dense window; takes effect at the next factor_csc); bit 7:
  * one problem assembles Linv by recursive doubling after the panel steps instead of row by row inside them; bit 8:
- * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain; bit 10: batches
- * factor a block by 64-column steps (tile, potrf_panel, potrf_update: the round-2 path) instead of 128-column diagonal
- * blocks with GEMM panels (comparison); bit 11: the rows below a 256-column panel meet its two 128 x 128 inverses one after the
- * other (three K = 128 products per panel) instead of the panel's 256 x 256 inverse in one K = 256 product (comparison);
- * bit 12: batches always assemble the full block inverses (no split representation; comparison). */
+ * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain;
+ * bit 12: batches always assemble the full block inverses (no split representation; comparison); bit 13: no persistent
+ * launches (potrf_persist) -- the launch-per-step forms; bit 15: small batches keep potrf_diag128 + the 128^3 products
+ * instead of one persistent launch per panel diagonal block; bit 16: the mean's backward sweep is NOT fused into the sample
+ * sweep (gmrf_bt_posterior_async takes the round-4 sequence; comparison).
+ * (Bits 6, 9, 10, 11, 14 selected comparison routes that lost twice -- left-looking panels, in-panel updates on the GEMM kernel,
+ * rank-64 panel steps of batches, 128-column panels, potrf_panel256 -- and were removed with them in round 5; they are ignored.) */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);
 gmrf_status gmrf_bt_synchronize(gmrf_handle* h);
 
@@ -485,9 +497,13 @@ gmrf_status gmrf_test_potrf_block(int32_t device, int64_t bs, double* S /* in/ou
 /* s_memtime stamps of the chain workgroup of the last gmrf_test_potrf_block that took the persistent form
  * (csrc/potrf_persist.hpp): out[0] = tile 0 done, then eight per step (tools/persist_stamps.py names them); cycles relative to out[0], -1 = not written. */
 gmrf_status gmrf_test_persist_stamps(double* out, int32_t n);
-/* factorisations of this handle that were repeated with the launch-per-step form because a bounded wait inside a persistent
- * launch gave up (GMRF_PERSIST_SPIN_MS, default 2000) */
+/* block ranges of this handle that were repeated with the launch-per-step form because a bounded wait inside a persistent
+ * launch gave up (GMRF_PERSIST_SPIN_MS: default 2000 for one problem, 200 for batches); also in gmrf_stats.persist_aborts */
 gmrf_status gmrf_test_persist_aborts(gmrf_handle* h, int32_t* n);
+/* The per-device budget of CUs for persistent launches, host only (no GPU needed): `n` handles ask for demands[i] CUs one after
+ * the other on a device of `cus` CUs; granted[i] = 1 if the claim fitted beside the earlier ones, 0 if it was refused (the
+ * handle would take the launch-per-step routes up front instead of meeting a bounded wait). */
+gmrf_status gmrf_test_persist_budget(int32_t cus, int32_t n, const int32_t* demands, int32_t* granted);
 gmrf_status gmrf_test_mfma_f64_rate(int32_t device, double* tflops);
 /* Shader clock under load: _start launches a bounded probe (8 waves stamping s_memtime / s_memrealtime every ~3.4 us x sleeps,
  * n samples) on a stream of its own and returns; run the load under test; _finish waits and returns n - 1 interval clocks in GHz

@@ -279,6 +279,7 @@ struct GmrfStats                             # gmrf_stats
     n::Int64; n_blocks::Int64; block_size::Int64; block_size_padded::Int64; factor_bytes::Int64
     kernel_ms::NTuple{24,Float64}; kernel_work::NTuple{24,Float64}; kernel_launches::NTuple{24,Int64}
     sweep_bytes_streamed::Float64
+    persist_route::Int32; persist_aborts::Int32; persist_cus::Int32; persist_refused::Int32
 end
 
 function stats(F::TridiagonalCholeskyFactor)

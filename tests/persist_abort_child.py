@@ -37,6 +37,30 @@ out["single_aborts_of_the_step_form"] = aborts(Fs)
 out["single_equal"] = bool(np.array_equal(mu, pkg.ldiv(Fs, w.rhs)) and np.array_equal(mu, mu2)
                            and np.array_equal(F.chos[7], Fs.chos[7]))
 out["single_logdet_equal"] = bool(F.logdet() == Fs.logdet())
+keys = ("persist_aborts", "persist_route", "persist_cus", "persist_refused")
+out["single_stats"] = {k: F.stats()[k] for k in keys}
+F.set_eager(0); F.refactor(w.Q.data)       # (bit 13 clear: a handle that gave a persistent launch up does not get the form back)
+out["single_after_set_eager_0"] = {k: F.stats()[k] for k in keys}
+# stepwise (the shared-factor job): every range is packed right after its step, as HipEngine.share_range does
+import torch
+Fp = pkg.TridiagonalCholeskyFactor()
+Fp.factor_begin(w.Q, w.n_blocks)
+Fq = pkg.TridiagonalCholeskyFactor(); Fq.set_eager(8192)
+Fq.factor_begin(w.Q, w.n_blocks)
+same = True
+for i0 in range(0, w.n_blocks, 4):
+    imgs = []
+    for G in (Fp, Fq):
+        G.factor_step_async(i0, i0 + 4)
+        buf = torch.zeros((1, G.packed_size(i0, i0 + 4)), dtype=torch.float64, device="cuda")
+        G.pack_blocks_async(i0, i0 + 4, buf)
+        G.synchronize()
+        imgs.append(buf.cpu().numpy())
+    same = same and bool(np.array_equal(imgs[0], imgs[1]))
+Fp.factor_end(); Fq.factor_end()
+out["stepwise_aborts"] = aborts(Fp)
+out["stepwise_images_equal"] = same
+out["stepwise_solve_equal"] = bool(np.array_equal(pkg.ldiv(Fp, w.rhs), pkg.ldiv(Fq, w.rhs)))
 # a small batch: one persistent launch per 256-column panel (burgers512x64 as a batch of two)
 w = pkg.workloads.make("burgers512x64")
 vals = np.stack([w.Q.data, w.Q.data * 1.25])

@@ -114,8 +114,9 @@ def _spd(n, seed, cond_boost=0.0):
     return G @ G.T + (n + cond_boost) * np.eye(n)
 
 
-def test_potrf_tile_and_inverse(lib, pkg):
-    A = _spd(64, 1)
+@pytest.mark.parametrize("seed", [1, 7])
+def test_potrf_tile_and_inverse(lib, pkg, seed):
+    A = _spd(64, seed)
     t = A.copy(); inv = np.zeros((64, 64)); info = C.c_int32(0)
     pkg._cabi.check(lib.gmrf_test_potrf_tile(0, pkg._cabi.ptr(t), pkg._cabi.ptr(inv), C.byref(info)))
     L = np.linalg.cholesky(A)
@@ -125,9 +126,10 @@ def test_potrf_tile_and_inverse(lib, pkg):
     assert np.max(np.abs(inv @ L - np.eye(64))) < 1e-12
 
 
-def test_potrf_tile_reports_non_spd(lib, pkg):
+@pytest.mark.parametrize("where", [3, 17, 40, 63])          # one pivot in each wave's panel
+def test_potrf_tile_reports_non_spd(lib, pkg, where):
     A = _spd(64, 2)
-    A[40, 40] = -1.0
+    A[where, where] = -1.0
     t = A.copy(); inv = np.zeros((64, 64)); info = C.c_int32(0)
     pkg._cabi.check(lib.gmrf_test_potrf_tile(0, pkg._cabi.ptr(t), pkg._cabi.ptr(inv), C.byref(info)))
     assert info.value == 1

@@ -51,6 +51,23 @@ def test_storage_size_query_needs_no_gpu(pkg, lib):
     assert lib.gmrf_bt_storage_bytes(64, 1, 0, C.byref(a), C.byref(b), C.byref(c)) == pkg._cabi.ERR_BAD_SHAPE
 
 
+def test_persistent_launch_budget_refuses_a_fifth_batched_handle(pkg, lib):
+    """Round 5: every workgroup of a persistent launch must be resident, so the handles of a device share a
+    budget of its CUs (gmrf_handle::persist_cus; persist_plan in csrc/gmrf_hip.hip).  Four StreamSet handles of batch 8 ask for
+    4 x 8 x 7 = 224 of 256 CUs and get them; a fifth is refused UP FRONT (it takes potrf_diag128 + GEMM) instead of meeting the
+    200 ms bound of a wait; two one-problem handles of 135 workgroups (darcy256) do not fit together either."""
+    import ctypes as C
+
+    def grant(cus, demands):
+        d = (C.c_int32 * len(demands))(*demands); g = (C.c_int32 * len(demands))()
+        pkg._cabi.check(lib.gmrf_test_persist_budget(cus, len(demands), d, g))
+        return list(g)
+    assert grant(256, [56] * 5) == [1, 1, 1, 1, 0]
+    assert grant(256, [135, 135]) == [1, 0]
+    assert grant(256, [135, 56, 56, 56]) == [1, 1, 1, 0]
+    assert grant(256, [0, 256]) == [0, 1] and grant(256, [257]) == [0]
+
+
 def test_argument_validation_in_python_layer(pkg):
     with pytest.raises(ValueError):
         pkg.tridiagonal_cholesky(sp.identity(10, format="csc"), 3)
@@ -147,9 +164,9 @@ def test_julia_shim_ccalls_match_the_header():
     # struct mirrors: same number of fields as the C structs
     stats_fields = re.search(r"typedef struct \{((?:(?!typedef struct).)*?)\} gmrf_stats;", hdr, flags=re.S).group(1)
     stats_fields = re.sub(r"/\*.*?\*/", "", stats_fields, flags=re.S)
-    n_c = len(re.findall(r"^\s*(?:double|int64_t)\s+[^;]+;", stats_fields, flags=re.M))
+    n_c = len(re.findall(r"^\s*(?:double|int64_t|int32_t)\s+[^;]+;", stats_fields, flags=re.M))
     jl = re.search(r"struct GmrfStats(.*?)\nend", src, flags=re.S).group(1)
-    c_names = [n.strip().split("[")[0] for line in re.findall(r"^\s*(?:double|int64_t)\s+([^;]+);", stats_fields, flags=re.M) for n in line.split(",")]
+    c_names = [n.strip().split("[")[0] for line in re.findall(r"^\s*(?:double|int64_t|int32_t)\s+([^;]+);", stats_fields, flags=re.M) for n in line.split(",")]
     j_names = re.findall(r"(\w+)::", jl)
     assert c_names == j_names, (c_names, j_names)
     assert n_c >= 6
