@@ -209,7 +209,18 @@ __device__ __forceinline__ void strip_store_sc1(double* g, int64_t ld, const v4d
         }
 }
 
-constexpr size_t POTRF_PERSIST_LDS = POTRF_STEP_LDS + 64;      // + the two verdict words of wg_wait, two prefetch words
+constexpr size_t POTRF_PERSIST_LDS = POTRF_STEP_LDS + 64;      // + words in LDS: two verdicts of wg_wait, four of the prefetch, the publish count, the compute waves' barrier count
+
+// A barrier of the four computing waves of the chain workgroup alone (s_barrier would wait for waves 4 - 7, which are busy
+// publishing the last tile): every wave adds one to an LDS word behind its LDS work (a wave's LDS operations are served in order)
+// and waits until the word shows that all four have.  `epoch` counts this wave's barriers.
+__device__ __forceinline__ void compute_waves_barrier(lds_word* cnt, int& epoch, int lane) {
+    asm volatile("" ::: "memory");
+    epoch += 4;
+    if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (*cnt < epoch) {}
+    asm volatile("" ::: "memory");
+}
 
 // Diagonal tile update  T = N - L L^T  (lower 16 x 16 blocks) with the ten blocks dealt 3 / 3 / 2 / 2 over the four waves instead of
 // strip by strip (1 / 2 / 3 / 4: wave 3's 64 MFMAs were the length of the step, 4 450 cycles; now 48).  Every block is summed as
@@ -377,26 +388,47 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
         cs.gL = nullptr;
         prefetch_for(pa.j0);
         __syncthreads();
+        // X_jj is what every workgroup of the next step waits for.  Waves 4 - 7 store it (write through), issue the stores of L_jj
+        // (which nobody inside the launch reads) behind it, wait for all but those eight youngest stores -- a wave's stores are
+        // counted in issue order: X_jj and, issued long before, this wave's half of L[j, j-1] have arrived -- count themselves in an
+        // LDS word, and the one whose count is the fourth raises the flags (the guide's form: every storing wave waits for its
+        // stores, the wave whose add is last signals).  Waves 0 - 3 are in the next step's first product meanwhile: the publish
+        // (2 000 cycles of store issue and drain per step in round 4) and the 600 cycles of L_jj's store issue have left the chain.
+        // (Measured on the way: the step's first barrier met with `vmcnt(0)` by every wave -- waves 0 - 3 waited there for the
+        //  drain of L_jj, 2 460 cycles where 880 had been; L_jj held in 32 registers until Ts was free -- the kernel is at the 256
+        //  registers an eight-wave workgroup can have, 38 of them spilled, and the diagonal update took 6 600 cycles instead of 4 200.)
+        lds_word* pubcnt = okw + 6;
+        lds_word* cwcnt = okw + 7;
+        lds_word* tsread = okw + 8;                          // waves 4 - 7 have read L_jj out of Ts (its place is the next diagonal tile's)
+        int cw_epoch = 0, ts_epoch = 0;
+        if (tid == 0) { *pubcnt = 0; *cwcnt = 0; *tsread = 0; }
+        auto publish_tile = [&](int jt, unsigned* also) {    // waves 4 - 7
+            const int64_t ot = (int64_t)jt * 64;
+            tile_s2g_sc1(Xs, pa.X + ot * ld + ot, ld, tid - 256);
+            tile_s2g_sc1(Ts, pa.L + ot * ld + ot, ld, tid - 256);          // (eight stores per lane)
+            asm volatile("" ::: "memory");                  // (the stores are issued: their data has left LDS)
+            if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)tsread, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            if (lane == 0) {
+                const int before = __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)pubcnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if ((before & 3) == 3) {
+                    st_flag(fD + jt, 1u);
+                    if (also) st_flag(also, 1u);
+                }
+            }
+        };
         tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
         if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
-        if (cw) tile_s2g_sc1(Xs, pa.X + o0 * ld + o0, ld, tid);
-        wg_publish(fD + pa.j0, nullptr, tid);
-        if (cw) tile_s2g_sc1(Ts, pa.L + o0 * ld + o0, ld, tid);
-        // The write-through stores of L_jj drain BEHIND the next step's first product: whatever `pend1` / `pend2` name goes up at
-        // that step's first barrier, after every wave's vmcnt(0).  (The step's prefetch words were written before
-        // tile_potrf_inv's last barrier.)
-        unsigned* pend1 = nullptr;
-        unsigned* pend2 = nullptr;
+        if (!cw) publish_tile(pa.j0, nullptr);
+        // (The step's prefetch words were written before tile_potrf_inv's last barrier.)
         if (pa.stamps && tid == 0) pa.stamps[0] = __builtin_amdgcn_s_memtime();
         for (int j = pa.j0; j + 1 < pa.j1; ++j) {
             const int64_t oj = (int64_t)j * 64, o1 = oj + 64;
-            // (the publish above was a barrier: the words are what waves 4 - 7 left during the last factorisation)
+            // (tile_potrf_inv ended with a barrier: the words are what waves 4 - 7 left during the last factorisation)
             const bool pre_a = done[0] == j + 1 && done[1] == j + 1, pre_n = done[2] == j + 1 && done[3] == j + 1;
             if (pre_a && pre_n) {
                 if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 1] = __builtin_amdgcn_s_memtime();
             } else {
-                wg_publish(pend1, pend2, tid);              // (nothing stays unpublished across a wait)
-                pend1 = nullptr; pend2 = nullptr;
                 const unsigned* w1 = (j > pa.j0) ? fF + (j + 1) * nt + j : nullptr;
                 const unsigned* w2 = (j + 1 >= pa.j0 + 2) ? fF + (j + 1) * nt + (j + 1) : nullptr;
                 if (!wg_wait(w1, w2, nullptr, pa, okw, phase, tid)) return;
@@ -424,24 +456,24 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
                 }
             }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 3] = __builtin_amdgcn_s_memtime();
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the last tile's stores (every wave its own)
-            __syncthreads();
-            if (tid == 0) {
-                if (pend1) st_flag(pend1, 1u);
-                if (pend2) st_flag(pend2, 1u);
-            }
-            pend1 = nullptr; pend2 = nullptr;
+            // (waves 4 - 7 are publishing the last tile: the next two meetings are of the four computing waves alone)
             if (cw) {
+                compute_waves_barrier(cwcnt, cw_epoch, lane);    // every wave has read As
 #pragma unroll
                 for (int Jb = 0; Jb < 4; ++Jb) store_d16(As + (16 * wave) * TLD + 16 * Jb, TLD, lr[Jb], li, lq);
+                compute_waves_barrier(cwcnt, cw_epoch, lane);
             }
-            __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 4] = __builtin_amdgcn_s_memtime();
             // (L[j+1, j] leaves for global memory beside the tile factorisation below: ChainSide::extra)
             // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
             // (the ten lower blocks dealt evenly over the waves; L_jj has left Ts: its stores were drained by wg_publish; the tile
             //  (j+1, j+1) waits in Bs, prefetched or just loaded)
-            if (cw) diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
+            ts_epoch += 4;
+            if (cw) {
+                while (*tsread < ts_epoch) {}               // (long true: waves 4 - 7 read L_jj out of Ts right after the tile)
+                asm volatile("" ::: "memory");
+                diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
+            }
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();
             cs.gL = pa.L + o1 * ld + oj;
             prefetch_for(j + 1);
@@ -450,15 +482,10 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
             tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
             if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
-            // X_{j+1,j+1} is what every workgroup of the next step waits for: stored, drained and flagged at once; L_{j+1,j+1}
-            // (read by nobody inside the launch) and the flag of L[j+1, j] drain behind the next step's first product
-            if (cw) tile_s2g_sc1(Xs, pa.X + o1 * ld + o1, ld, tid);
-            wg_publish(fD + j + 1, nullptr, tid);
-            if (cw) tile_s2g_sc1(Ts, pa.L + o1 * ld + o1, ld, tid);
-            pend1 = fPL + (j + 1) * nt + j; pend2 = nullptr;
+            if (!cw) publish_tile(j + 1, fPL + (j + 1) * nt + j);      // X_{j+1,j+1} and (stored beside the tile) L[j+1, j]: drained, flagged
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();
         }
-        wg_publish(pend1, pend2, tid);
+        wg_publish(nullptr, nullptr, tid);                   // (every store of this workgroup has arrived before it counts itself out)
         return;
     }
 

@@ -217,7 +217,7 @@ constexpr int RV_OFF = 2560;            // 64 reciprocal pivots, by column of th
 constexpr int TFLAG_OFF = 2624;         // 32 ints: words the waves of a tile pass to each other (below)
 constexpr int WK_ELEMS = 2640;
 typedef __attribute__((address_space(3))) volatile int tile_word;
-enum { TF_CS = 0 /* +p: the columns of panel p are in Ts */, TF_I = 4 /* +k: X_kk is in Xs */, TF_X10 = 8, TF_X21 = 9, TF_X20 = 10, TF_S32 = 11,
+enum { TF_CS = 0 /* +p: the columns of panel p are in Ts */, TF_I = 4 /* +k: X_kk is in Xs */, TF_X10 = 8, TF_X21 = 9, TF_X20 = 10,
        TF_BAD = 12 /* +wave: a non-positive pivot, or a wait that gave up */, TF_SIDE = 16 /* .. 23: the Side's own words */, TF_WORDS = 24 };
 constexpr int TILE_SPIN_LIMIT = 1 << 16;    // polls (>= 64 cycles each) of one wave over one tile: past it the waits fall through, the tile is wrong and flagged `bad`
 
@@ -430,48 +430,63 @@ __device__ __forceinline__ void inv16(const double* Ts, const double* rinvs, dou
     for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
 }
 
-// inv16 for the diagonal block KB (columns 16 KB ..), run by another wave WHILE those columns are being factored: step k needs
-// column k of the block and its reciprocal pivot, which panel_lead leaves in the panel scratch as it goes (pcol[k][row], then
-// rv[column]); this wave waits for the rv to turn non-zero, reads the column and does the step of inv16 -- the same operations
-// on the same values, so the same X_kk bitwise -- and is done a step after the block instead of 2 900 cycles after it.
-template <int KB>
-__device__ __forceinline__ void inv16_follow(double* Wk, double* Xs, int lane, int& spins) {
+// Y = L_kk^-1 R for NR right-hand sides R (16 x 16 each) of the diagonal block KB (columns 16 KB ..), run by another wave WHILE
+// those columns are being factored: step k needs column k of the block and its reciprocal pivot, which panel_lead leaves in the
+// panel scratch as it goes (pcol[k][row], then rv[column]); this wave looks at the pivot word -- and, behind it in the LDS queue,
+// at the column -- until the word is non-zero, and does the step of the column-oriented substitution of inv16 (lane 4 c + q owns
+// rows q, q + 4, q + 8, q + 12 of column c of every right-hand side).  R = I gives X_kk with the operations of inv16 on the same
+// values, bitwise.  (NR > 1, or R = -S_3J to get the last block row of the tile inverse without waiting for X_33: built and
+// measured -- a step with two right-hand sides is ~40 instructions, ~320 cycles for a lone wave against the leader's ~190 per
+// column, and the tile got 800 cycles LONGER; the last block row stays a product with X_33, one per wave.)
+template <int KB, int NR>
+__device__ __forceinline__ void solve16_follow(double* Wk, double (&x)[NR][4], int lane, int& spins) {
     constexpr int c0 = 16 * KB;
     typedef __attribute__((address_space(3))) const volatile double lds_cvd;
     lds_cvd* wk = (lds_cvd*)Wk;
     lds_cvd* rvp = (lds_cvd*)(Wk + RV_OFF + c0);
-    const int c = lane >> 2, q = lane & 3;
-    double x[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) x[i] = (4 * i + q == c) ? 1.0 : 0.0;
-#define GMRF_INV16F_STEP(K)                                                                       \
+    const int q = lane & 3;
+#define GMRF_SOLVE16F_STEP(K)                                                                     \
     {                                                                                              \
         constexpr int ik = (K) / 4, qk = (K) % 4;                                                  \
         constexpr int base = pcol_off(KB) + (K) * (64 - c0);                                       \
         double rk = rvp[K];                                                                        \
+        double lvk[4];                                                                             \
+        _Pragma("unroll") for (int i = ik; i < 4; ++i) lvk[i] = wk[base + 4 * i + q];             \
         _Pragma("clang loop unroll(disable)")                                                      \
         while (rk == 0.0 && spins < TILE_SPIN_LIMIT) {                                             \
-            __builtin_amdgcn_s_sleep(1);                                                           \
             ++spins;                                                                               \
             rk = rvp[K];                                                                           \
+            _Pragma("unroll") for (int i = ik; i < 4; ++i) lvk[i] = wk[base + 4 * i + q];         \
         }                                                                                          \
-        double lvk[4];                                                                             \
-        _Pragma("unroll") for (int i = ik; i < 4; ++i) {                                           \
-            const double v = wk[base + 4 * i + q];                                                 \
-            lvk[i] = (4 * i + q > (K)) ? v : 0.0;                                                  \
+        lvk[ik] = (4 * ik + q > (K)) ? lvk[ik] : 0.0;   /* (the rows of the later groups are all below row K) */ \
+        _Pragma("unroll") for (int r = 0; r < NR; ++r) {                                           \
+            const double xs = x[r][ik] * rk;                                                       \
+            if (q == qk) x[r][ik] = xs;               /* rows above the step's diagonal keep their values */ \
+            const double xk = quad_bcast<qk>(x[r][ik]);                                            \
+            _Pragma("unroll") for (int i = ik; i < 4; ++i) x[r][i] = fma(-lvk[i], xk, x[r][i]);   \
         }                                                                                          \
-        const double xs = x[ik] * rk;                                                              \
-        if (q == qk) x[ik] = xs;                                                                   \
-        const double xk = quad_bcast<qk>(x[ik]);                                                   \
-        _Pragma("unroll") for (int i = ik; i < 4; ++i) x[i] = fma(-lvk[i], xk, x[i]);             \
     }
-    GMRF_INV16F_STEP(0) GMRF_INV16F_STEP(1) GMRF_INV16F_STEP(2) GMRF_INV16F_STEP(3)
-    GMRF_INV16F_STEP(4) GMRF_INV16F_STEP(5) GMRF_INV16F_STEP(6) GMRF_INV16F_STEP(7)
-    GMRF_INV16F_STEP(8) GMRF_INV16F_STEP(9) GMRF_INV16F_STEP(10) GMRF_INV16F_STEP(11)
-    GMRF_INV16F_STEP(12) GMRF_INV16F_STEP(13) GMRF_INV16F_STEP(14) GMRF_INV16F_STEP(15)
-#undef GMRF_INV16F_STEP
+    GMRF_SOLVE16F_STEP(0) GMRF_SOLVE16F_STEP(1) GMRF_SOLVE16F_STEP(2) GMRF_SOLVE16F_STEP(3)
+    GMRF_SOLVE16F_STEP(4) GMRF_SOLVE16F_STEP(5) GMRF_SOLVE16F_STEP(6) GMRF_SOLVE16F_STEP(7)
+    GMRF_SOLVE16F_STEP(8) GMRF_SOLVE16F_STEP(9) GMRF_SOLVE16F_STEP(10) GMRF_SOLVE16F_STEP(11)
+    GMRF_SOLVE16F_STEP(12) GMRF_SOLVE16F_STEP(13) GMRF_SOLVE16F_STEP(14) GMRF_SOLVE16F_STEP(15)
+#undef GMRF_SOLVE16F_STEP
+}
+// right-hand side / result of solve16_follow <-> a 16 x 16 block in LDS (row stride ld): lane 4 c + q, register i <-> (4 i + q, c)
+__device__ __forceinline__ void solve16_rhs_identity(double (&x)[4], int lane) {
+    const int c = lane >> 2, q = lane & 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) Xs[(c0 + 4 * i + q) * TLD + c0 + c] = x[i];
+    for (int i = 0; i < 4; ++i) x[i] = (4 * i + q == c) ? 1.0 : 0.0;
+}
+__device__ __forceinline__ void solve16_rhs_neg(double (&x)[4], const double* blk, int ld, int lane) {
+    const int c = lane >> 2, q = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x[i] = -blk[(4 * i + q) * ld + c];
+}
+__device__ __forceinline__ void solve16_store(const double (&x)[4], double* blk, int ld, int lane) {
+    const int c = lane >> 2, q = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) blk[(4 * i + q) * ld + c] = x[i];
 }
 
 // What the waiting waves of a tile factorisation can do for their caller (tile_potrf_inv<Side>):
@@ -548,20 +563,43 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
     };
     auto dbgp = [&](int p) -> unsigned long long* { return side.stamps ? side.stamps + 32 + 3 * p : nullptr; };
     auto idle = [&](int tick) { side.idle(tick, wave, lane); };
+    // accumulate one more product into a sum that waits in its block of Xs:  Xs[I][J] += L[I][K] X[K][J]
+    auto add_ij = [&](int I, int J, int K) {
+        v4d t = load_d16(Xs + (16 * I) * TLD + 16 * J, TLD, li, lq);
+        t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, t, li, lq);
+    };
+    auto sum_upto = [&](int I, int J, int Kend) {        // Xs[I][J] <- sum_{K=J..Kend-1} L[I][K] X[K][J]
+        v4d t = zero;
+        for (int K = J; K < Kend; ++K)
+            t = mm16_nn(Ts + (16 * I) * TLD + 16 * K, TLD, Xs + (16 * K) * TLD + 16 * J, TLD, t, false, li, lq);
+        store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, t, li, lq);
+    };
     if (wave == 0) {
         panel_lead<0>(a, Ts, rinvs, Wk, lane, bad, dbgp(0));
         if (lane == 0) TILE_STAMP(1);
         zero_x_upper();
         inv16(Ts, rinvs, Xs, 0, lane);                       // (its own stores of panel 0: in order)
         tile_set(fl + TF_I + 0, lane);
-        inv16_follow<2>(Wk, Xs, lane, spins);                // beside wave 2's panel, then beside wave 3's
+        {   // X_22 beside wave 2's panel
+            double x[1][4];
+            solve16_rhs_identity(x[0], lane);
+            solve16_follow<2, 1>(Wk, x, lane, spins);
+            solve16_store(x[0], Xs + 32 * TLD + 32, TLD, lane);
+        }
         tile_set(fl + TF_I + 2, lane);
         if (lane == 0) TILE_STAMP(7);
-        inv16_follow<3>(Wk, Xs, lane, spins);
+        need_cols(48);
+        sum_ij(3, 2);                                        // S_32 = L_32 X_22
+        {   // X_33 beside wave 3's panel
+            double x[1][4];
+            solve16_rhs_identity(x[0], lane);
+            solve16_follow<3, 1>(Wk, x, lane, spins);
+            solve16_store(x[0], Xs + 48 * TLD + 48, TLD, lane);
+        }
         tile_set(fl + TF_I + 3, lane);
         if (lane == 0) TILE_STAMP(8);
-        need(TF_S32);                                        // (the sum is wave 1's; the product closes the tile on this wave)
-        finish_ij(3, 2);
+        finish_ij(3, 2);                                     // (the last block row: one product with X_33 per wave)
     } else if (wave == 1) {
         panels_follow_mfma<16>(acc, Wk, li, lq, spins, idle);
         panel_to_rows<16>(s0, acc, a, Ts, lane, li, lq);
@@ -573,11 +611,18 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         need(TF_I + 0); need_cols(16);
         sum_ij(1, 0); finish_ij(1, 0);
         tile_set(fl + TF_X10, lane);
-        need(TF_I + 2); need_cols(48);
-        sum_ij(3, 2);
-        tile_set(fl + TF_S32, lane);
-        need(TF_X21);
-        sum_ij(3, 1);
+        // everything of block rows 2 and 3 that needs neither X_22 nor panel 2's columns, while panel 2 is being factored
+        sum_ij(2, 1);                                        // L_21 X_11
+        sum_ij(2, 0);                                        // L_20 X_00 + L_21 X_10
+        sum_upto(3, 1, 2);                                   // L_31 X_11
+        sum_upto(3, 0, 2);                                   // L_30 X_00 + L_31 X_10
+        need(TF_I + 2);
+        finish_ij(2, 1);
+        tile_set(fl + TF_X21, lane);
+        finish_ij(2, 0);
+        tile_set(fl + TF_X20, lane);
+        need_cols(48);
+        add_ij(3, 1, 2);                                     // + L_32 X_21
         need(TF_I + 3);
         finish_ij(3, 1);
     } else if (wave == 2) {
@@ -586,12 +631,8 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         if (lane == 63) TILE_STAMP(58);
         panel_lead<2>(a, Ts, rinvs, Wk, lane, bad, dbgp(2));
         if (lane == 32) TILE_STAMP(3);
-        need(TF_I + 1); need(TF_I + 2); need_cols(32);
-        sum_ij(2, 1); finish_ij(2, 1);
-        tile_set(fl + TF_X21, lane);
-        need(TF_I + 0); need(TF_X10);
-        sum_ij(2, 0); finish_ij(2, 0);
-        sum_ij(3, 0);
+        need(TF_X20);                                        // (wave 1 formed the sums of block (3, 0) up to K = 1 before it)
+        add_ij(3, 0, 2);                                     // + L_32 X_20
         need(TF_I + 3);
         finish_ij(3, 0);
     } else if (wave == 3) {
