@@ -2096,7 +2096,7 @@ static gmrf_status pack_blocks_on(gmrf_handle* h, hipStream_t st, int64_t i0, in
         HIPCHK(hipMemcpy2DAsync(buf + xe + ce + 2, seg * sizeof(double), h->d_logdet + i0, h->N * sizeof(double),
                                 (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
     } else {
-        hipLaunchKernelGGL(pack_tag_read, dim3(1), dim3(1), 0, st, buf + xe + ce, h->d_info + 2);
+        hipLaunchKernelGGL(pack_tag_read, dim3(1), dim3(1), 0, st, buf + xe + ce, seg, (int)h->B, h->d_info + 2);
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpy2DAsync(h->d_logdet + i0, h->N * sizeof(double), buf + xe + ce + 2, seg * sizeof(double),
                                 (i1 - i0) * sizeof(double), (size_t)h->B, hipMemcpyDeviceToDevice, st));
@@ -4009,21 +4009,35 @@ gmrf_status gmrf_test_clock_probe_start(int32_t device, int32_t n, int32_t sleep
     if (!probe || n < 2 || n > 100000 || sleeps < 1 || sleeps > 64) return bad_shape("clock probe: 2 <= n <= 100000, 1 <= sleeps <= 64");
     HIPCHK(hipSetDevice(device));
     ClockProbe* p = new ClockProbe{device, nullptr, nullptr, n};
-    HIPCHK(hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking));
-    HIPCHK(hipMalloc(&p->d, sizeof(unsigned long long) * 2 * 8 * (size_t)n));
-    HIPCHK(hipMemsetAsync(p->d, 0, sizeof(unsigned long long) * 2 * 8 * (size_t)n, p->st));
+    auto drop = [&](hipError_t e) {                 // (no probe, stream or buffer is left behind on an error path: ADVICE r4)
+        if (p->d) (void)hipFree(p->d);
+        if (p->st) (void)hipStreamDestroy(p->st);
+        delete p;
+        g_last_error = std::string("clock probe: ") + hipGetErrorString(e);
+        return GMRF_ERR_HIP;
+    };
+    hipError_t e = hipStreamCreateWithFlags(&p->st, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc(&p->d, sizeof(unsigned long long) * 2 * 8 * (size_t)n);
+    if (e == hipSuccess) e = hipMemsetAsync(p->d, 0, sizeof(unsigned long long) * 2 * 8 * (size_t)n, p->st);
+    if (e != hipSuccess) return drop(e);
     hipLaunchKernelGGL(clock_probe_kernel, dim3(8), dim3(64), 0, p->st, p->d, n, sleeps);
-    HIPCHK(hipGetLastError());
+    if ((e = hipGetLastError()) != hipSuccess) return drop(e);
     *probe = p;
     return GMRF_OK;
 }
 gmrf_status gmrf_test_clock_probe_finish(void* probe, double* ghz, double* t_ms) {
     ClockProbe* p = static_cast<ClockProbe*>(probe);
     if (!p || !ghz) return bad_shape("null pointer");
-    HIPCHK(hipSetDevice(p->device));
-    HIPCHK(hipStreamSynchronize(p->st));
     std::vector<unsigned long long> h((size_t)2 * 8 * p->n);
-    HIPCHK(hipMemcpy(h.data(), p->d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    hipError_t e = hipSetDevice(p->device);
+    if (e == hipSuccess) e = hipStreamSynchronize(p->st);
+    if (e == hipSuccess) e = hipMemcpy(h.data(), p->d, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) {
+        (void)hipFree(p->d); (void)hipStreamDestroy(p->st);
+        delete p;
+        g_last_error = std::string("clock probe: ") + hipGetErrorString(e);
+        return GMRF_ERR_HIP;
+    }
     for (int i = 0; i + 1 < p->n; ++i) {
         double v[8];
         for (int b = 0; b < 8; ++b) {

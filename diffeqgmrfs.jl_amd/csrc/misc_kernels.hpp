@@ -70,11 +70,17 @@ __global__ void pack_tag_write(double* __restrict__ buf, int64_t pbuf, double xs
     double* q = buf + (int64_t)threadIdx.x * pbuf;
     q[0] = xsplit; q[1] = PACK_TAG_MAGIC;
 }
-__global__ void pack_tag_read(const double* __restrict__ buf, int* __restrict__ seen) {
-    const double v = buf[0];
-    int code = (buf[1] == PACK_TAG_MAGIC && v >= 0.0 && v < 1.0e6 && v == (double)(int)v) ? (int)v + 1 : -1;
-    const int old = *seen;
-    if (old != 0 && old != code) code = -1;
+// (one thread walks the tags of all `nprob` segments: in the all-gather form the problems of one image come from different ranks,
+//  and a rank whose inverses are in the other representation, or a corrupt segment, must not pass because problem 0 is fine:
+//  ADVICE r4)
+__global__ void pack_tag_read(const double* __restrict__ buf, int64_t pbuf, int nprob, int* __restrict__ seen) {
+    int code = *seen;
+    for (int p = 0; p < nprob; ++p) {
+        const double* q = buf + (int64_t)p * pbuf;
+        const double v = q[0];
+        const int c = (q[1] == PACK_TAG_MAGIC && v >= 0.0 && v < 1.0e6 && v == (double)(int)v) ? (int)v + 1 : -1;
+        code = (code == 0 || code == c) ? c : -1;
+    }
     *seen = code;
 }
 

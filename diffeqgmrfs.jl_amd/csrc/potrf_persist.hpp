@@ -256,6 +256,19 @@ __device__ __forceinline__ void diag_update_balanced(const double* Ls, const dou
         }
     }
 }
+// one 16 x 16 block (BI, BJ) of  N - L L^T  in the MFMA C/D layout, summed as above (bitwise the block diag_update_balanced gives)
+__device__ __forceinline__ v4d diag_update_block(int BI, int BJ, const double* Ls, const double* Ns, int li, int lq) {
+    v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kg = 0; kg < 8; ++kg) {
+        const int k = 8 * kg + 2 * lq;
+        const v2d av = *reinterpret_cast<const v2d*>(Ls + (16 * BI + li) * TLD + k);
+        const v2d bv = *reinterpret_cast<const v2d*>(Ls + (16 * BJ + li) * TLD + k);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bv.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bv.y, acc, 0, 0, 0);
+    }
+    return load_d16(Ns + (16 * BI) * TLD + 16 * BJ, TLD, li, lq) - acc;
+}
 __device__ __forceinline__ void diag_update_balanced_w(int w, const double* Ls, const double* Ns, double* Ts, int li, int lq) {
     switch (w) {
         case 0: diag_update_balanced<0>(Ls, Ns, Ts, li, lq); break;
@@ -284,7 +297,51 @@ struct ChainSide {
     int tag;
     unsigned long long* stamps;
     unsigned long long* dbg;                  // diagnostic: 1 + the 64-column quarter of the tile in which As was there (tools/persist_stamps.py), else nullptr
+    bool split_update;                        // the caller left only the first 16 columns of the updated tile in Ts (As = L[j+1, j], Bs = tile (j+1, j+1))
+    lds_word* used;                           // LDS: counts the waves 1 - 3 that are done with As and Bs (3 per tile: `used_target`)
+    int used_target;
     __device__ __forceinline__ void idle(int, int, int) {}
+    // Waves 1 - 3, beside wave 0's first panel: the 16 x 16 blocks of  tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T  of their own panels,
+    // straight into the accumulator layout they wait in -- wave 1: (1,1), (2,1) and, from wave 3 through Ts, (3,1); wave 2: (2,2),
+    // (3,2); wave 3: (3,1) for wave 1, then (3,3).  Only the first 16 columns of the update (one block per wave, before the
+    // routine) are on the chain: 1 300 cycles where the whole update was 4 300.
+    __device__ __forceinline__ void load_panel(int w, v4d (&s0)[4], double* Ts, tile_word* fl, int li, int lq, int& spins) {
+        if (!split_update) {
+#pragma unroll
+            for (int I = 0; I < 4; ++I) s0[I] = load_d16(Ts + (16 * I) * TLD + 16 * w, TLD, li, lq);
+            return;
+        }
+        const v4d z = (v4d){0.0, 0.0, 0.0, 0.0};
+        s0[0] = z; s0[1] = z; s0[2] = z; s0[3] = z;
+        if (w == 1) {
+            s0[1] = diag_update_block(1, 1, sL, sN, li, lq);
+            s0[2] = diag_update_block(2, 1, sL, sN, li, lq);
+        } else if (w == 2) {
+            s0[2] = diag_update_block(2, 2, sL, sN, li, lq);
+            s0[3] = diag_update_block(3, 2, sL, sN, li, lq);
+        } else {
+            const v4d b31 = diag_update_block(3, 1, sL, sN, li, lq);
+            store_d16(Ts + 48 * TLD + 16, TLD, b31, li, lq);
+            tile_set(fl + TF_SIDE + 0, li + 16 * lq);
+            s0[3] = diag_update_block(3, 3, sL, sN, li, lq);
+        }
+        asm volatile("" ::: "memory");
+        if (li + 16 * lq == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) int*)used, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (w == 1) {
+            tile_wait(fl + TF_SIDE + 0, spins);
+            s0[3] = load_d16(Ts + 48 * TLD + 16, TLD, li, lq);
+        }
+    }
+    // waves 4 - 7, before they overwrite As / Bs with the next step's operands: waves 1 - 3 have read L and the tile out of them
+    __device__ __forceinline__ bool operands_free(tile_word* fl) const {
+        if (!split_update) return true;
+        for (int n = 0; n < (1 << 16); ++n) {
+            if (*used >= used_target) return true;
+            if (fl[TF_I + 3] != 0) return false;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return false;
+    }
     __device__ __forceinline__ void half_load(const double* g, double* s, int half, int lane) const {
         const __amdgpu_buffer_rsrc_t rs = tile_rsrc(g);
         v4u v[16];
@@ -325,12 +382,12 @@ struct ChainSide {
                     __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(sL + r * TLD + c), rs, (int)((r * ld + c) * 8), 0, 16);
                 }
             }
-            if (!gA || !wait_flag(f1, fl, lane)) return;
+            if (!gA || !wait_flag(f1, fl, lane) || !operands_free(fl)) return;
             half_load(gA, sA, half, lane);             // (behind this wave's own reads of its half of As: the LDS serves them in order)
             if (lane == 0) done[half] = tag;
             if (dbg && half == 0 && lane == 0) *dbg = 1ull + (fl[TF_CS + 0] != 0) + (fl[TF_CS + 1] != 0) + (fl[TF_CS + 2] != 0);
         } else {
-            if (!gN || !wait_flag(f2, fl, lane)) return;
+            if (!gN || !wait_flag(f2, fl, lane) || !operands_free(fl)) return;
             half_load(gN, sN, half, lane);
             if (lane == 0) done[2 + half] = tag;
         }
@@ -372,6 +429,8 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
         if (tid < 4) done[tid] = 0;
         ChainSide cs;
         cs.ld = ld; cs.done = done; cs.stamps = nullptr; cs.dbg = nullptr; cs.sA = As; cs.sN = Bs; cs.sL = As;
+        cs.split_update = false; cs.used = okw + 9; cs.used_target = 0;
+        if (tid == 0) *cs.used = 0;
         auto prefetch_for = [&](int jn) {                    // operands of step jn (tile jn + 1) -> cs, or none past the last step
             cs.tag = jn + 1;
             if (jn + 1 < pa.j1) {
@@ -468,19 +527,24 @@ __device__ __forceinline__ void potrf_persist_body(PersistArgs pa) {
             // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: product from zero, ONE subtraction (as potrf_step)
             // (the ten lower blocks dealt evenly over the waves; L_jj has left Ts: its stores were drained by wg_publish; the tile
             //  (j+1, j+1) waits in Bs, prefetched or just loaded)
+            // tile (j+1, j+1) - L[j+1, j] L[j+1, j]^T: only its first 16 columns here, one block per wave -- the other six blocks are
+            // formed by waves 1 - 3 inside the tile routine, beside wave 0's first panel (ChainSide::load_panel)
             ts_epoch += 4;
             if (cw) {
                 while (*tsread < ts_epoch) {}               // (long true: waves 4 - 7 read L_jj out of Ts right after the tile)
                 asm volatile("" ::: "memory");
-                diag_update_balanced_w(wave, As, Bs, Ts, li, lq);
+                const v4d b0 = diag_update_block(wave, 0, As, Bs, li, lq);
+                store_d16(Ts + (16 * wave) * TLD, TLD, b0, li, lq);
             }
+            cs.split_update = true; cs.used_target += 3;
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 6] = __builtin_amdgcn_s_memtime();
             cs.gL = pa.L + o1 * ld + oj;
             prefetch_for(j + 1);
             cs.dbg = pa.stamps ? pa.stamps + 8 * (j - pa.j0) + 5 : nullptr;
+            tile_potrf_prepare(Wk, tid);
             __syncthreads();
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 7] = __builtin_amdgcn_s_memtime();
-            tile_potrf_inv(Ts, Xs, Wk, rinvs, tid, bad, cs);
+            tile_potrf_inv<true>(Ts, Xs, Wk, rinvs, tid, bad, cs);
             if (bad && tid == 0) atomicCAS(pa.info, 0, pa.blk);
             if (!cw) publish_tile(j + 1, fPL + (j + 1) * nt + j);      // X_{j+1,j+1} and (stored beside the tile) L[j+1, j]: drained, flagged
             if (pa.stamps && tid == 0) pa.stamps[8 * (j - pa.j0) + 8] = __builtin_amdgcn_s_memtime();

@@ -494,10 +494,18 @@ __device__ __forceinline__ void solve16_store(const double (&x)[4], double* blk,
 //                            is called for the ticks < 4 w except its last): a bounded piece of work, never a wait.
 //   extra(w, lane, fl)       waves 4 + w of a workgroup with more than four waves, between the routine's two barriers: anything that
 //                            ends by itself (fl: the routine's hand-over words, e.g. fl[TF_I + 3] != 0: the tile is done).
+//   load_panel(w, s0, ...)   waves 1 - 3, behind the routine's first barrier: the wave's 16-column panel of the tile, one 16 x 16 block
+//                            per row block I >= w in the MFMA C/D layout.  Default: it is in Ts.  (The chain workgroup of
+//                            potrf_persist has only the first panel of the updated tile in Ts when the routine starts, and forms
+//                            the others here, beside wave 0's first panel.)
 struct NoSide {
     unsigned long long* stamps = nullptr;     // diagnostic: s_memtime at phase boundaries (tests only)
     __device__ __forceinline__ void idle(int, int, int) {}
     __device__ __forceinline__ void extra(int, int, tile_word*) {}
+    __device__ __forceinline__ void load_panel(int w, v4d (&s0)[4], const double* Ts, tile_word*, int li, int lq, int&) {
+#pragma unroll
+        for (int I = 0; I < 4; ++I) s0[I] = load_d16(Ts + (16 * I) * TLD + 16 * w, TLD, li, lq);
+    }
 };
 
 #define TILE_STAMP(i) do { if (side.stamps) side.stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -505,15 +513,22 @@ struct NoSide {
 // Ts: SPD tile (lower triangle valid) -> L (strict upper zero).  Xs -> L^-1 (strict upper zero).
 // Wk: WK_ELEMS doubles of scratch.  All threads of the workgroup must call this (waves 0 - 3 factor; more waves run Side::extra);
 // Ts must be in LDS for everybody (a barrier behind its last store) and nobody may still read Xs, Wk or rinvs.
-template <class Side>
+// the words of a call of tile_potrf_inv: reciprocal pivots (0 = not there) and hand-over flags (the Side's too: its hooks run
+// behind the barrier that follows).  Inside the routine, or -- PREPARED -- by the caller before ITS last barrier ahead of the call.
+__device__ __forceinline__ void tile_potrf_prepare(double* Wk, int tid) {
+    tile_word* fl = (tile_word*)reinterpret_cast<int*>(Wk + TFLAG_OFF);
+    if (tid < 64) Wk[RV_OFF + tid] = 0.0;
+    else if (tid < 64 + TF_WORDS) fl[tid - 64] = 0;
+}
+// PREPARED: the caller has run tile_potrf_prepare and then a barrier behind which Ts is complete too (the chain workgroup of
+// potrf_persist: one barrier of eight waves per tile less).
+template <bool PREPARED = false, class Side>
 __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* Wk, double* rinvs, int tid, bool& bad, Side& side) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (wave-uniform: scalar branches, not exec masks, on `wave`)
     const int li = lane & 15, lq = lane >> 4;
     tile_word* fl = (tile_word*)reinterpret_cast<int*>(Wk + TFLAG_OFF);
     if (tid == 0) TILE_STAMP(0);
-    // the words of this call: reciprocal pivots (0 = not there) and hand-over flags
-    if (tid < 64) Wk[RV_OFF + tid] = 0.0;
-    else if (tid < 64 + TF_SIDE) fl[tid - 64] = 0;
+    if (!PREPARED) tile_potrf_prepare(Wk, tid);
     double a[16];
     v4d s0[4], acc[4];                                      // waves 1 - 3: the panel as it came, and what the earlier panels owe it
     if (wave == 0) {
@@ -522,14 +537,14 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
             const v2d v = *reinterpret_cast<const v2d*>(Ts + lane * TLD + c);
             a[c] = v.x; a[c + 1] = v.y;
         }
-    } else if (wave < 4) {
-#pragma unroll
-        for (int I = 0; I < 4; ++I) {
-            s0[I] = load_d16(Ts + (16 * I) * TLD + 16 * wave, TLD, li, lq);
-            acc[I] = (v4d){0.0, 0.0, 0.0, 0.0};
-        }
     }
-    __syncthreads();
+    if (!PREPARED) __syncthreads();
+    int spins = 0;
+    if (wave >= 1 && wave < 4) {
+        side.load_panel(wave, s0, Ts, fl, li, lq, spins);
+#pragma unroll
+        for (int I = 0; I < 4; ++I) acc[I] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
     // --- inverse of the tile by block forward substitution over the four 16-row blocks:
     //        X[I][J] = -X[I][I] * sum_{K=J..I-1} L[I][K] X[K][J],      I = 1, 2, 3,  J < I.
     // Only the 16x16 diagonal inverses (computed by substitution) multiply, so L X = I holds to
@@ -548,7 +563,6 @@ __device__ __forceinline__ void tile_potrf_inv(double* Ts, double* Xs, double* W
         const v4d x = mm16_nn(Xs + (16 * I) * TLD + 16 * I, TLD, Xs + (16 * I) * TLD + 16 * J, TLD, zero, true, li, lq);
         store_d16(Xs + (16 * I) * TLD + 16 * J, TLD, x, li, lq);
     };
-    int spins = 0;
     auto need = [&](int w) { tile_wait(fl + w, spins); };
     auto need_cols = [&](int c_end) {                    // the columns [0, c_end) of L are in Ts
         for (int p = 0; p < c_end / 16; ++p) tile_wait(fl + TF_CS + p, spins);

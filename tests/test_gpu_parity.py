@@ -1308,6 +1308,35 @@ def test_measured_path_darcy256_batch_against_oracle(pkg):
         assert r["var_exact_max_rel"] < max(1e-9, 0.01 * w.meta["cond"] * EPS), r
 
 
+def test_measured_path_elliptic512_batch8_against_oracle(pkg):
+    """BASELINE config C4 on the route its bench line is TIMED on: elliptic512 (n = 262 144, 256 blocks of
+    1024) as a batch of 8 problems -- the pattern's values scaled per problem, as bench.py's ProblemsJob builds a non-Darcy batch --
+    keep_l = 0, on a StreamSet stream, HipEngine / ShardedPosterior.step replayed from its graphs: every 256-column panel's
+    diagonal block is ONE persistent launch on 7 workgroups per problem (potrf_persist, kernel class 17; no potrf_diag128), the
+    rest 32 x 32- and 64 x 64-tile GEMMs.  One problem of the batch against the oracle at FULL block size: mean, 32 samples
+    (device draws fetched with gmrf_bt_normals), log-determinant, exact and RBMC variances of the last two blocks."""
+    from importlib import import_module
+    from tests import measured_path as MP
+    post = import_module(pkg.__name__ + ".posterior")
+    w = pkg.workloads.make("elliptic512")
+    B = 8
+    vals = np.stack([w.Q.data * (1.0 + 0.01 * p) for p in range(B)])
+    rhs = np.stack([w.rhs] * B)
+    tol = solve_tol(w)
+    res = MP.run(pkg, post, O, w.Q, w.n_blocks, vals, rhs, k_samples=32, check=(5,), last_blocks=2, rbmc_k=16)
+    print("measured path (elliptic512, batch 8):", res, "cond", w.meta["cond"])
+    route = res["route"]
+    assert route.get(17, 0) == (w.block_size // 256) * w.n_blocks, route          # one persistent launch per panel
+    for cls in (16, 1, 8, 9):
+        assert route.get(cls, 0) == 0, (cls, route)
+    assert route.get(14, 0) + route.get(15, 0) + route.get(13, 0) > 0, route
+    r = res[5]
+    assert r["mean_rel_l2"] < tol and r["samples_rel_l2"] < tol, (r, tol)
+    assert r["logdet_rel"] < 1e-10, r
+    assert r["var_exact_max_rel"] < max(1e-9, 0.01 * w.meta["cond"] * EPS), r
+    assert r["var_rbmc_max_rel"] < 4.0 * tol, r
+
+
 def test_exact_variance_error_not_worse_than_lapack(pkg):
     """Why the exact-variance gate at darcy256 is cond-aware (7.5e-9 instead of BASELINE.md's flat 1e-9): entries of
     diag(Q^-1) in extended precision (columns Q^-1 e_i refined with long-double residuals, 24 interior nodes of the
