@@ -1229,7 +1229,11 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
         // single rounding as D - acc, and only the rows the product does not write (>= rmax) need
         // zeroing -- a quarter of the block on darcy instead of all of it.  The first block has no product.
         const int rm_s = (i > 0) ? (int)h->rmax : 0;
-        if (rm_s < bsp) {
+        // (round 5: where the coupling product of this block runs on spmm_bxt_tiles, that launch zeroes the rows as well)
+        static const bool no_tiles_z = [] { const char* e = getenv("GMRF_BXT_TILES"); return e && atoi(e) == 0; }();
+        const bool zero_in_bxt = i > 0 && h->sparse_b && !h->dense_g1 && h->bxt_plan_ok && !no_tiles_z && h->bxt_nrt == (int)h->rmax / 64
+                                 && ((int64_t)(bsp - rm_s) * bsp) % 2 == 0;
+        if (rm_s < bsp && !zero_in_bxt) {
             const int64_t cnt = (int64_t)(bsp - rm_s) * bsp;
             hipLaunchKernelGGL(zero_rows, dim3((unsigned)((cnt / 2 + 255) / 256), nb), dim3(256), 0, h->stream,
                                h->d_S + (int64_t)rm_s * ld, cnt, bstride);
@@ -1292,7 +1296,13 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                         ta.nch = nch_env > 0 ? std::min(nch_env, chunks) : best;
                     }
                     const int ncg = (chunks + ta.nch - 1) / ta.nch;
-                    hipLaunchKernelGGL(spmm_bxt_tiles, dim3((unsigned)(ncg * ng * (int)nb)), dim3(256), bxt_tile_lds_bytes(h->bxt_ecap),
+                    ta.nprob = (int)nb;
+                    ta.zdst = nullptr; ta.zcount = 0; ta.zpdst = 0; ta.zwgs = 0;
+                    if (zero_in_bxt && rm_s < bsp) {
+                        ta.zdst = h->d_S + (int64_t)rm_s * ld; ta.zcount = (int64_t)(bsp - rm_s) * bsp; ta.zpdst = bstride;
+                        ta.zwgs = (int)std::min<int64_t>(32, std::max<int64_t>(1, ta.zcount / 16384));      // >= 128 KB per workgroup
+                    }
+                    hipLaunchKernelGGL(spmm_bxt_tiles, dim3((unsigned)((ncg * ng + ta.zwgs) * (int)nb)), dim3(256), bxt_tile_lds_bytes(h->bxt_ecap),
                                        h->stream, ta);
                 }
                 else if (h->lo_row_max <= 8) hipLaunchKernelGGL(spmm_bxt<8>, grid, dim3(256), 0, h->stream, ba);

@@ -275,6 +275,10 @@ struct BxtTileArgs {
     int nch;                  // 16-column chunks per workgroup
     int ecap;                 // padded entries per group (LDS capacity, multiple of 8)
     int skip_dead;            // leave a row's multiply loop at the first turn that only meets zero rows of the staged image
+    // round 5: the launch also zeroes the rows of the Schur block that the product S = -C C^T will not write (zero_rows was a
+    // launch of its own per block, 5 us + a boundary on one problem's chain): `zwgs` more workgroups per problem behind the others
+    int nprob;                // problems of the launch (the grid no longer says)
+    double* zdst; int64_t zcount, zpdst; int zwgs;      // zdst == nullptr / zwgs == 0: nothing to zero
 };
 
 constexpr int BXT_UCAP = 256;             // distinct columns per group (one per thread)
@@ -295,7 +299,17 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
     const int t = threadIdx.x;
     const int W = a.bsp - a.cm;
     const int ncg = (W / 16 + a.nch - 1) / a.nch;
-    const int nprob = (int)gridDim.x / (ncg * a.ng);
+    const int nprob = a.nprob;
+    if ((int)blockIdx.x >= ncg * a.ng * nprob) {
+        // zeroing role: workgroup z of problem p clears its share of zdst[p]
+        const int zi = (int)blockIdx.x - ncg * a.ng * nprob;
+        const int p = zi / a.zwgs, z = zi % a.zwgs;
+        const int64_t per = ((a.zcount / 2 + a.zwgs - 1) / a.zwgs) * 2;           // doubles per workgroup (even)
+        const int64_t lo = (int64_t)z * per, hi = min(a.zcount, lo + per);
+        double* d = a.zdst + (int64_t)p * a.zpdst;
+        for (int64_t i = lo + 2 * t; i < hi; i += 512) *reinterpret_cast<v2d*>(d + i) = (v2d){0.0, 0.0};
+        return;
+    }
     int cg, g, prob;
     {
         const int groups = (nprob % 8 == 0) ? 8 : 1;

@@ -41,12 +41,51 @@ __device__ __forceinline__ void sweep_select_problem(SweepArgs& s, int p) {
     s.Out += (int64_t)p * s.pOut;
 }
 
+
+typedef unsigned sw_v4u __attribute__((ext_vector_type(4)));
+typedef unsigned sw_v2u __attribute__((ext_vector_type(2)));
+
+// The right-hand panel as a sweep body reads and writes it.  COH = false (one launch per product): plain loads and stores.
+// COH = true (sweep_persist.hpp: the products of a whole sweep inside ONE launch, workgroups on different XCDs handing the
+// panel on to each other): every load is an `sc1` buffer load (L1 bypassed, the per-XCD L2s are not coherent), every store an
+// `sc1` write-through store -- the hand-off form of potrf_persist.hpp.  Offsets are 32-bit byte offsets from the base.
+template <bool COH>
+struct SweepVec {
+    const double* p;
+    __amdgpu_buffer_rsrc_t rs;
+    __device__ __forceinline__ explicit SweepVec(const double* q) : p(q) {
+        if (COH) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(q), 0, 0x7fffffff, 0x00020000);
+    }
+    __device__ __forceinline__ double ld(int64_t i) const {
+        if (COH) {
+            const sw_v2u u = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(i * 8), 0, 16);
+            return __hiloint2double((int)u.y, (int)u.x);
+        }
+        return p[i];
+    }
+    __device__ __forceinline__ v2d ld2(int64_t i) const {
+        if (COH) {
+            const sw_v4u u = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(i * 8), 0, 16);
+            return (v2d){__hiloint2double((int)u.y, (int)u.x), __hiloint2double((int)u.w, (int)u.z)};
+        }
+        return *reinterpret_cast<const v2d*>(p + i);
+    }
+    __device__ __forceinline__ void st(int64_t i, double v) const {
+        if (COH) {
+            sw_v2u u;
+            u.x = (unsigned)__double2loint(v); u.y = (unsigned)__double2hiint(v);
+            __builtin_amdgcn_raw_buffer_store_b64(u, rs, (int)(i * 8), 0, 16);
+        } else {
+            const_cast<double*>(p)[i] = v;
+        }
+    }
+};
+
 // TRANS = false: out[m] = sum_k Mat[m][k] x[k]   (TRI: Mat lower triangular, k <= m)
 // TRANS = true : out[m] = sum_k Mat[k][m] x[k]   (TRI: Mat lower triangular, k >= m)
-template <bool TRANS, bool TRI>
-__global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
-    sweep_select_problem(s, blockIdx.z);
-    const int m0 = blockIdx.x * 16, r0 = blockIdx.y * 16;
+template <bool TRANS, bool TRI, bool COH>
+__device__ __forceinline__ void sweep_mm_body(const SweepArgs& s, int bx, int by) {
+    const int m0 = bx * 16, r0 = by * 16;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int li = lane & 15, lq = lane >> 4;
     int kb = 0, ke = s.kdim;
@@ -63,7 +102,8 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
     const int k_hi = min(ke, k_lo + chunk);
 
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* __restrict__ xrow = s.Xin + (int64_t)(r0 + li) * s.ldx;
+    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
+    const int64_t xrow = (int64_t)(r0 + li) * s.ldx;
     // Operands come straight from global memory (each wave has its own K range, nothing to share
     // through LDS).  Loads are issued a whole chunk of 8 k-groups ahead of the MFMAs that consume
     // them, otherwise every pair of MFMAs waits a full memory latency.
@@ -75,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
             v2d a[CH], b[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                a[u] = *reinterpret_cast<const v2d*>(xrow + k + 8 * u + 2 * lq);
+                a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
                 b[u] = *reinterpret_cast<const v2d*>(mrow + k + 8 * u + 2 * lq);
             }
 #pragma unroll
@@ -85,7 +125,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
             }
         }
         for (; k < k_hi; k += 8) {
-            const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
+            const v2d a = X.ld2(xrow + k + 2 * lq);
             const v2d b = *reinterpret_cast<const v2d*>(mrow + k + 2 * lq);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc, 0, 0, 0);
@@ -98,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
             double b0[CH], b1[CH];
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                a[u] = *reinterpret_cast<const v2d*>(xrow + k + 8 * u + 2 * lq);
+                a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
                 b0[u] = mcol[(int64_t)(k + 8 * u + 2 * lq) * s.ld];
                 b1[u] = mcol[(int64_t)(k + 8 * u + 2 * lq + 1) * s.ld];
             }
@@ -109,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
             }
         }
         for (; k < k_hi; k += 8) {
-            const v2d a = *reinterpret_cast<const v2d*>(xrow + k + 2 * lq);
+            const v2d a = X.ld2(xrow + k + 2 * lq);
             const double b0 = mcol[(int64_t)(k + 2 * lq) * s.ld];
             const double b1 = mcol[(int64_t)(k + 2 * lq + 1) * s.ld];
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
@@ -125,21 +165,25 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
     const int rhs = ((t & 63) >> 4) + 4 * (t >> 6);
     const int m = t & 15;
     double v = sum;
-    if (s.sub) v = s.Bin[(int64_t)(r0 + rhs) * s.ldb + m0 + m] - sum;
-    s.Out[(int64_t)(r0 + rhs) * s.ldo + m0 + m] = v;
+    if (s.sub) v = Bv.ld((int64_t)(r0 + rhs) * s.ldb + m0 + m) - sum;
+    Ov.st((int64_t)(r0 + rhs) * s.ldo + m0 + m, v);
+}
+template <bool TRANS, bool TRI>
+__global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
+    sweep_mm_body<TRANS, TRI, false>(s, blockIdx.x, blockIdx.y);
 }
 
 // One right-hand side, non-transposed: one wave per row, 16-byte loads along the row.
-template <bool TRI>
-__global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
-    sweep_select_problem(s, blockIdx.z);
+template <bool TRI, bool COH>
+__device__ __forceinline__ void sweep_gemv_n_body(const SweepArgs& s, int bx) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = bx * 4 + (threadIdx.x >> 6);
     if (row >= s.rows) return;
     const int ke = TRI ? (row + 1) : s.kdim;
     const int kb = (!TRI && s.kst) ? s.kst[row >> 6] : 0;      // staircase: the row is zero left of kb
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
-    const double* __restrict__ x = s.Xin;
+    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
     double sum0 = 0.0, sum1 = 0.0;
     const int ke2 = ke & ~1;
     // all loads of a chunk of 8 strides are issued before the first fma consumes one
@@ -149,7 +193,7 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
-            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
+            xv[u] = X.ld2(k + 128 * u);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -163,7 +207,7 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
-            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
+            xv[u] = X.ld2(k + 128 * u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -173,19 +217,24 @@ __global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
     }
     for (; k < ke2; k += 128) {
         const v2d mv = *reinterpret_cast<const v2d*>(mrow + k);
-        const v2d xv = *reinterpret_cast<const v2d*>(x + k);
+        const v2d xv = X.ld2(k);
         sum0 = fma(mv.x, xv.x, sum0);
         sum1 = fma(mv.y, xv.y, sum1);
     }
-    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], x[ke - 1], sum0);
+    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], X.ld(ke - 1), sum0);
     double sum = sum0 + sum1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if (lane == 0) {
         double v = sum;
-        if (s.sub) v = s.Bin[row] - sum;
-        s.Out[row] = v;
+        if (s.sub) v = Bv.ld(row) - sum;
+        Ov.st(row, v);
     }
+}
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
+    sweep_gemv_n_body<TRI, false>(s, blockIdx.x);
 }
 
 // One right-hand side, non-transposed, SHORT rows (kdim <= 256: the first block column of a split block inverse, see
@@ -302,19 +351,18 @@ __global__ __launch_bounds__(256) void sweep_gemv_n4(SweepArgs s) {
 // the first workgroup reads 64 times what the last one does, and once the short ones have left, the
 // long ones run on a nearly empty chip (3.0 TB/s on darcy256 / batch 32 against 4.6 for the other
 // sweep kernels).  Non-TRI (C^T inside its staircase): rows [0, mend[column tile]).
-template <bool TRI, int CW>
-__global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
-    sweep_select_problem(s, blockIdx.z);
+template <bool TRI, int CW, bool COH>
+__device__ __forceinline__ void sweep_gemv_t_body(const SweepArgs& s, int bx) {
     constexpr int TPR = CW / 2, RG = 256 / TPR;
     const int t = threadIdx.x;
     const int c2 = (t % TPR) * 2, gidx = t / TPR;
-    const double* __restrict__ x = s.Xin;
+    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
     __shared__ double red[RG][CW + 1];
     const int ncb = s.rows / CW;
     const int npass = TRI ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
-        const int cb = TRI ? (pass == 0 ? (int)blockIdx.x : ncb - 1 - (int)blockIdx.x) : (int)blockIdx.x;
-        if (TRI && pass == 1 && cb == (int)blockIdx.x) break;          // odd block count: the middle block once
+        const int cb = TRI ? (pass == 0 ? bx : ncb - 1 - bx) : bx;
+        if (TRI && pass == 1 && cb == bx) break;          // odd block count: the middle block once
         const int col0 = cb * CW;
         const int kb = TRI ? col0 : 0;          // lower triangular: rows >= column (zeros above the diagonal are stored)
         const int ke = (!TRI && s.mend) ? s.mend[col0 >> 6] : s.kdim;
@@ -327,14 +375,14 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 mv[u] = *reinterpret_cast<const v2d*>(mp + (int64_t)(k + u * RG) * s.ld);
-                xv[u] = x[k + u * RG];
+                xv[u] = X.ld(k + u * RG);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s0 = fma(mv[u].x, xv[u], s0); s1 = fma(mv[u].y, xv[u], s1); }
         }
         for (; k < ke; k += RG) {
             const v2d mv = *reinterpret_cast<const v2d*>(mp + (int64_t)k * s.ld);
-            const double xv = x[k];
+            const double xv = X.ld(k);
             s0 = fma(mv.x, xv, s0); s1 = fma(mv.y, xv, s1);
         }
         if (pass == 1) __syncthreads();                                  // the first block's reduction has read `red`
@@ -345,10 +393,15 @@ __global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
 #pragma unroll
             for (int i = 0; i < RG; ++i) tot += red[i][t];
             double v = tot;
-            if (s.sub) v = s.Bin[col0 + t] - tot;
-            s.Out[col0 + t] = v;
+            if (s.sub) v = Bv.ld(col0 + t) - tot;
+            Ov.st(col0 + t, v);
         }
     }
+}
+template <bool TRI, int CW>
+__global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
+    sweep_gemv_t_body<TRI, CW, false>(s, blockIdx.x);
 }
 
 inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s, int nprob) {
