@@ -58,6 +58,8 @@ KERNEL_CLASSES = {      # one class per kernel symbol (include/gmrf_hip.h, gmrf_
     9: ("potrf_update", "mfma"),
     2: ("sweep_mm", "mfma"),
     3: ("sweep_gemv", "hbm"),
+    19: ("sweep_persist<k=1>", "hbm"),      # one problem: a whole k = 1 sweep as ONE persistent launch (round 5)
+    20: ("sweep_persist<k>=16>", "mfma"),   # ... a whole sweep of 16 .. 128 right-hand sides
     10: ("spmm_bxt", "hbm"),
     4: ("csr_spmm", "hbm"),
 }
@@ -1000,7 +1002,8 @@ def main():
             out["single_problem"] = {"latency_ms": 1e3 * lat1, "solves_per_s": (1 + args.samples) / lat1, "factor_ms": f1,
                                      "factor_tflops_lapack_count": s1p["factor_flops"] / (f1 * 1e-3) / 1e12,
                                      "persist_route": int(s1p["persist_route"]), "persist_aborts": int(s1p["persist_aborts"]),
-                                     "persist_cus": int(s1p["persist_cus"]), "persist_refused": int(s1p["persist_refused"])}
+                                     "persist_cus": int(s1p["persist_cus"]), "persist_refused": int(s1p["persist_refused"]),
+                                     "sweep_persist": int(s1p["sweep_persist"]), "solve_ms": s1p["solve_ms"], "sample_ms": s1p["sample_ms"]}
             # (top level too, so that the driver's record keeps them: VERDICT r4 item 1)
             out["single_problem_latency_ms"] = 1e3 * lat1
             out["single_problem_factor_ms"] = f1

@@ -57,6 +57,7 @@ class Stats(C.Structure):
         ("kernel_ms", C.c_double * 24), ("kernel_work", C.c_double * 24), ("kernel_launches", C.c_int64 * 24),
         ("sweep_bytes_streamed", C.c_double),
         ("persist_route", C.c_int32), ("persist_aborts", C.c_int32), ("persist_cus", C.c_int32), ("persist_refused", C.c_int32),
+        ("sweep_persist", C.c_int32), ("sweep_persist_launches", C.c_int32),
     ]
 
 

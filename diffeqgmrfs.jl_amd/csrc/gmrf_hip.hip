@@ -33,6 +33,7 @@
 #include "potrf_step.hpp"
 #include "potrf_persist.hpp"
 #include "sweep.hpp"
+#include "sweep_persist.hpp"
 #include "swe_assemble.hpp"
 #include "fem_assemble_p2.hpp"
 
@@ -210,6 +211,18 @@ struct gmrf_handle {
     int cu_count = 0;
     unsigned* d_pflags = nullptr;      // flag words of the persistent launches (zero between launches: potrf_persist cleans up after itself)
     int64_t pflags_words = 0;
+    // One problem: a whole sweep as ONE persistent launch (sweep_persist.hpp) instead of two dependent launches per block.  Every
+    // workgroup must be resident: the handle then claims the whole chip (persist_plan).  A wait that gives up sets the mapped host
+    // word; gmrf_bt_solve / gmrf_bt_sample see it at their synchronisation and repeat the call with the launch-per-product form.
+    bool no_sweep_persist = false;     // set_eager bit 16 / GMRF_SWEEP_PERSIST=0
+    bool sweep_persist_planned = false;   // the claim covers the whole chip (persist_plan)
+    bool sweep_persist_launched = false;  // such a launch was enqueued since the abort word was last looked at
+    unsigned* d_sweep_flags = nullptr;    // [0] the device's abort word
+    double* d_Tsw = nullptr;              // intermediate panel of the persistent sweeps (right-hand side minus coupling product)
+    int64_t t_elems = 0;
+    unsigned* h_sweep_abort = nullptr;    // mapped host word
+    int sweep_nw = 0;
+    bool sweep_persist_hold = false;      // this call must not use it (its input would be lost if the launch gave up: in-place solve)
     bool no_persist_panels = false;    // batches small enough for it keep potrf_diag128 + the 128^3 products instead of one persistent launch per panel (set_eager bit 15)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
@@ -894,14 +907,27 @@ static int persist_demand(const gmrf_handle* h) {
     wgs *= h->B;
     return wgs > 0 && wgs <= h->cu_count ? (int)wgs : 0;
 }
+// One problem with blocks of 512 and more: its sweeps run as one persistent launch each (sweep_persist.hpp), whose workgroups --
+// one per CU, up to 256 -- must all be resident: the handle then asks for the whole chip.  0: the sweeps keep a launch per product.
+static int sweep_persist_demand(const gmrf_handle* h) {
+    if (h->no_persist || h->no_sweep_persist || h->persist_gave_up || h->cu_count < 64 || h->B != 1) return 0;
+    if (h->bsp < 512 || h->bsp > SWEEP_PERSIST_XMAX || h->bsp % 64 != 0 || h->cmin % 16 != 0 || h->rmax % 16 != 0) return 0;      // (the bodies' tilings: 16 rows, 8 / 16 columns)
+    return h->cu_count;
+}
 // plan the persistent launches of the next factorisation: claim (or release) this handle's CUs
 static void persist_plan(gmrf_handle* h) {
-    const int want = persist_demand(h);
+    const int want_f = persist_demand(h), want_s = sweep_persist_demand(h);
+    int want = std::max(want_f, want_s);
     bool ok;
     {
         std::lock_guard<std::mutex> lock(g_persist_mu);
-        ok = persist_budget_claim(g_persist_claims[h->device], h, want, h->cu_count, persist_margin());
+        ok = persist_budget_claim(g_persist_claims[h->device], h, want, h->cu_count, want == h->cu_count ? 0 : persist_margin());
+        if (!ok && want_f > 0 && want_f < want) {          // (the whole chip is not free: the factorisation's launches alone)
+            want = want_f;
+            ok = persist_budget_claim(g_persist_claims[h->device], h, want, h->cu_count, persist_margin());
+        }
     }
+    h->sweep_persist_planned = ok && want_s > 0 && want >= want_s;
     const int got = ok ? want : 0;
     if (got != h->persist_cus) destroy_graphs(h);              // (a captured factor graph holds the launches of the old plan)
     h->persist_cus = got;
@@ -914,6 +940,7 @@ static void persist_release(gmrf_handle* h) {
     if (it != g_persist_claims.end()) it->second.erase(h);
     h->persist_cus = 0;
     h->stats.persist_cus = 0;
+    h->sweep_persist_planned = false;
 }
 
 // One persistent launch (potrf_persist.hpp) over the column tiles [j0, j1) of a block of nt tiles (its flag words are zero
@@ -1532,7 +1559,96 @@ static double sweep_bytes(const gmrf_handle* h, int64_t k) {
     return 8.0 * (N * bs * (bs + 1) / 2.0 + (N - 1) * bs * bs) + 16.0 * (double)h->n * (double)k;
 }
 
+// One problem: may this sweep run as one persistent launch?  (the claim is planned with the factorisation: persist_plan)
+static bool sweep_persist_ok(const gmrf_handle* h, int kp) {
+    if (!h->sweep_persist_planned || h->sweep_persist_hold || h->no_sweep_persist || h->no_persist || h->persist_gave_up || h->B != 1 || h->xsplit != 0) return false;
+    if (h->persist_cus < h->cu_count || sweep_persist_demand(h) <= 0) return false;
+    if (kp != 1 && (kp % 16 != 0 || (int64_t)kp * h->n_pad * 8 >= ((int64_t)1 << 31))) return false;
+    if (h->n_pad * 8 >= ((int64_t)1 << 31)) return false;
+    const bool via_gemm = (kp % 64 == 0) && !h->sweep_no_gemm && (int64_t)(h->bsp / 64) * (kp / 64) >= 128;
+    return !via_gemm;
+}
+
+// the words and the intermediate panel of the persistent sweeps (before any capture: allocations are not allowed inside one)
+static gmrf_status sweep_persist_prepare(gmrf_handle* h, int kp) {
+    if (!h->d_sweep_flags) {
+        HIPCHK(hipMalloc(&h->d_sweep_flags, sizeof(unsigned) * 16));
+        HIPCHK(hipMemsetAsync(h->d_sweep_flags, 0, sizeof(unsigned) * 16, h->stream));
+    }
+    h->sweep_nw = std::min(256, h->cu_count);
+    if (!h->h_sweep_abort) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h->h_sweep_abort), 64, hipHostMallocMapped));
+        *h->h_sweep_abort = 0u;
+    }
+    const int64_t need = (int64_t)kp * h->n_pad;
+    if (!h->d_Tsw || h->t_elems < need) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        free_dev(h->d_Tsw); h->d_Tsw = nullptr; h->t_elems = 0;
+        destroy_graphs(h);                                  // (captured sweeps hold the old pointer)
+        HIPCHK(hipMalloc(&h->d_Tsw, sizeof(double) * (size_t)need));
+        h->t_elems = need;
+    }
+    return GMRF_OK;
+}
+
+static gmrf_status launch_sweep_persist(gmrf_handle* h, bool backward, int kp, double* Pin, double* Yout) {
+    const int nw = h->sweep_nw;
+    const int64_t elems = (int64_t)kp * h->n_pad;
+    if (!h->d_sweep_flags || !h->h_sweep_abort || nw <= 0 || !h->d_Tsw || h->t_elems < elems)
+        return bad_shape("internal: words / panel of the persistent sweeps not allocated");
+    SweepPersistArgs a;
+    a.C = h->d_C; a.Linv = h->d_Linv; a.Pin = Pin; a.T = h->d_Tsw; a.Yout = Yout;
+    a.N = (int)h->N; a.bsp = (int)h->bsp; a.cm = (int)h->cmin; a.rm = (int)h->rmax; a.kp = kp; a.backward = backward ? 1 : 0; a.nw = nw;
+    a.npad = h->n_pad; a.ldc = c_ld(h); a.cstride = c_blk(h); a.bstride = (int64_t)h->bsp * h->bsp;
+    a.kst = h->d_kst; a.mend = h->d_mend;
+    a.abort_w = h->d_sweep_flags;
+    void* dev_abort = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&dev_abort, h->h_sweep_abort, 0));
+    a.host_abort = reinterpret_cast<unsigned*>(dev_abort);
+    static const int limit_ms = [] {
+        const char* e = getenv("GMRF_SWEEP_SPIN_MS");              // (tests: the sweeps' own bound, so that the factorisation's launches pass)
+        if (!e) e = getenv("GMRF_PERSIST_SPIN_MS");
+        return e ? atoi(e) : -1;
+    }();
+    a.spin_limit = (unsigned)(limit_ms >= 0 ? limit_ms : 2000) * 100000u;
+    static const int dbg = [] { const char* e = getenv("GMRF_SWEEP_DBG"); return e ? atoi(e) : 0; }();      // tuning aid
+    a.dbg = dbg;
+    const double N = (double)h->N, bsp = (double)h->bsp;
+    const double work = (kp == 1) ? 8.0 * ((N - 1) * h->c_streamed + N * 0.5 * bsp * (bsp + 1))
+                                  : kp * (2.0 * (N - 1) * h->c_streamed + N * bsp * (bsp + 1));
+    {
+        // the panels the products read from each other: sentinel everywhere (elems is even: n_pad is a multiple of 64)
+        ProfScope ps(h, 5, 16.0 * (double)elems);
+        hipLaunchKernelGGL(sweep_fill_sentinel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, h->stream, h->d_Tsw, Yout, elems);
+        HIPCHK(hipGetLastError());
+    }
+    ProfScope ps(h, kp == 1 ? 19 : 20, work);
+    if (kp == 1) hipLaunchKernelGGL(sweep_persist<true>, dim3((unsigned)nw), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL(sweep_persist<false>, dim3((unsigned)nw), dim3(256), 0, h->stream, a);
+    HIPCHK(hipGetLastError());
+    return GMRF_OK;
+}
+
+// behind a synchronisation of the stream: did a persistent sweep give up?  Then its panels hold garbage: the words are zeroed,
+// the handle keeps the launch-per-product form for good (stats.persist_aborts), and the caller repeats its call.
+static gmrf_status sweep_persist_check(gmrf_handle* h, bool* repeat) {
+    *repeat = false;
+    if (!h->sweep_persist_launched) return GMRF_OK;
+    h->sweep_persist_launched = false;
+    if (!h->h_sweep_abort || *reinterpret_cast<volatile unsigned*>(h->h_sweep_abort) == 0u) return GMRF_OK;
+    *h->h_sweep_abort = 0u;
+    h->persist_gave_up = true; h->persist_aborts++;
+    h->stats.persist_aborts = h->persist_aborts;
+    persist_release(h);
+    destroy_graphs(h);
+    HIPCHK(hipMemsetAsync(h->d_sweep_flags, 0, sizeof(unsigned) * 16, h->stream));
+    h->stats.sweep_persist = 0;
+    *repeat = true;
+    return GMRF_OK;
+}
+
 static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double* Pin, double* Yout) {
+    if (sweep_persist_ok(h, kp)) return launch_sweep_persist(h, backward, kp, Pin, Yout);
     const int bsp = (int)h->bsp;
     const int64_t ld = bsp, bstride = (int64_t)bsp * bsp, npad = h->n_pad;
     const int64_t N = h->N;
@@ -1636,8 +1752,16 @@ static gmrf_status run_sweeps(gmrf_handle* h, int mode, int kp) {
         GCHK(sweep_launches(h, false, kp, h->d_P, h->d_Y));
         return sweep_launches(h, true, kp, h->d_Y, h->d_P);
     };
+    const bool persistent = sweep_persist_ok(h, kp);
+    if (persistent) {
+        GCHK(sweep_persist_prepare(h, kp));
+        h->sweep_persist_launched = true;                  // (here, not at the launch: a graph replay launches it too)
+        h->stats.sweep_persist = 1;
+        h->stats.sweep_persist_launches += (mode == GMRF_SOLVE_FULL) ? 2 : 1;
+    }
     if (h->eager || h->profiling) return body();
-    const int64_t key = ((int64_t)h->xsplit << 32) | ((int64_t)mode * 4096 + kp);       // (the representation decides the launches)
+    const int64_t key = ((int64_t)h->xsplit << 32) | ((int64_t)mode * 4096 + kp) |       // (the representation decides the launches)
+                        (persistent ? ((int64_t)1 << 60) : 0);
     auto it = h->sweep_graphs.find(key);
     if (it == h->sweep_graphs.end()) {
         std::lock_guard<std::mutex> capture_lock(g_capture_mu);
@@ -1707,6 +1831,7 @@ gmrf_status gmrf_bt_create(int32_t device, void* stream, gmrf_handle** out) {
     HIPCHK(hipFuncSetAttribute((const void*)potrf_persist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)POTRF_PERSIST_LDS));
     HIPCHK(hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, device));
     { const char* e = getenv("GMRF_PERSIST"); if (e && atoi(e) == 0) h->no_persist = true; }      // tuning aid
+    { const char* e = getenv("GMRF_SWEEP_PERSIST"); if (e && atoi(e) == 0) h->no_sweep_persist = true; }      // tuning aid
     HIPCHK(hipFuncSetAttribute((const void*)potrf_diag128_slim, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     HIPCHK(gemm_init());
     HIPCHK(gemm_dma_init());
@@ -1726,6 +1851,8 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
+    free_dev(h->d_sweep_flags); free_dev(h->d_Tsw);
+    if (h->h_sweep_abort) { (void)hipHostFree(h->h_sweep_abort); h->h_sweep_abort = nullptr; }
     free_dev(h->d_info); free_dev(h->d_logdet); free_dev(h->d_pflags); free_dev(h->d_kbx); free_dev(h->d_V);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
     free_dev(h->d_stage); free_dev(h->d_mean); free_dev(h->d_acc);
@@ -1780,6 +1907,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 4096) != 0) != h->no_xsplit) { destroy_graphs(h); h->no_xsplit = (eager & 4096) != 0; }
     if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
     if (((eager & 32768) != 0) != h->no_persist_panels) { destroy_graphs(h); h->no_persist_panels = (eager & 32768) != 0; }
+    if (((eager & 65536) != 0) != h->no_sweep_persist) { destroy_graphs(h); h->no_sweep_persist = (eager & 65536) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }
@@ -2512,6 +2640,8 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
     const bool b_dev = is_device_ptr(b), y_dev = is_device_ptr(y);
     h->stats.solve_ms = 0.0;
     const int64_t nb = h->B;            // b / y hold nb consecutive groups of k columns (problem-major)
+    h->sweep_persist_hold = (b == y);   // (in place: a persistent sweep that gave up could not be repeated)
+    h->stats.sweep_persist = 0;
     for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
         const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
         const int kp = pad_k(kc);
@@ -2539,6 +2669,9 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
                                     h->n * sizeof(double), kc * nb, hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
         }
+        bool repeat = false;
+        GCHK(sweep_persist_check(h, &repeat));
+        if (repeat) { c0 -= KP_CHUNK; continue; }           // (this chunk again, with a launch per product: b is untouched)
         float ms = 0.f;
         (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
         h->stats.solve_ms += ms;
@@ -2595,6 +2728,8 @@ gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int6
     const double* d_mean = nullptr;
     GCHK(stage_vector(h, mean, &h->d_mean, &d_mean));
     const bool out_dev = is_device_ptr(out);
+    h->sweep_persist_hold = (z == out);
+    h->stats.sweep_persist = 0;
     HIPCHK(hipEventRecord(h->ev0, h->stream));
     for (int64_t c0 = 0; c0 < k; c0 += KP_CHUNK) {
         const int kc = (int)std::min<int64_t>(KP_CHUNK, k - c0);
@@ -2611,6 +2746,9 @@ gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int6
     }
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    bool repeat = false;
+    GCHK(sweep_persist_check(h, &repeat));
+    if (repeat) return gmrf_bt_sample(h, seed, first_id, k, mean, z, out, ld);     // (once: the handle has left the persistent form)
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
     h->stats.sample_ms = ms;

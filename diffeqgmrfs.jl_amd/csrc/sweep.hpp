@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "gemm_f64.hpp"
 
@@ -32,6 +33,11 @@ struct SweepArgs {
     // TRANS = false: row tile t sums over k >= kst[t];  TRANS = true: output tile u sums over k < mend[u].
     const int* kst = nullptr;
     const int* mend = nullptr;
+    // sweep_persist.hpp only (the bodies' COH form): words a bounded wait for the input panel gives up on
+    unsigned* abort_w = nullptr;
+    unsigned* host_abort = nullptr;
+    unsigned spin_limit = 0;
+    int dbg = 0;                        // tuning aid (GMRF_SWEEP_DBG): 1 = the k = 1 flow bodies skip their matrix loads (garbage results: the pure hand-off time)
 };
 
 __device__ __forceinline__ void sweep_select_problem(SweepArgs& s, int p) {
@@ -47,13 +53,21 @@ typedef unsigned sw_v2u __attribute__((ext_vector_type(2)));
 
 // The right-hand panel as a sweep body reads and writes it.  COH = false (one launch per product): plain loads and stores.
 // COH = true (sweep_persist.hpp: the products of a whole sweep inside ONE launch, workgroups on different XCDs handing the
-// panel on to each other): every load is an `sc1` buffer load (L1 bypassed, the per-XCD L2s are not coherent), every store an
-// `sc1` write-through store -- the hand-off form of potrf_persist.hpp.  Offsets are 32-bit byte offsets from the base.
+// panel on to each other as a DATA FLOW, no flags): every store is an 8-byte `sc1` write-through store, every load an `sc1`
+// buffer load (L1 bypassed; the per-XCD L2s are not coherent), and the INPUT vectors are read by the `ldw` forms, which
+// repeat a chunk's loads until none of its values is the sentinel the panel was filled with before the launch (an element is
+// written once per launch, by one store instruction: a value that is not the sentinel is final -- the guide's data-tagged
+// granule, MI355X_MICROARCH.md "allgather", with the fp64 value as its own tag).  Every repetition is bounded: after
+// `spin_limit` ticks of the 100 MHz clock (or when another wave has given up) the abort words are set and the body goes on
+// with what it has -- the launch always drains, the host repeats the solve.  Offsets are 32-bit byte offsets from the base.
+constexpr unsigned SWEEP_SENT_HI = 0x7ffbadc0u, SWEEP_SENT_LO = 0xdec0de5au;      // a quiet NaN no arithmetic produces
+
 template <bool COH>
 struct SweepVec {
     const double* p;
     __amdgpu_buffer_rsrc_t rs;
-    __device__ __forceinline__ explicit SweepVec(const double* q) : p(q) {
+    const SweepArgs* sa;
+    __device__ __forceinline__ SweepVec(const double* q, const SweepArgs& s) : p(q), sa(&s) {
         if (COH) rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(q), 0, 0x7fffffff, 0x00020000);
     }
     __device__ __forceinline__ double ld(int64_t i) const {
@@ -79,6 +93,55 @@ struct SweepVec {
             const_cast<double*>(p)[i] = v;
         }
     }
+    static __device__ __forceinline__ bool sent(double v) { return (unsigned)__double2hiint(v) == SWEEP_SENT_HI; }
+    // one more look has failed: false when the wait is over for good (abort).  The clock and the abort word are looked at every
+    // 64th time only (either is a trip of its own through the scalar cache / the fabric, and nearly every wait fails once or twice)
+    __device__ __forceinline__ bool again(unsigned& n, unsigned long long& t0) const {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++n & 63u) == 0u || sa->spin_limit == 0u) {           // (limit 0, tests: the first look that fails gives up)
+            if (__hip_atomic_load(sa->abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (n <= 64u) t0 = now;
+            if (now - t0 >= (unsigned long long)sa->spin_limit) {
+                __hip_atomic_store(sa->abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sa->host_abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                return false;
+            }
+        }
+        return true;
+    }
+    // NV 16-byte pieces of the input, `stride` elements apart: v[u] = in[i0 + u stride .. +1]
+    template <int NV>
+    __device__ __forceinline__ void ldw2(v2d (&v)[NV], int64_t i0, int64_t stride) const {
+        unsigned n = 0; unsigned long long t0 = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) v[u] = ld2(i0 + u * stride);
+            if (!COH) return;
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) bad = bad || sent(v[u].x) || sent(v[u].y);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+            if (!again(n, t0)) return;
+        }
+    }
+    // NV single elements of the input, `stride` apart
+    template <int NV>
+    __device__ __forceinline__ void ldw1(double (&v)[NV], int64_t i0, int64_t stride) const {
+        unsigned n = 0; unsigned long long t0 = 0;
+#pragma clang loop unroll(disable)
+        for (;;) {
+#pragma unroll
+            for (int u = 0; u < NV; ++u) v[u] = ld(i0 + u * stride);
+            if (!COH) return;
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < NV; ++u) bad = bad || sent(v[u]);
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) return;
+            if (!again(n, t0)) return;
+        }
+    }
 };
 
 // TRANS = false: out[m] = sum_k Mat[m][k] x[k]   (TRI: Mat lower triangular, k <= m)
@@ -102,59 +165,75 @@ __device__ __forceinline__ void sweep_mm_body(const SweepArgs& s, int bx, int by
     const int k_hi = min(ke, k_lo + chunk);
 
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
+    const SweepVec<COH> X(s.Xin, s), Bv(s.Bin, s), Ov(s.Out, s);
     const int64_t xrow = (int64_t)(r0 + li) * s.ldx;
     // Operands come straight from global memory (each wave has its own K range, nothing to share
-    // through LDS).  Loads are issued a whole chunk of 8 k-groups ahead of the MFMAs that consume
-    // them, otherwise every pair of MFMAs waits a full memory latency.
-    constexpr int CH = 8;
+    // through LDS).  Loads are issued a whole chunk of k-groups ahead of the MFMAs that consume
+    // them, otherwise every pair of MFMAs waits a full memory latency: chunks of 8 groups, then single groups -- and inside
+    // sweep_persist (COH), where a lone workgroup per CU has the registers for it and nothing else hides the latency, chunks
+    // of 16 first and of 4 and 2 behind the 8s.  The MFMAs run in ascending k whatever the chunking: same sums, bit for bit.
+    int k = k_lo;
     if (!TRANS) {
         const double* __restrict__ mrow = s.Mat + (int64_t)(m0 + li) * s.ld;
-        int k = k_lo;
-        for (; k + 8 * CH <= k_hi; k += 8 * CH) {
-            v2d a[CH], b[CH];
+        auto run = [&](auto chc) {
+            constexpr int CH = decltype(chc)::value;
+            for (; k + 8 * CH <= k_hi; k += 8 * CH) {
+                v2d a[CH], b[CH];
+                if (COH) {                              // (the block's piece first: it does not wait for anybody)
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
-                b[u] = *reinterpret_cast<const v2d*>(mrow + k + 8 * u + 2 * lq);
-            }
+                    for (int u = 0; u < CH; ++u) b[u] = *reinterpret_cast<const v2d*>(mrow + k + 8 * u + 2 * lq);
+                    X.ldw2(a, xrow + k + 2 * lq, 8);
+                } else {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, acc, 0, 0, 0);
+                    for (int u = 0; u < CH; ++u) {
+                        a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
+                        b[u] = *reinterpret_cast<const v2d*>(mrow + k + 8 * u + 2 * lq);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, acc, 0, 0, 0);
+                }
             }
-        }
-        for (; k < k_hi; k += 8) {
-            const v2d a = X.ld2(xrow + k + 2 * lq);
-            const v2d b = *reinterpret_cast<const v2d*>(mrow + k + 2 * lq);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc, 0, 0, 0);
-        }
+        };
+        if (COH) run(std::integral_constant<int, 16>{});
+        run(std::integral_constant<int, 8>{});
+        if (COH) { run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 2>{}); }
+        run(std::integral_constant<int, 1>{});
     } else {
         const double* __restrict__ mcol = s.Mat + m0 + li;
-        int k = k_lo;
-        for (; k + 8 * CH <= k_hi; k += 8 * CH) {
-            v2d a[CH];
-            double b0[CH], b1[CH];
+        auto run = [&](auto chc) {
+            constexpr int CH = decltype(chc)::value;
+            for (; k + 8 * CH <= k_hi; k += 8 * CH) {
+                v2d a[CH];
+                double b0[CH], b1[CH];
+                if (COH) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
-                b0[u] = mcol[(int64_t)(k + 8 * u + 2 * lq) * s.ld];
-                b1[u] = mcol[(int64_t)(k + 8 * u + 2 * lq + 1) * s.ld];
-            }
+                    for (int u = 0; u < CH; ++u) {
+                        b0[u] = mcol[(int64_t)(k + 8 * u + 2 * lq) * s.ld];
+                        b1[u] = mcol[(int64_t)(k + 8 * u + 2 * lq + 1) * s.ld];
+                    }
+                    X.ldw2(a, xrow + k + 2 * lq, 8);
+                } else {
 #pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b0[u], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b1[u], acc, 0, 0, 0);
+                    for (int u = 0; u < CH; ++u) {
+                        a[u] = X.ld2(xrow + k + 8 * u + 2 * lq);
+                        b0[u] = mcol[(int64_t)(k + 8 * u + 2 * lq) * s.ld];
+                        b1[u] = mcol[(int64_t)(k + 8 * u + 2 * lq + 1) * s.ld];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b0[u], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b1[u], acc, 0, 0, 0);
+                }
             }
-        }
-        for (; k < k_hi; k += 8) {
-            const v2d a = X.ld2(xrow + k + 2 * lq);
-            const double b0 = mcol[(int64_t)(k + 2 * lq) * s.ld];
-            const double b1 = mcol[(int64_t)(k + 2 * lq + 1) * s.ld];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b0, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b1, acc, 0, 0, 0);
-        }
+        };
+        if (COH) run(std::integral_constant<int, 16>{});
+        run(std::integral_constant<int, 8>{});
+        if (COH) { run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 2>{}); }
+        run(std::integral_constant<int, 1>{});
     }
     __shared__ double red[4][256];
 #pragma unroll
@@ -175,15 +254,16 @@ __global__ __launch_bounds__(256, 2) void sweep_mm(SweepArgs s) {
 }
 
 // One right-hand side, non-transposed: one wave per row, 16-byte loads along the row.
-template <bool TRI, bool COH>
-__device__ __forceinline__ void sweep_gemv_n_body(const SweepArgs& s, int bx) {
+template <bool TRI>
+__global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
     const int lane = threadIdx.x & 63;
-    const int row = bx * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= s.rows) return;
     const int ke = TRI ? (row + 1) : s.kdim;
     const int kb = (!TRI && s.kst) ? s.kst[row >> 6] : 0;      // staircase: the row is zero left of kb
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
-    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
+    const double* __restrict__ x = s.Xin;
     double sum0 = 0.0, sum1 = 0.0;
     const int ke2 = ke & ~1;
     // all loads of a chunk of 8 strides are issued before the first fma consumes one
@@ -193,7 +273,7 @@ __device__ __forceinline__ void sweep_gemv_n_body(const SweepArgs& s, int bx) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
-            xv[u] = X.ld2(k + 128 * u);
+            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -207,7 +287,7 @@ __device__ __forceinline__ void sweep_gemv_n_body(const SweepArgs& s, int bx) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             mv[u] = *reinterpret_cast<const v2d*>(mrow + k + 128 * u);
-            xv[u] = X.ld2(k + 128 * u);
+            xv[u] = *reinterpret_cast<const v2d*>(x + k + 128 * u);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -217,24 +297,19 @@ __device__ __forceinline__ void sweep_gemv_n_body(const SweepArgs& s, int bx) {
     }
     for (; k < ke2; k += 128) {
         const v2d mv = *reinterpret_cast<const v2d*>(mrow + k);
-        const v2d xv = X.ld2(k);
+        const v2d xv = *reinterpret_cast<const v2d*>(x + k);
         sum0 = fma(mv.x, xv.x, sum0);
         sum1 = fma(mv.y, xv.y, sum1);
     }
-    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], X.ld(ke - 1), sum0);
+    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], x[ke - 1], sum0);
     double sum = sum0 + sum1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if (lane == 0) {
         double v = sum;
-        if (s.sub) v = Bv.ld(row) - sum;
-        Ov.st(row, v);
+        if (s.sub) v = s.Bin[row] - sum;
+        s.Out[row] = v;
     }
-}
-template <bool TRI>
-__global__ __launch_bounds__(256) void sweep_gemv_n(SweepArgs s) {
-    sweep_select_problem(s, blockIdx.z);
-    sweep_gemv_n_body<TRI, false>(s, blockIdx.x);
 }
 
 // One right-hand side, non-transposed, SHORT rows (kdim <= 256: the first block column of a split block inverse, see
@@ -351,18 +426,19 @@ __global__ __launch_bounds__(256) void sweep_gemv_n4(SweepArgs s) {
 // the first workgroup reads 64 times what the last one does, and once the short ones have left, the
 // long ones run on a nearly empty chip (3.0 TB/s on darcy256 / batch 32 against 4.6 for the other
 // sweep kernels).  Non-TRI (C^T inside its staircase): rows [0, mend[column tile]).
-template <bool TRI, int CW, bool COH>
-__device__ __forceinline__ void sweep_gemv_t_body(const SweepArgs& s, int bx) {
+template <bool TRI, int CW>
+__global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
+    sweep_select_problem(s, blockIdx.z);
     constexpr int TPR = CW / 2, RG = 256 / TPR;
     const int t = threadIdx.x;
     const int c2 = (t % TPR) * 2, gidx = t / TPR;
-    const SweepVec<COH> X(s.Xin), Bv(s.Bin), Ov(s.Out);
+    const double* __restrict__ x = s.Xin;
     __shared__ double red[RG][CW + 1];
     const int ncb = s.rows / CW;
     const int npass = TRI ? 2 : 1;
     for (int pass = 0; pass < npass; ++pass) {
-        const int cb = TRI ? (pass == 0 ? bx : ncb - 1 - bx) : bx;
-        if (TRI && pass == 1 && cb == bx) break;          // odd block count: the middle block once
+        const int cb = TRI ? (pass == 0 ? (int)blockIdx.x : ncb - 1 - (int)blockIdx.x) : (int)blockIdx.x;
+        if (TRI && pass == 1 && cb == (int)blockIdx.x) break;          // odd block count: the middle block once
         const int col0 = cb * CW;
         const int kb = TRI ? col0 : 0;          // lower triangular: rows >= column (zeros above the diagonal are stored)
         const int ke = (!TRI && s.mend) ? s.mend[col0 >> 6] : s.kdim;
@@ -375,14 +451,14 @@ __device__ __forceinline__ void sweep_gemv_t_body(const SweepArgs& s, int bx) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 mv[u] = *reinterpret_cast<const v2d*>(mp + (int64_t)(k + u * RG) * s.ld);
-                xv[u] = X.ld(k + u * RG);
+                xv[u] = x[k + u * RG];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) { s0 = fma(mv[u].x, xv[u], s0); s1 = fma(mv[u].y, xv[u], s1); }
         }
         for (; k < ke; k += RG) {
             const v2d mv = *reinterpret_cast<const v2d*>(mp + (int64_t)k * s.ld);
-            const double xv = X.ld(k);
+            const double xv = x[k];
             s0 = fma(mv.x, xv, s0); s1 = fma(mv.y, xv, s1);
         }
         if (pass == 1) __syncthreads();                                  // the first block's reduction has read `red`
@@ -393,15 +469,10 @@ __device__ __forceinline__ void sweep_gemv_t_body(const SweepArgs& s, int bx) {
 #pragma unroll
             for (int i = 0; i < RG; ++i) tot += red[i][t];
             double v = tot;
-            if (s.sub) v = Bv.ld(col0 + t) - tot;
-            Ov.st(col0 + t, v);
+            if (s.sub) v = s.Bin[col0 + t] - tot;
+            s.Out[col0 + t] = v;
         }
     }
-}
-template <bool TRI, int CW>
-__global__ __launch_bounds__(256) void sweep_gemv_t(SweepArgs s) {
-    sweep_select_problem(s, blockIdx.z);
-    sweep_gemv_t_body<TRI, CW, false>(s, blockIdx.x);
 }
 
 inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, const SweepArgs& s, int nprob) {
@@ -424,14 +495,19 @@ inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, con
             else hipLaunchKernelGGL((sweep_gemv_n<false>), grid, block, 0, st, s);
         } else {
             // wide column blocks (256-byte row pieces) when the batch supplies enough workgroups that way (two per CU),
-            // narrow ones otherwise (a lone problem's latency-bound chain; the short products of a split block inverse)
+            // narrow ones otherwise (the short products of a split block inverse); one problem (or a few) with blocks of 512 and more:
+            // 8 columns (64-byte row pieces, 64 row groups) -- its chain of dependent products is bound by what ONE CU pulls in,
+            // and twice the workgroups pull twice as much (round 5; sweep_persist's k = 1 bodies do the same sums)
             const int ncb32 = s.rows / 32;
             const bool wide = nprob >= 8 && s.rows % 32 == 0 && (int64_t)(tri ? (ncb32 + 1) / 2 : ncb32) * nprob >= 512;
-            const int cw = wide ? 32 : 16, ncb = s.rows / cw;
+            const bool narrow = nprob < 8 && s.rows >= 512 && s.rows % 8 == 0;      // (a few problems: the same sums as one alone)
+            const int cw = wide ? 32 : (narrow ? 8 : 16), ncb = s.rows / cw;
             dim3 grid(tri ? (ncb + 1) / 2 : ncb, 1, nprob), block(256);
             if (tri && wide) hipLaunchKernelGGL((sweep_gemv_t<true, 32>), grid, block, 0, st, s);
+            else if (tri && narrow) hipLaunchKernelGGL((sweep_gemv_t<true, 8>), grid, block, 0, st, s);
             else if (tri) hipLaunchKernelGGL((sweep_gemv_t<true, 16>), grid, block, 0, st, s);
             else if (wide) hipLaunchKernelGGL((sweep_gemv_t<false, 32>), grid, block, 0, st, s);
+            else if (narrow) hipLaunchKernelGGL((sweep_gemv_t<false, 8>), grid, block, 0, st, s);
             else hipLaunchKernelGGL((sweep_gemv_t<false, 16>), grid, block, 0, st, s);
         }
     } else {

@@ -87,7 +87,8 @@ typedef struct {
      * 17 potrf_persist (one problem: the in-block Cholesky of a block / a 256-column panel in ONE persistent launch; small
      *    batches: the 256 x 256 diagonal block of a panel.  Round 4 booked these under class 1; class 17 was potrf_panel256, removed)
      * 18 gemm_f64_dma<.., A [k][m]> (the A^T B products of selected inversion: round 4)
-     * work = algorithmic flops (0-2, 6-9, 11-18) or algorithmic bytes (3-5, 10). */
+     * 19 / 20 sweep_persist<k = 1> / <k >= 16> (one problem: a whole sweep in ONE persistent launch; round 5)
+     * work = algorithmic flops (0-2, 6-9, 11-18, 20) or algorithmic bytes (3-5, 10, 19). */
 #define GMRF_KERNEL_CLASSES 24
     double kernel_ms[GMRF_KERNEL_CLASSES];
     double kernel_work[GMRF_KERNEL_CLASSES];
@@ -103,6 +104,9 @@ typedef struct {
     int32_t persist_cus;          /* CUs this handle holds of its device's budget for persistent launches (every workgroup of such a
                                    * launch must be resident; the claims of all handles of a device never exceed its CU count) */
     int32_t persist_refused;      /* 1: the budget refused this handle's claim (other handles hold the CUs): no persistent launches */
+    int32_t sweep_persist;        /* 1: the last gmrf_bt_solve / gmrf_bt_sample ran its sweeps as ONE persistent launch each (one problem,
+                                   * blocks of 512 and more, the handle holds the whole chip); a launch that gives up counts in persist_aborts */
+    int32_t sweep_persist_launches;   /* such launches since the handle was created */
 } gmrf_stats;
 
 /* ------------------------------------------------------------------ life cycle */
@@ -341,8 +345,8 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * one problem re-factors the diagonal tile in every workgroup of a step instead of the look-ahead chain;
  * bit 12: batches always assemble the full block inverses (no split representation; comparison); bit 13: no persistent
  * launches (potrf_persist) -- the launch-per-step forms; bit 15: small batches keep potrf_diag128 + the 128^3 products
- * instead of one persistent launch per panel diagonal block; bit 16: the mean's backward sweep is NOT fused into the sample
- * sweep (gmrf_bt_posterior_async takes the round-4 sequence; comparison).
+ * instead of one persistent launch per panel diagonal block; bit 16: one problem's sweeps keep one launch per product
+ * instead of ONE persistent launch per sweep (sweep_persist; comparison -- bit 13 switches both persistent forms off).
  * (Bits 6, 9, 10, 11, 14 selected comparison routes that lost twice -- left-looking panels, in-panel updates on the GEMM kernel,
  * rank-64 panel steps of batches, 128-column panels, potrf_panel256 -- and were removed with them in round 5; they are ignored.) */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);

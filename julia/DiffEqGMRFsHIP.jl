@@ -280,6 +280,7 @@ struct GmrfStats                             # gmrf_stats
     kernel_ms::NTuple{24,Float64}; kernel_work::NTuple{24,Float64}; kernel_launches::NTuple{24,Int64}
     sweep_bytes_streamed::Float64
     persist_route::Int32; persist_aborts::Int32; persist_cus::Int32; persist_refused::Int32
+    sweep_persist::Int32; sweep_persist_launches::Int32
 end
 
 function stats(F::TridiagonalCholeskyFactor)

@@ -1140,6 +1140,73 @@ def test_persistent_launch_abort_falls_back(pkg):
     assert out["stepwise_aborts"] == 1 and out["stepwise_images_equal"] and out["stepwise_solve_equal"], out
 
 
+def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg):
+    """Round 5: one problem with blocks of 512 and more runs each sweep (/root/reference/src/tridiagonal_cholesky.jl:24-52) as
+    ONE persistent launch (sweep_persist.hpp: the products hand the panel on as a data flow, sentinel-tagged) instead of two
+    dependent launches per block (set_eager bit 16 keeps those).  Same decomposition, same summation order: mean, forward-only,
+    backward-only solves and samples (k = 16, 64: the MFMA bodies; the k = 1 bodies) are BITWISE those of the launch-per-product
+    form, in graph replay and in eager mode; the statistics say which form ran; an in-place solve keeps the launch-per-product
+    form (its input would be lost if a persistent launch gave up)."""
+    import gc
+    import torch
+    for name in ("burgers512x64", "darcy256"):
+        w = pkg.workloads.make(name)
+        rhs = torch.from_numpy(w.rhs).cuda()
+        F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        st = F.stats()
+        assert st["persist_cus"] == 256 and st["persist_refused"] == 0, st        # (the handle holds the whole chip)
+        res = {}
+        for label, bits in (("persist", 0), ("persist_eager", 1), ("per_product", 65536)):
+            F.set_eager(bits)
+            mu = pkg.ldiv(F, rhs); s_mu = F.stats()["sweep_persist"]
+            yf = pkg.forward_solve(F, rhs)
+            xb = pkg.backward_solve(F, rhs)
+            X64 = F.sample(64, mean=mu, seed=3, like=rhs); s_x = F.stats()["sweep_persist"]
+            X16 = F.sample(16, mean=mu, seed=5, like=rhs)
+            res[label] = (mu, yf, xb, X64, X16)
+            assert s_mu == s_x == (0 if bits == 65536 else 1), (name, label, s_mu, s_x)
+        for label in ("persist", "persist_eager"):
+            for a, b in zip(res[label], res["per_product"]):
+                assert torch.equal(a, b), (name, label)
+        F.set_eager(0)
+        n0 = F.stats()["sweep_persist_launches"]
+        buf = rhs.clone()
+        F._solve(buf, pkg._cabi.SOLVE_FULL, out=buf)                               # in place
+        assert F.stats()["sweep_persist"] == 0 and F.stats()["sweep_persist_launches"] == n0
+        assert torch.equal(buf, res["per_product"][0])
+        assert F.stats()["persist_aborts"] == 0
+        r = w.Q @ res["persist"][0].cpu().numpy() - w.rhs
+        assert np.linalg.norm(r) / np.linalg.norm(w.rhs) < 1e-8
+        # a second one-problem handle beside the first: the chip is taken, it keeps the launch-per-step / per-product forms
+        G = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        sg = G.stats()
+        assert sg["persist_cus"] == 0 and sg["persist_refused"] == 1 and sg["persist_route"] == 0, sg
+        assert torch.equal(pkg.ldiv(G, rhs), res["per_product"][0]) and G.stats()["sweep_persist"] == 0
+        del F, G
+        gc.collect()
+
+
+def test_persistent_sweep_abort_falls_back(pkg):
+    """The safety net of the persistent sweeps: every wait for an input panel is bounded; a wave that gives up raises the abort
+    words, every other wait ends on them, the launch drains; gmrf_bt_solve / gmrf_bt_sample see the (mapped host) word behind
+    their own synchronisation and repeat the call with a launch per product, which the handle keeps (stats.persist_aborts, claim
+    released).  Forced in a child process with GMRF_SWEEP_SPIN_MS=0: results bitwise those of the launch-per-product form."""
+    import json
+    import subprocess
+    import sys
+    env = dict(_os.environ, GMRF_SWEEP_SPIN_MS="0")
+    r = subprocess.run([sys.executable, _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "sweep_abort_child.py")],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["after_factor"] == {"persist_aborts": 0, "persist_cus": 256, "sweep_persist": 0}, out
+    assert out["after_solve"] == {"persist_aborts": 1, "persist_cus": 0, "sweep_persist": 0}, out
+    assert out["after_sample"] == {"persist_aborts": 1, "persist_cus": 0, "sweep_persist": 0}, out
+    assert out["route_after_refactor"] == 0 and out["aborts_of_the_per_product_form"] == 0, out
+    assert out["solve_equal"] and out["sample_equal"], out
+    assert out["sample_first"] == {"persist_aborts": 1, "persist_cus": 0, "sweep_persist": 0} and out["sample_first_equal"], out
+
+
 def test_inverse_rows_inside_the_fused_steps(pkg):
     """One problem, blocks of up to 16 tiles: the inverse Linv_i is assembled row by row by extra workgroups of
     the fused panel-step launches (block forward substitution, X[r,c] = -X_rr sum_p L[r,p] X[p,c]) instead of by
