@@ -167,6 +167,10 @@ __device__ __forceinline__ void sweep_mm_body(const SweepArgs& s, int bx, int by
     v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
     const SweepVec<COH> X(s.Xin, s), Bv(s.Bin, s), Ov(s.Out, s);
     const int64_t xrow = (int64_t)(r0 + li) * s.ldx;
+    // (sweep_persist: the addend is requested before the wait for the input -- behind the reduction it is a round trip on the critical path)
+    const int rhs_t = ((t & 63) >> 4) + 4 * (t >> 6), m_t = t & 15;
+    double bin_early = 0.0;
+    if (COH && s.sub) bin_early = Bv.ld((int64_t)(r0 + rhs_t) * s.ldb + m0 + m_t);
     // Operands come straight from global memory (each wave has its own K range, nothing to share
     // through LDS).  Loads are issued a whole chunk of k-groups ahead of the MFMAs that consume
     // them, otherwise every pair of MFMAs waits a full memory latency: chunks of 8 groups, then single groups -- and inside
@@ -244,7 +248,7 @@ __device__ __forceinline__ void sweep_mm_body(const SweepArgs& s, int bx, int by
     const int rhs = ((t & 63) >> 4) + 4 * (t >> 6);
     const int m = t & 15;
     double v = sum;
-    if (s.sub) v = Bv.ld((int64_t)(r0 + rhs) * s.ldb + m0 + m) - sum;
+    if (s.sub) v = (COH ? bin_early : Bv.ld((int64_t)(r0 + rhs) * s.ldb + m0 + m)) - sum;
     Ov.st((int64_t)(r0 + rhs) * s.ldo + m0 + m, v);
 }
 template <bool TRANS, bool TRI>

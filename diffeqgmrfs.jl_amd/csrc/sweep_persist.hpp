@@ -72,6 +72,10 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
     const int kb = (!TRI && s.kst && valid) ? s.kst[row >> 6] : 0;
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
     const int ke2 = ke & ~1;
+    // (the addend too is requested before the wait: behind the reduction it would be a round trip of its own on the critical path)
+    const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
+    double bin = 0.0;
+    if (s.sub && lane == 0 && valid) bin = Bv.ld(row);
     double sum0 = 0.0, sum1 = 0.0;
     auto trip = [&](int kk, bool first) {
         v2d mv[NM];
@@ -94,12 +98,7 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
     double sum = sum0 + sum1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0 && valid) {
-        const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
-        double v = sum;
-        if (s.sub) v = Bv.ld(row) - sum;
-        Ov.st(row, v);
-    }
+    if (lane == 0 && valid) Ov.st(row, s.sub ? bin - sum : sum);
 }
 
 // backward: out[c] = sum_k Mat[k][c] x[k] for the CW columns of block `cb` -- CW / 2 threads x 16 bytes per matrix row, 512 / CW row
@@ -116,6 +115,9 @@ __device__ __forceinline__ void sweep_gemv_t_flow(const SweepArgs& s, int cb, sp
     const int kb = TRI ? col0 : 0;
     const int ke = (!TRI && s.mend) ? s.mend[col0 >> 6] : s.kdim;
     const double* __restrict__ mp = s.Mat + col0 + c2;
+    const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
+    double bin = 0.0;
+    if (s.sub && t < CW) bin = Bv.ld(col0 + t);        // (before the wait, not behind the reduction)
     double s0 = 0.0, s1 = 0.0;
     auto trip = [&](int kk, bool first) {
         v2d mv[NM];
@@ -139,10 +141,7 @@ __device__ __forceinline__ void sweep_gemv_t_flow(const SweepArgs& s, int cb, sp
         double tot = 0.0;
 #pragma unroll
         for (int i = 0; i < RG; ++i) tot += red[i][t];
-        const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
-        double v = tot;
-        if (s.sub) v = Bv.ld(col0 + t) - tot;
-        Ov.st(col0 + t, v);
+        Ov.st(col0 + t, s.sub ? bin - tot : tot);
     }
 }
 
@@ -151,8 +150,11 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
     constexpr int CWB = 8;                              // column block of the backward k = 1 products (launch_sweep: `narrow`)
     __shared__ __attribute__((aligned(16))) double xs[KP1 ? SWEEP_PERSIST_XMAX : 2];
     __shared__ double red_t[KP1 ? 512 / CWB : 1][CWB + 1];
+    __shared__ int stair[2][SWEEP_PERSIST_XMAX / 64];    // kst | mend: looked up in every product, so not from global memory each time
     const int w = blockIdx.x, tid = threadIdx.x, nw = a.nw;
     const int bsp = a.bsp, cm = a.cm, rm = a.rm, wc = bsp - cm;
+    if (tid < bsp / 64) { stair[0][tid] = a.kst[tid]; stair[1][tid] = a.mend[tid]; }
+    __syncthreads();
     const bool bw = a.backward != 0;
     // product p = 0 .. 2 N - 2:  p = 0 is the first block's X product; then (C product, X product) per block
     auto product = [&](int p, SweepArgs& s) -> int {
@@ -169,7 +171,7 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
             s.Bin = a.Pin + (int64_t)i * bsp + (bw ? cm : 0);
             s.Out = a.T + (int64_t)i * bsp + (bw ? cm : 0);
             s.rows = bw ? wc : rm; s.kdim = bw ? rm : wc; s.sub = 1;
-            s.kst = a.kst; s.mend = a.mend;
+            s.kst = stair[0]; s.mend = stair[1];
         } else {
             s.Mat = a.Linv + (int64_t)i * a.bstride; s.ld = bsp;
             s.Xin = (step == 0 ? a.Pin : a.T) + (int64_t)i * bsp;        // (the first block has no coupling product)
@@ -208,6 +210,8 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
                 xhi = min((xhi + 1) & ~1, (s.kdim + 1) & ~1);
                 auto gather = [&]() {
                     const SweepVec<true> X(s.Xin, s);
+                    // (piece by piece: looking at a thread's pieces together, or a pause before the first look, measured slower --
+                    //  0.59 -> 0.60 ms and +0.28 us per product per 0.43 us of pause on darcy256's forward sweep)
                     for (int k = xlo + 2 * tid; k < xhi; k += 512) {
                         v2d v[1];
                         X.ldw2(v, k, 0);
