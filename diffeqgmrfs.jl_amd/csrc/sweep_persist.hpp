@@ -63,7 +63,7 @@ typedef __attribute__((address_space(3))) const double sp_lds_double;
 // forward: out[row] = sum_k Mat[row][k] x[k] -- one wave per row; per lane the even / odd elements of k = kb + 2 lane + 128 u in two
 // sums, ascending u; the odd last element on lane 0; the wave's xor-shuffle reduction
 template <bool TRI, class Gather>
-__device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp_lds_double* xs, Gather&& gather) {
+__device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp_lds_double* xs, double* res, Gather&& gather) {
     constexpr int NM = 32;                            // 16-byte pieces per lane and trip: rows of up to 4096 in one
     const int lane = threadIdx.x & 63;
     const int row = vb * 4 + (threadIdx.x >> 6);
@@ -73,9 +73,12 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
     const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
     const int ke2 = ke & ~1;
     // (the addend too is requested before the wait: behind the reduction it would be a round trip of its own on the critical path)
+    // (the four rows' results leave in ONE store instruction, 32 contiguous bytes from lanes 0 - 3 of wave 0: a 128-byte line of
+    //  the panel then sees 4 write-through stores per product instead of 16)
     const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
+    const int trow = vb * 4 + (int)threadIdx.x;
     double bin = 0.0;
-    if (s.sub && lane == 0 && valid) bin = Bv.ld(row);
+    if (s.sub && threadIdx.x < 4 && trow < s.rows) bin = Bv.ld(trow);
     double sum0 = 0.0, sum1 = 0.0;
     auto trip = [&](int kk, bool first) {
         v2d mv[NM];
@@ -98,7 +101,9 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
     double sum = sum0 + sum1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0 && valid) Ov.st(row, s.sub ? bin - sum : sum);
+    if (lane == 0) res[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x < 4 && trow < s.rows) Ov.st(trow, s.sub ? bin - res[threadIdx.x] : res[threadIdx.x]);
 }
 
 // backward: out[c] = sum_k Mat[k][c] x[k] for the CW columns of block `cb` -- CW / 2 threads x 16 bytes per matrix row, 512 / CW row
@@ -150,6 +155,7 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
     constexpr int CWB = 8;                              // column block of the backward k = 1 products (launch_sweep: `narrow`)
     __shared__ __attribute__((aligned(16))) double xs[KP1 ? SWEEP_PERSIST_XMAX : 2];
     __shared__ double red_t[KP1 ? 512 / CWB : 1][CWB + 1];
+    __shared__ double res_n[4];
     __shared__ int stair[2][SWEEP_PERSIST_XMAX / 64];    // kst | mend: looked up in every product, so not from global memory each time
     const int w = blockIdx.x, tid = threadIdx.x, nw = a.nw;
     const int bsp = a.bsp, cm = a.cm, rm = a.rm, wc = bsp - cm;
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
                     }
                     __syncthreads();
                 };
-                if (!bw) { if (part == 0) sweep_gemv_n_flow<false>(s, vb, xl, gather); else sweep_gemv_n_flow<true>(s, vb, xl, gather); }
+                if (!bw) { if (part == 0) sweep_gemv_n_flow<false>(s, vb, xl, res_n, gather); else sweep_gemv_n_flow<true>(s, vb, xl, res_n, gather); }
                 else { if (part == 0) sweep_gemv_t_flow<false, CWB>(s, cb, xl, red_t, gather); else sweep_gemv_t_flow<true, CWB>(s, cb, xl, red_t, gather); }
                 __syncthreads();                   // (the next block's vector / partial sums go to the same LDS words)
             }
