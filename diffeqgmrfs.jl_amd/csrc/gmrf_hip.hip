@@ -907,7 +907,7 @@ static int persist_demand(const gmrf_handle* h) {
     wgs *= h->B;
     return wgs > 0 && wgs <= h->cu_count ? (int)wgs : 0;
 }
-// One problem with blocks of 512 and more: its sweeps run as one persistent launch each (sweep_persist.hpp), whose workgroups --
+// One problem with blocks of 512 .. 1024: its sweeps run as one persistent launch each (sweep_persist.hpp), whose workgroups --
 // one per CU, up to 256 -- must all be resident: the handle then asks for the whole chip.  0: the sweeps keep a launch per product.
 static int sweep_persist_demand(const gmrf_handle* h) {
     if (h->no_persist || h->no_sweep_persist || h->persist_gave_up || h->cu_count < 64 || h->B != 1) return 0;

@@ -29,7 +29,11 @@
 
 namespace gmrf {
 
-constexpr int SWEEP_PERSIST_XMAX = 4096;      // one right-hand side: block sizes up to this (the input vector of a product sits in LDS)
+// Block sizes up to this: with 1024 a product is at most ONE virtual block per workgroup (256 workgroups: 1024 rows / 4, 64 x 4 tiles)
+// and the persistent form wins (darcy256, elliptic512, burgers512x64).  Blocks of 4096 were measured with the limit at 4096
+// (burgers4096x512: four virtual blocks per workgroup and product, each with its own gather): mean 48.6 -> 63.7 ms, 64 samples
+// 124.6 -> 138.4 ms -- there a launch per product, whose boundary is small beside its 32 - 128 MB products, stays.
+constexpr int SWEEP_PERSIST_XMAX = 1024;
 
 struct SweepPersistArgs {
     const double* C; const double* Linv;     // the factor: coupling windows, explicit inverses of the diagonal blocks
@@ -64,7 +68,7 @@ typedef __attribute__((address_space(3))) const double sp_lds_double;
 // sums, ascending u; the odd last element on lane 0; the wave's xor-shuffle reduction
 template <bool TRI, class Gather>
 __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp_lds_double* xs, double* res, Gather&& gather) {
-    constexpr int NM = 32;                            // 16-byte pieces per lane and trip: rows of up to 4096 in one
+    constexpr int NM = SWEEP_PERSIST_XMAX / 128;      // 16-byte pieces per lane and trip: a whole row in one
     const int lane = threadIdx.x & 63;
     const int row = vb * 4 + (threadIdx.x >> 6);
     const bool valid = row < s.rows;

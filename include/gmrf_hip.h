@@ -105,7 +105,7 @@ typedef struct {
                                    * launch must be resident; the claims of all handles of a device never exceed its CU count) */
     int32_t persist_refused;      /* 1: the budget refused this handle's claim (other handles hold the CUs): no persistent launches */
     int32_t sweep_persist;        /* 1: the last gmrf_bt_solve / gmrf_bt_sample ran its sweeps as ONE persistent launch each (one problem,
-                                   * blocks of 512 and more, the handle holds the whole chip); a launch that gives up counts in persist_aborts */
+                                   * blocks of 512 .. 1024, the handle holds the whole chip); a launch that gives up counts in persist_aborts */
     int32_t sweep_persist_launches;   /* such launches since the handle was created */
 } gmrf_stats;
 

@@ -1141,7 +1141,7 @@ def test_persistent_launch_abort_falls_back(pkg):
 
 
 def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg):
-    """Round 5: one problem with blocks of 512 and more runs each sweep (/root/reference/src/tridiagonal_cholesky.jl:24-52) as
+    """Round 5: one problem with blocks of 512 .. 1024 runs each sweep (/root/reference/src/tridiagonal_cholesky.jl:24-52) as
     ONE persistent launch (sweep_persist.hpp: the products hand the panel on as a data flow, sentinel-tagged) instead of two
     dependent launches per block (set_eager bit 16 keeps those).  Same decomposition, same summation order: mean, forward-only,
     backward-only solves and samples (k = 16, 64: the MFMA bodies; the k = 1 bodies) are BITWISE those of the launch-per-product
@@ -1184,6 +1184,54 @@ def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg
         assert torch.equal(pkg.ldiv(G, rhs), res["per_product"][0]) and G.stats()["sweep_persist"] == 0
         del F, G
         gc.collect()
+
+
+def test_persistent_sweeps_under_uneven_load(pkg):
+    """The hand-offs of the persistent sweeps (data-tagged: a consumer repeats its `sc1` loads of a panel chunk until no value
+    is the sentinel) must hold when the chip is NOT idle -- the guide's rule for every inter-workgroup hand-off: test under
+    uneven load, checking every word.  A second host thread keeps a batch of 16 darcy256-sized problems (blocks of 1024: GEMMs
+    and `potrf_persist`-free batch routes on another stream) factoring and solving while the one-problem handle runs 30
+    solves and samples as persistent launches: every result bitwise the launch-per-product result taken on the idle chip;
+    no abort."""
+    import threading
+    import torch
+    w = pkg.workloads.make("burgers512x64")
+    rhs = torch.from_numpy(w.rhs).cuda()
+    F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+    F.set_eager(65536)
+    mu0 = pkg.ldiv(F, rhs); X0 = F.sample(16, mean=mu0, seed=9, like=rhs)
+    F.set_eager(0)
+    streams = pkg.StreamSet(1)
+    stop = threading.Event()
+    err = []
+    def load():
+        try:
+            B = 16
+            Fb = pkg.TridiagonalCholeskyFactor(batch=B, stream=streams.pointers[0])
+            vals = np.stack([w.Q.data * (1.0 + 0.01 * p) for p in range(B)])
+            Fb.factor(w.Q, w.n_blocks, values=vals)
+            rb = np.stack([w.rhs] * B)[:, None, :]
+            while not stop.is_set():
+                Fb.refactor(vals)
+                Fb.solve_batch(rb)
+            Fb.close()
+        except Exception as e:      # noqa: BLE001
+            err.append(repr(e))
+    th = threading.Thread(target=load)
+    th.start()
+    try:
+        bad = 0
+        for it in range(30):
+            mu = pkg.ldiv(F, rhs)
+            X = F.sample(16, mean=mu, seed=9, like=rhs)
+            bad += int(not torch.equal(mu, mu0)) + int(not torch.equal(X, X0))
+        st = F.stats()
+    finally:
+        stop.set(); th.join()
+    assert not err, err
+    assert bad == 0 and st["persist_aborts"] == 0 and st["sweep_persist"] == 1, (bad, st["persist_aborts"], st["sweep_persist"])
+    del F
+    import gc; gc.collect()
 
 
 def test_persistent_sweep_abort_falls_back(pkg):
