@@ -64,48 +64,56 @@ typedef __attribute__((address_space(3))) const double sp_lds_double;
 // input vector into LDS (the workgroup polls it there: SweepVec::ldw; ends with a barrier), then the sums run from registers
 // and LDS.  The matrix's trip through the memory system thus overlaps the input's -- the one thing a launch per product cannot do.
 
+// A lone workgroup per CU issues about one instruction per 8 cycles and wave: the bodies below count instructions.  Which
+// pieces of a thread's sequence exist is decided by SCALAR comparisons (whole pieces: the same for every lane of the wave /
+// thread of the workgroup; only the last, partial piece carries a per-lane predicate), and the matrix is read by buffer
+// loads whose per-piece stride sits in the scalar offset (no 64-bit address arithmetic per piece).
+
 // forward: out[row] = sum_k Mat[row][k] x[k] -- one wave per row; per lane the even / odd elements of k = kb + 2 lane + 128 u in two
 // sums, ascending u; the odd last element on lane 0; the wave's xor-shuffle reduction
 template <bool TRI, class Gather>
 __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp_lds_double* xs, double* res, Gather&& gather) {
-    constexpr int NM = SWEEP_PERSIST_XMAX / 128;      // 16-byte pieces per lane and trip: a whole row in one
+    constexpr int NM = SWEEP_PERSIST_XMAX / 128;      // 16-byte pieces per lane: a whole row
     const int lane = threadIdx.x & 63;
-    const int row = vb * 4 + (threadIdx.x >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int row = vb * 4 + wv;                       // (wave-uniform)
     const bool valid = row < s.rows;
     const int ke = valid ? (TRI ? (row + 1) : s.kdim) : 0;
-    const int kb = (!TRI && s.kst && valid) ? s.kst[row >> 6] : 0;
-    const double* __restrict__ mrow = s.Mat + (int64_t)row * s.ld;
+    const int kb = (!TRI && s.kst && valid) ? __builtin_amdgcn_readfirstlane(s.kst[row >> 6]) : 0;
     const int ke2 = ke & ~1;
-    // (the addend too is requested before the wait: behind the reduction it would be a round trip of its own on the critical path)
+    const int span = max(ke2 - kb, 0), nfull = span >> 7, rem = span & 127;      // whole pieces of 128 elements; the partial one
+    const bool tail = 2 * lane < rem;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(s.Mat), 0, 0x7fffffff, 0x00020000);
+    const int voff = (int)(((int64_t)row * s.ld + kb + 2 * lane) * 8);
     // (the four rows' results leave in ONE store instruction, 32 contiguous bytes from lanes 0 - 3 of wave 0: a 128-byte line of
     //  the panel then sees 4 write-through stores per product instead of 16)
     const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
     const int trow = vb * 4 + (int)threadIdx.x;
     double bin = 0.0;
     if (s.sub && threadIdx.x < 4 && trow < s.rows) bin = Bv.ld(trow);
+    sw_v4u mv[NM];
+#pragma unroll
+    for (int u = 0; u < NM; ++u) {
+        if (s.dbg) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
+        else if (u < nfull) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * 1024, 0);
+        else if (u == nfull && tail) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * 1024, 0);
+    }
+    gather();
     double sum0 = 0.0, sum1 = 0.0;
-    auto trip = [&](int kk, bool first) {
-        v2d mv[NM];
+    sp_lds_double* xl = xs + kb + 2 * lane;
 #pragma unroll
-        for (int u = 0; u < NM; ++u)
-            if (kk + 128 * u < ke2) mv[u] = s.dbg ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(mrow + kk + 128 * u);
-        if (first) gather();
-#pragma unroll
-        for (int u = 0; u < NM; ++u)
-            if (kk + 128 * u < ke2) {
-                const v2d xv = *reinterpret_cast<__attribute__((address_space(3))) const v2d*>(xs + kk + 128 * u);
-                sum0 = fma(mv[u].x, xv.x, sum0);
-                sum1 = fma(mv[u].y, xv.y, sum1);
-            }
-    };
-    const int k0 = kb + lane * 2;
-    trip(k0, true);
-    for (int kk = k0 + NM * 128; kk < ke2; kk += NM * 128) trip(kk, false);
-    if ((ke & 1) && lane == 0) sum0 = fma(mrow[ke - 1], xs[ke - 1], sum0);
+    for (int u = 0; u < NM; ++u) {
+        if (u < nfull || (u == nfull && tail)) {
+            const v2d xv = *reinterpret_cast<__attribute__((address_space(3))) const v2d*>(xl + 128 * u);
+            sum0 = fma(__hiloint2double((int)mv[u].y, (int)mv[u].x), xv.x, sum0);
+            sum1 = fma(__hiloint2double((int)mv[u].w, (int)mv[u].z), xv.y, sum1);
+        }
+    }
+    if ((ke & 1) && lane == 0) sum0 = fma(s.Mat[(int64_t)row * s.ld + ke - 1], xs[ke - 1], sum0);
     double sum = sum0 + sum1;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-    if (lane == 0) res[threadIdx.x >> 6] = sum;
+    if (lane == 0) res[wv] = sum;
     __syncthreads();
     if (threadIdx.x < 4 && trow < s.rows) Ov.st(trow, s.sub ? bin - res[threadIdx.x] : res[threadIdx.x]);
 }
@@ -117,33 +125,38 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
 template <bool TRI, int CW, class Gather>
 __device__ __forceinline__ void sweep_gemv_t_flow(const SweepArgs& s, int cb, sp_lds_double* xs, double (*red)[CW + 1], Gather&& gather) {
     constexpr int TPR = CW / 2, RG = 256 / TPR;
-    constexpr int NM = 1024 / RG > 32 ? 32 : 1024 / RG;        // rows per thread and trip: blocks of 1024 in one
+    constexpr int NM = SWEEP_PERSIST_XMAX / RG;                 // rows per thread: a whole block
     const int t = threadIdx.x;
     const int c2 = (t % TPR) * 2, gidx = t / TPR;
     const int col0 = cb * CW;
     const int kb = TRI ? col0 : 0;
-    const int ke = (!TRI && s.mend) ? s.mend[col0 >> 6] : s.kdim;
-    const double* __restrict__ mp = s.Mat + col0 + c2;
+    const int ke = (!TRI && s.mend) ? __builtin_amdgcn_readfirstlane(s.mend[col0 >> 6]) : s.kdim;
+    const int span = max(ke - kb, 0), nfull = span / RG, rem = span - nfull * RG;      // whole pieces of RG rows; the partial one
+    const bool tail = gidx < rem;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(s.Mat), 0, 0x7fffffff, 0x00020000);
+    const int voff = (int)(((int64_t)(kb + gidx) * s.ld + col0 + c2) * 8);
+    const int step = (int)(RG * s.ld * 8);
     const SweepVec<true> Bv(s.Bin, s), Ov(s.Out, s);
     double bin = 0.0;
     if (s.sub && t < CW) bin = Bv.ld(col0 + t);        // (before the wait, not behind the reduction)
+    sw_v4u mv[NM];
+#pragma unroll
+    for (int u = 0; u < NM; ++u) {
+        if (s.dbg) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
+        else if (u < nfull) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * step, 0);
+        else if (u == nfull && tail) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * step, 0);
+    }
+    gather();
     double s0 = 0.0, s1 = 0.0;
-    auto trip = [&](int kk, bool first) {
-        v2d mv[NM];
+    sp_lds_double* xl = xs + kb + gidx;
 #pragma unroll
-        for (int u = 0; u < NM; ++u)
-            if (kk + u * RG < ke) mv[u] = s.dbg ? (v2d){1.0, 1.0} : *reinterpret_cast<const v2d*>(mp + (int64_t)(kk + u * RG) * s.ld);
-        if (first) gather();
-#pragma unroll
-        for (int u = 0; u < NM; ++u)
-            if (kk + u * RG < ke) {
-                const double xv = xs[kk + u * RG];
-                s0 = fma(mv[u].x, xv, s0); s1 = fma(mv[u].y, xv, s1);
-            }
-    };
-    const int k0 = kb + gidx;
-    trip(k0, true);
-    for (int kk = k0 + NM * RG; kk < ke; kk += NM * RG) trip(kk, false);
+    for (int u = 0; u < NM; ++u) {
+        if (u < nfull || (u == nfull && tail)) {
+            const double xv = xl[u * RG];
+            s0 = fma(__hiloint2double((int)mv[u].y, (int)mv[u].x), xv, s0);
+            s1 = fma(__hiloint2double((int)mv[u].w, (int)mv[u].z), xv, s1);
+        }
+    }
     red[gidx][c2] = s0; red[gidx][c2 + 1] = s1;
     __syncthreads();
     if (t < CW) {
