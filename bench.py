@@ -84,7 +84,7 @@ def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
     """HBM bytes per launch of kernel symbols from the committed rocprofv3 --pmc snapshot profiles/<round>_<file_stem>.json
     (newest round present; FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_summary.py).  A snapshot, not a live counter read: the
     source string names the commit it was taken at.  Returns ({symbol: bytes}, source) or (None, None)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")
         try:
             prof = json.load(open(path))
@@ -106,7 +106,7 @@ def pmc_traffic(file_stem: str, symbol_prefixes, batch=None):
 def pmc_traffic_weighted(file_stem: str, prefix: str, batch=None):
     """Launch-weighted HBM bytes per launch over every kernel symbol that starts with `prefix` in the newest committed
     snapshot (see pmc_traffic).  Returns (bytes, source) or (None, None)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{file_stem}.json")))
         except Exception:
@@ -702,7 +702,9 @@ def main():
         per_step = world * pj.solves_per_step()
         workload = (f"{w.name}: n={w.n}, {w.n_blocks} blocks x {w.block_size}, nnz={w.Q.nnz}; {pj.n_streams * pj.batch} independent "
                     f"posterior(s) per GPU and step ({pj.n_streams} stream(s) x batch {pj.batch}), each factor + mean + {args.samples} samples")
-        sharding = "independent problems per rank, no data-path collective"
+        sharding = ("independent problems per rank, no data-path collective (weak scaling; north_star's split -- ONE factor shared, samples "
+                    "sharded by Philox id over RCCL -- is measured at n_gpus > 1 in side_legs.shared_factor_allgather / side_legs.shared_factor "
+                    "(root broadcast) / side_legs.c4_elliptic512 of this line)")
         extra["streams_on_own_hardware_queue"] = pj.streams_on_own_queue
 
     if rank == 0:

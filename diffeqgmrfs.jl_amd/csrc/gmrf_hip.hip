@@ -911,6 +911,7 @@ static int persist_demand(const gmrf_handle* h) {
 // one per CU, up to 256 -- must all be resident: the handle then asks for the whole chip.  0: the sweeps keep a launch per product.
 static int sweep_persist_demand(const gmrf_handle* h) {
     if (h->no_persist || h->no_sweep_persist || h->persist_gave_up || h->cu_count < 64 || h->B != 1) return 0;
+    if (!h->d_kst || !h->d_mend) return 0;             // (a handle that adopted a factor without analysing a pattern)
     if (h->bsp < 512 || h->bsp > SWEEP_PERSIST_XMAX || h->bsp % 64 != 0 || h->cmin % 16 != 0 || h->rmax % 16 != 0) return 0;      // (the bodies' tilings: 16 rows, 8 / 16 columns)
     return h->cu_count;
 }
@@ -1655,6 +1656,7 @@ static gmrf_status sweep_launches(gmrf_handle* h, bool backward, int kp, double*
     SweepArgs s;
     s.ld = ld;
     const int nprob = (int)h->B;
+    s.narrow = (nprob < 8 && bsp >= 512 && bsp <= SWEEP_PERSIST_XMAX) ? 1 : 0;      // (what sweep_persist's k = 1 bodies sum: 8-column blocks)
     const int64_t pPanel = (int64_t)kp * npad;
     const int64_t pX = stride_pX(h), pCm = stride_pC(h);
     const int64_t ldc = c_ld(h), cstride = c_blk(h);
@@ -2142,6 +2144,7 @@ gmrf_status gmrf_bt_adopt_commit(gmrf_handle* h, int32_t l_blocks_valid) {
     for (char g : h->got_block) all = all && g;
     h->logdet_valid = all;
     h->got_block.assign((size_t)h->N, 0);
+    persist_plan(h);                   // (a receiver's sweeps may be persistent launches too: the claim is planned where a factor becomes usable)
     return GMRF_OK;
 }
 
@@ -2380,6 +2383,7 @@ gmrf_status gmrf_bt_import_factor(gmrf_handle* h, const void* buf, int64_t bytes
     in += (N - 1) * be;
     for (int64_t i = 0; i < N; ++i) GCHK(put(in + i * be, h->d_Linv + h->sel * stride_pX(h) + i * blk_elems(h), true));
     h->factored = true; h->l_valid = true;
+    persist_plan(h);
     h->xsplit = 0;                                     // the image holds the full inverses
     return GMRF_OK;
 }

@@ -37,6 +37,7 @@ struct SweepArgs {
     unsigned* abort_w = nullptr;
     unsigned* host_abort = nullptr;
     unsigned spin_limit = 0;
+    int narrow = 0;                     // k = 1, transposed: 8-column blocks (one problem or a few, blocks of 512 .. 1024: launch_sweep)
     int dbg = 0;                        // tuning aid (GMRF_SWEEP_DBG): 1 = the k = 1 flow bodies skip their matrix loads (garbage results: the pure hand-off time)
 };
 
@@ -504,7 +505,9 @@ inline hipError_t launch_sweep(hipStream_t st, bool trans, bool tri, int kp, con
             // and twice the workgroups pull twice as much (round 5; sweep_persist's k = 1 bodies do the same sums)
             const int ncb32 = s.rows / 32;
             const bool wide = nprob >= 8 && s.rows % 32 == 0 && (int64_t)(tri ? (ncb32 + 1) / 2 : ncb32) * nprob >= 512;
-            const bool narrow = nprob < 8 && s.rows >= 512 && s.rows % 8 == 0;      // (a few problems: the same sums as one alone)
+            // (a few problems: the same sums as one alone.  Up to 1024 rows: darcy256's backward sweep 1.10 -> 0.91 ms; blocks of 4096
+            //  have the workgroups anyway and lose on the 64-byte row pieces -- burgers4096x512: 26 -> 46 us per coupling product)
+            const bool narrow = s.narrow != 0 && s.rows % 8 == 0;      // (the host decides by the BLOCK size: sweep_launches)
             const int cw = wide ? 32 : (narrow ? 8 : 16), ncb = s.rows / cw;
             dim3 grid(tri ? (ncb + 1) / 2 : ncb, 1, nprob), block(256);
             if (tri && wide) hipLaunchKernelGGL((sweep_gemv_t<true, 32>), grid, block, 0, st, s);
