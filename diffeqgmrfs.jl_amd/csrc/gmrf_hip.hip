@@ -151,6 +151,7 @@ struct gmrf_handle {
     double g2_tile_k = 0.0;            // sum over lower tiles of the K extent of S = -C C^T (flop accounting)
     bool c_dirty = false;              // C must be re-zeroed (new pattern)
     int* d_lo_rowptr = nullptr;
+    int* d_dg_rowptr = nullptr;       // [N][bsp + 1]: the diagonal blocks' entries row by row (absolute positions in d_keys)
     // tile plan of the sparse C = B X^T (spmm_bxt_tiles): per lower block and 64-row tile the distinct columns, per entry its index into them
     int* d_bxt_uptr = nullptr; int* d_bxt_ucols = nullptr; uint16_t* d_bxt_lidx = nullptr; int* d_bxt_gtiles = nullptr;
     std::vector<int> bxt_ng;           // groups of row tiles per lower block (host copy: the launch's grid)
@@ -215,6 +216,7 @@ struct gmrf_handle {
     // workgroup must be resident: the handle then claims the whole chip (persist_plan).  A wait that gives up sets the mapped host
     // word; gmrf_bt_solve / gmrf_bt_sample see it at their synchronisation and repeat the call with the launch-per-product form.
     bool no_sweep_persist = false;     // set_eager bit 16 / GMRF_SWEEP_PERSIST=0
+    bool no_scatter_fold = false;      // set_eager bit 17: one problem keeps scatter_block as a launch of its own behind S = -C C^T (comparison)
     bool sweep_persist_planned = false;   // the claim covers the whole chip (persist_plan)
     bool sweep_persist_launched = false;  // such a launch was enqueued since the abort word was last looked at
     unsigned* d_sweep_flags = nullptr;    // [0] the device's abort word
@@ -541,6 +543,7 @@ struct SymbolicPlan {
     std::vector<int> uptr, ucols, gtiles, ng;
     std::vector<uint16_t> lidx;
     int ecap = 0, nrt = 0;
+    std::vector<int> drowptr;          // [N][bsp + 1]: a diagonal block's entries row by row
 };
 
 static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector<HostEntry>>& dg,
@@ -551,7 +554,11 @@ static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector
     keys.clear(); src.clear();
     for (int64_t i = 0; i < N; ++i) {
         sp.diag_first[i] = (int64_t)keys.size(); sp.diag_count[i] = (int64_t)dg[i].size();
-        for (auto& e : dg[i]) { keys.push_back(e.key); src.push_back(e.src); }
+        {   // row by row too (round 5): the workgroups of spmm_bxt_tiles that zero rows of the next Schur block scatter D_i's rows into them
+            std::vector<HostEntry> drow(dg[i]);
+            std::stable_sort(drow.begin(), drow.end(), [](const HostEntry& x, const HostEntry& y) { return x.key < y.key; });
+            for (auto& e : drow) { keys.push_back(e.key); src.push_back(e.src); }
+        }
         sp.low_first[i] = (int64_t)keys.size(); sp.low_count[i] = (int64_t)lo[i].size();
         std::vector<HostEntry> byrow(lo[i]);           // row by row (key = row << 32 | col): spmm_bxt walks rows
         std::stable_sort(byrow.begin(), byrow.end(), [](const HostEntry& x, const HostEntry& y) { return x.key < y.key; });
@@ -584,6 +591,17 @@ static void build_symbolic(int64_t N, int64_t bsp, const std::vector<std::vector
         for (int64_t r = 0; r < bsp; ++r) max_row = std::max<int64_t>(max_row, rp[r + 1]);
         rp[0] = (int)first;
         for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
+    }
+    // row pointers into the diagonal blocks' entry lists (absolute positions in `keys`)
+    sp.drowptr.assign((size_t)(N * (bsp + 1)), 0);
+    if (keys.size() < ((size_t)1 << 31)) {
+        for (int64_t i = 0; i < N; ++i) {
+            int* rp = sp.drowptr.data() + i * (bsp + 1);
+            const int64_t first = sp.diag_first[i], cnt = sp.diag_count[i];
+            for (int64_t k = 0; k < cnt; ++k) rp[(keys[first + k] >> 32) + 1]++;
+            rp[0] = (int)first;
+            for (int64_t r = 0; r < bsp; ++r) rp[r + 1] += rp[r];
+        }
     }
     // dense GEMM: 2 bs^3 flop at ~50 TF/s; sparse: one pass over C.  Rows of up to 32 entries go the sparse way,
     // anything denser keeps the GEMM.
@@ -688,6 +706,10 @@ static gmrf_status upload_entries(gmrf_handle* h, const std::vector<std::vector<
     h->d_lo_rowptr = nullptr;
     HIPCHK(hipMalloc(&h->d_lo_rowptr, sp.rowptr.size() * sizeof(int)));
     HIPCHK(hipMemcpyAsync(h->d_lo_rowptr, sp.rowptr.data(), sp.rowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    free_dev(h->d_dg_rowptr);
+    h->d_dg_rowptr = nullptr;
+    HIPCHK(hipMalloc(&h->d_dg_rowptr, sp.drowptr.size() * sizeof(int)));
+    HIPCHK(hipMemcpyAsync(h->d_dg_rowptr, sp.drowptr.data(), sp.drowptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     h->lo_row_max = sp.max_row;
     h->sparse_b = sp.sparse_b;
@@ -1259,8 +1281,10 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
         const int rm_s = (i > 0) ? (int)h->rmax : 0;
         // (round 5: where the coupling product of this block runs on spmm_bxt_tiles, that launch zeroes the rows as well)
         static const bool no_tiles_z = [] { const char* e = getenv("GMRF_BXT_TILES"); return e && atoi(e) == 0; }();
-        const bool zero_in_bxt = i > 0 && h->sparse_b && !h->dense_g1 && h->bxt_plan_ok && !no_tiles_z && h->bxt_nrt == (int)h->rmax / 64
-                                 && ((int64_t)(bsp - rm_s) * bsp) % 2 == 0;
+        const bool scatter_in_bxt = i > 0 && nb == 1 && h->sparse_b && !h->dense_g1 && h->bxt_plan_ok && !no_tiles_z && h->bxt_nrt == (int)h->rmax / 64
+                                    && h->d_dg_rowptr && h->bsp == h->bs && !h->no_scatter_fold;
+        const bool zero_in_bxt = scatter_in_bxt || (i > 0 && h->sparse_b && !h->dense_g1 && h->bxt_plan_ok && !no_tiles_z && h->bxt_nrt == (int)h->rmax / 64
+                                                    && ((int64_t)(bsp - rm_s) * bsp) % 2 == 0);
         if (rm_s < bsp && !zero_in_bxt) {
             const int64_t cnt = (int64_t)(bsp - rm_s) * bsp;
             hipLaunchKernelGGL(zero_rows, dim3((unsigned)((cnt / 2 + 255) / 256), nb), dim3(256), 0, h->stream,
@@ -1326,7 +1350,14 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
                     const int ncg = (chunks + ta.nch - 1) / ta.nch;
                     ta.nprob = (int)nb;
                     ta.zdst = nullptr; ta.zcount = 0; ta.zpdst = 0; ta.zwgs = 0;
-                    if (zero_in_bxt && rm_s < bsp) {
+                    ta.srowptr = nullptr; ta.skeys = nullptr; ta.svals = nullptr;
+                    if (scatter_in_bxt) {
+                        // one problem: the launch zeroes the WHOLE Schur block and scatters D_i into it row range by row range; the
+                        // product then accumulates, S = 1.0 * S - C C^T -- the same single rounding fl(D - acc) as "S := -C C^T, then
+                        // S += D_i", without the scatter launch (4.9 us + a boundary) between the product and the block's Cholesky
+                        ta.zdst = h->d_S; ta.zcount = (int64_t)bsp * bsp; ta.zpdst = bstride; ta.zwgs = 64;
+                        ta.srowptr = h->d_dg_rowptr + i * (h->bsp + 1); ta.skeys = h->d_keys; ta.svals = h->d_vals;
+                    } else if (zero_in_bxt && rm_s < bsp) {
                         ta.zdst = h->d_S + (int64_t)rm_s * ld; ta.zcount = (int64_t)(bsp - rm_s) * bsp; ta.zpdst = bstride;
                         ta.zwgs = (int)std::min<int64_t>(32, std::max<int64_t>(1, ta.zcount / 16384));      // >= 128 KB per workgroup
                     }
@@ -1344,11 +1375,11 @@ static gmrf_status factor_blocks_range(gmrf_handle* h, int64_t i0, int64_t i1) {
             }
             // S = D - C C^T             (src/tridiagonal_cholesky.jl:77): the product part.  Tile (R, R') sums over
             // the columns from max(kst[R], kst[R']) on -- the rest of the two row tiles is structurally zero.
-            GCHK(gemm(h, false, false, rm, rm, W, 0, 1, -1.0, C, ldc, C, ldc, 0.0, h->d_S, ld, pC, pC,
+            GCHK(gemm(h, false, false, rm, rm, W, 0, 1, -1.0, C, ldc, C, ldc, scatter_in_bxt ? 1.0 : 0.0, h->d_S, ld, pC, pC,
                       bstride, 1, 0, 0, 0, nullptr, 0, 0, 0, 2.0 * 64.0 * 64.0 * h->g2_tile_k * (double)h->B,
                       h->d_kst, h->d_kst, nullptr));
         }
-        if (h->diag_count[i] > 0) {
+        if (h->diag_count[i] > 0 && !scatter_in_bxt) {
             hipLaunchKernelGGL(scatter_block, dim3((unsigned)((h->diag_count[i] + 255) / 256), nb), dim3(256), 0,
                                h->stream, h->d_keys, h->d_vals, h->diag_first[i], h->diag_count[i], h->d_S, ld,
                                h->n_entries, bstride, 1);
@@ -1848,7 +1879,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     persist_release(h);
     destroy_graphs(h);
     free_dev(h->d_keys); free_dev(h->d_vals); free_dev(h->d_src); free_dev(h->d_nz_stage);
-    free_dev(h->d_lo_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
+    free_dev(h->d_lo_rowptr); free_dev(h->d_dg_rowptr); free_dev(h->d_kst); free_dev(h->d_mend);
     free_dev(h->d_bxt_uptr); free_dev(h->d_bxt_ucols); free_dev(h->d_bxt_lidx); free_dev(h->d_bxt_gtiles);
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
@@ -1910,6 +1941,7 @@ gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager) {
     if (((eager & 8192) != 0) != h->no_persist) { destroy_graphs(h); h->no_persist = (eager & 8192) != 0; }
     if (((eager & 32768) != 0) != h->no_persist_panels) { destroy_graphs(h); h->no_persist_panels = (eager & 32768) != 0; }
     if (((eager & 65536) != 0) != h->no_sweep_persist) { destroy_graphs(h); h->no_sweep_persist = (eager & 65536) != 0; }
+    if (((eager & 131072) != 0) != h->no_scatter_fold) { destroy_graphs(h); h->no_scatter_fold = (eager & 131072) != 0; }
     h->eager = (eager & 1) != 0;
     return GMRF_OK;
 }

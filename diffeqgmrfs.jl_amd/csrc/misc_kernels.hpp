@@ -279,6 +279,11 @@ struct BxtTileArgs {
     // launch of its own per block, 5 us + a boundary on one problem's chain): `zwgs` more workgroups per problem behind the others
     int nprob;                // problems of the launch (the grid no longer says)
     double* zdst; int64_t zcount, zpdst; int zwgs;      // zdst == nullptr / zwgs == 0: nothing to zero
+    // ... and (one problem) scatters the diagonal block D_i into the zeroed block: srowptr != nullptr -- zdst is then the WHOLE
+    // block (zcount = bsp^2), a zeroing workgroup owns whole rows and writes the entries of its rows behind its zeros
+    const int* srowptr;       // [bsp + 1] positions in skeys / svals of the rows of D_i
+    const uint64_t* skeys;    // row << 32 | col
+    const double* svals;
 };
 
 constexpr int BXT_UCAP = 256;             // distinct columns per group (one per thread)
@@ -304,9 +309,23 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         // zeroing role: workgroup z of problem p clears its share of zdst[p]
         const int zi = (int)blockIdx.x - ncg * a.ng * nprob;
         const int p = zi / a.zwgs, z = zi % a.zwgs;
+        double* d = a.zdst + (int64_t)p * a.zpdst;
+        if (a.srowptr) {
+            const int rpw = (a.bsp + a.zwgs - 1) / a.zwgs;                        // whole rows per workgroup
+            const int ra = min(a.bsp, z * rpw), rb = min(a.bsp, ra + rpw);
+            const int64_t lo = (int64_t)ra * a.ld, hi = (int64_t)rb * a.ld;
+            for (int64_t i = lo + 2 * t; i < hi; i += 512) *reinterpret_cast<v2d*>(d + i) = (v2d){0.0, 0.0};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the zeros have arrived before an entry lands on one)
+            __syncthreads();
+            const int e0 = a.srowptr[ra], e1 = a.srowptr[rb];
+            for (int e = e0 + t; e < e1; e += 256) {
+                const uint64_t key = a.skeys[e];
+                d[(int64_t)(key >> 32) * a.ld + (int64_t)(key & 0xffffffffu)] = a.svals[e];
+            }
+            return;
+        }
         const int64_t per = ((a.zcount / 2 + a.zwgs - 1) / a.zwgs) * 2;           // doubles per workgroup (even)
         const int64_t lo = (int64_t)z * per, hi = min(a.zcount, lo + per);
-        double* d = a.zdst + (int64_t)p * a.zpdst;
         for (int64_t i = lo + 2 * t; i < hi; i += 512) *reinterpret_cast<v2d*>(d + i) = (v2d){0.0, 0.0};
         return;
     }

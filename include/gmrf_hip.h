@@ -346,7 +346,9 @@ gmrf_status gmrf_bt_set_profiling(gmrf_handle* h, int32_t level);
  * bit 12: batches always assemble the full block inverses (no split representation; comparison); bit 13: no persistent
  * launches (potrf_persist) -- the launch-per-step forms; bit 15: small batches keep potrf_diag128 + the 128^3 products
  * instead of one persistent launch per panel diagonal block; bit 16: one problem's sweeps keep one launch per product
- * instead of ONE persistent launch per sweep (sweep_persist; comparison -- bit 13 switches both persistent forms off).
+ * instead of ONE persistent launch per sweep (sweep_persist; comparison -- bit 13 switches both persistent forms off); bit 17: one problem
+ * keeps scatter_block (S += D_i) as a launch of its own behind S = -C C^T instead of zero + scatter inside the spmm_bxt_tiles launch and an
+ * accumulating product (comparison; same bits).
  * (Bits 6, 9, 10, 11, 14 selected comparison routes that lost twice -- left-looking panels, in-panel updates on the GEMM kernel,
  * rank-64 panel steps of batches, 128-column panels, potrf_panel256 -- and were removed with them in round 5; they are ignored.) */
 gmrf_status gmrf_bt_set_eager(gmrf_handle* h, int32_t eager);

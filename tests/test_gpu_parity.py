@@ -1140,6 +1140,31 @@ def test_persistent_launch_abort_falls_back(pkg):
     assert out["stepwise_aborts"] == 1 and out["stepwise_images_equal"] and out["stepwise_solve_equal"], out
 
 
+def test_schur_block_assembled_inside_the_coupling_launch(pkg):
+    """Round 5, one problem: `S_i = D_i - C C^T` (/root/reference/src/tridiagonal_cholesky.jl:77) used to be "S := -C C^T (GEMM),
+    then S += D_i (scatter_block, a launch of its own on the chain of dependent launches)".  Now the workgroups of the coupling
+    launch (spmm_bxt_tiles) that zeroed the rows the product does not write zero the whole block and scatter D_i's rows into it,
+    and the product accumulates onto it -- the same single rounding fl(D - acc).  set_eager bit 17 keeps the old sequence: the
+    factor (L, C, Linv blocks), the log-determinant and a solve must be bitwise equal."""
+    for name in ("burgers512x64", "darcy256"):
+        w = pkg.workloads.make(name)
+        F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        G = pkg.TridiagonalCholeskyFactor()
+        G.set_eager(131072)
+        G.factor(w.Q, w.n_blocks)
+        for i in (0, 1, w.n_blocks // 2, w.n_blocks - 1):
+            assert np.array_equal(F.chos[i], G.chos[i]), (name, i)
+            assert np.array_equal(F.inverses[i], G.inverses[i]), (name, i)
+        assert np.array_equal(F.Cs[w.n_blocks - 2], G.Cs[w.n_blocks - 2])
+        assert F.logdet() == G.logdet()
+        assert np.array_equal(pkg.ldiv(F, w.rhs), pkg.ldiv(G, w.rhs))
+        F.refactor(w.Q.data * 1.5)                     # (graph replay: the zeroing is part of every replay)
+        G.refactor(w.Q.data * 1.5)
+        assert np.array_equal(F.chos[w.n_blocks - 1], G.chos[w.n_blocks - 1])
+        del F, G
+        import gc; gc.collect()
+
+
 def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg):
     """Round 5: one problem with blocks of 512 .. 1024 runs each sweep (/root/reference/src/tridiagonal_cholesky.jl:24-52) as
     ONE persistent launch (sweep_persist.hpp: the products hand the panel on as a data flow, sentinel-tagged) instead of two
