@@ -313,8 +313,11 @@ __global__ __launch_bounds__(256, 3) void spmm_bxt_tiles(BxtTileArgs a) {
         if (a.srowptr) {
             const int rpw = (a.bsp + a.zwgs - 1) / a.zwgs;                        // whole rows per workgroup
             const int ra = min(a.bsp, z * rpw), rb = min(a.bsp, ra + rpw);
-            const int64_t lo = (int64_t)ra * a.ld, hi = (int64_t)rb * a.ld;
-            for (int64_t i = lo + 2 * t; i < hi; i += 512) *reinterpret_cast<v2d*>(d + i) = (v2d){0.0, 0.0};
+            // (a row up to the end of its diagonal tile: the product and the Cholesky read the lower tiles only)
+            for (int r = ra; r < rb; ++r) {
+                const int cend = min(a.bsp, ((r >> 6) + 1) * 64);
+                for (int c = 2 * t; c < cend; c += 512) *reinterpret_cast<v2d*>(d + (int64_t)r * a.ld + c) = (v2d){0.0, 0.0};
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the zeros have arrived before an entry lands on one)
             __syncthreads();
             const int e0 = a.srowptr[ra], e1 = a.srowptr[rb];
