@@ -1165,6 +1165,19 @@ def test_schur_block_assembled_inside_the_coupling_launch(pkg):
         import gc; gc.collect()
 
 
+_ref16_cache = {}
+
+
+def F_ref16(F, res, rhs):
+    """16 samples with seed 6 by the launch-per-product form (computed once per handle)."""
+    key = id(F)
+    if key not in _ref16_cache:
+        F.set_eager(65536)
+        _ref16_cache[key] = F.sample(16, mean=res["per_product"][0], seed=6, like=rhs)
+        F.set_eager(0)
+    return _ref16_cache[key]
+
+
 def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg):
     """Round 5: one problem with blocks of 512 .. 1024 runs each sweep (/root/reference/src/tridiagonal_cholesky.jl:24-52) as
     ONE persistent launch (sweep_persist.hpp: the products hand the panel on as a data flow, sentinel-tagged) instead of two
@@ -1194,6 +1207,19 @@ def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg
             for a, b in zip(res[label], res["per_product"]):
                 assert torch.equal(a, b), (name, label)
         F.set_eager(0)
+        # consecutive solves with DIFFERENT right-hand sides through the same panels: a value left over from the previous call
+        # (in a cache of another XCD, or in a panel the sentinel fill did not cover) would be taken for this call's data
+        rhs2 = torch.flip(rhs, dims=[0]) * 0.37 + 1.0
+        F.set_eager(65536); mu2_ref = pkg.ldiv(F, rhs2); xb2_ref = pkg.backward_solve(F, rhs2); F.set_eager(0)
+        for it in range(6):
+            if it % 2 == 0:
+                assert torch.equal(pkg.ldiv(F, rhs), res["per_product"][0]), (name, it)
+                assert torch.equal(pkg.backward_solve(F, rhs), res["per_product"][2]), (name, it)
+            else:
+                assert torch.equal(pkg.ldiv(F, rhs2), mu2_ref), (name, it)
+                assert torch.equal(pkg.backward_solve(F, rhs2), xb2_ref), (name, it)
+            assert torch.equal(F.sample(16, mean=res["per_product"][0], seed=5 + it % 2, like=rhs),
+                               res["per_product"][4] if it % 2 == 0 else F_ref16(F, res, rhs)), (name, it)
         n0 = F.stats()["sweep_persist_launches"]
         buf = rhs.clone()
         F._solve(buf, pkg._cabi.SOLVE_FULL, out=buf)                               # in place
