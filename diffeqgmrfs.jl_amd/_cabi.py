@@ -23,7 +23,7 @@ BLOCK_L, BLOCK_C, BLOCK_LINV = 0, 1, 2
 EXPORTS = [
     "gmrf_bt_create", "gmrf_bt_destroy", "gmrf_last_error", "gmrf_version",
     "gmrf_bt_factor_csc", "gmrf_bt_factor_blocks", "gmrf_bt_refactor_values",
-    "gmrf_bt_solve", "gmrf_bt_sample", "gmrf_bt_normals", "gmrf_bt_marginal_var",
+    "gmrf_bt_solve", "gmrf_bt_sample", "gmrf_bt_posterior", "gmrf_bt_normals", "gmrf_bt_marginal_var",
     "gmrf_bt_var_accumulate", "gmrf_bt_logdet", "gmrf_bt_get_block", "gmrf_bt_factor_buffer",
     "gmrf_bt_adopt_shape", "gmrf_bt_adopt_commit", "gmrf_bt_adopt_layout", "gmrf_bt_get_layout", "gmrf_bt_block_range",
     "gmrf_bt_set_keep_l", "gmrf_bt_storage_bytes", "gmrf_bt_set_storage", "gmrf_bt_factor_begin_csc",
@@ -104,6 +104,7 @@ def load() -> C.CDLL:
         "gmrf_bt_refactor_values": [vp, vp, P(i32)],
         "gmrf_bt_solve": [vp, vp, vp, i64, i64, i64, i32],
         "gmrf_bt_sample": [vp, u64, i64, i64, vp, vp, vp, i64],
+        "gmrf_bt_posterior": [vp, vp, u64, i64, i64, vp, vp, i64],
         "gmrf_bt_normals": [vp, u64, i64, i64, vp, i64],
         "gmrf_bt_marginal_var": [vp, i32, i64, u64, vp, vp],
         "gmrf_bt_var_accumulate": [vp, i32, i64, i64, u64, vp, vp],

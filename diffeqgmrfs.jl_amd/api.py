@@ -696,6 +696,22 @@ class TridiagonalCholeskyFactor:
                                              _cabi.ptr(store), self.N))
         return view
 
+    def posterior(self, b, k: int, seed: int = 0x5EED, first_id: int = 0):
+        """(mean, samples) = (A^-1 b, mean + L^-T z) in ONE call (mean(x_cond) and rand(rng, x_cond) of the reference's script,
+        scripts/darcy/solve_darcy_gmrf-fem.jl:190-191): bitwise `ldiv(F, b)` and `F.sample(k, mean=...)`; on device tensors the
+        samples' sweep runs beside the mean's two where this handle's sweeps are persistent launches (gmrf_bt_posterior).
+        One problem (batch == 1); b: n values; samples come back n x k like `sample`."""
+        if self.batch != 1:
+            raise ValueError("posterior(): one problem per handle (use solve_batch / sample_batch for batches)")
+        xa, kb, ld, one_d = _colmajor(b, self.N)
+        if kb != 1:
+            raise ValueError("posterior(): one right-hand side")
+        mstore, mview = _alloc_like(xa, self.N, 1, True)
+        sstore, sview = _alloc_like(xa, self.N, k, False)
+        _cabi.check(self._lib.gmrf_bt_posterior(self._h, _cabi.ptr(xa), seed, first_id, k, _cabi.ptr(mstore), _cabi.ptr(sstore),
+                                                self.N))
+        return mview, sview
+
     def marginal_var(self, method: str = "exact", k: int = 50, seed: int = 0x5EED, Q: Optional[CsrMatrix] = None,
                      q_values=None, out=None):
         """diag(Q^-1).  "exact" (selected inversion), "rbmc" (the reference's RBMCStrategy(k); needs Q)

@@ -224,11 +224,14 @@ struct gmrf_handle {
     int64_t t_elems = 0;
     unsigned* h_sweep_abort = nullptr;    // mapped host word
     int sweep_nw = 0;
+    double *d_P2 = nullptr, *d_Y2 = nullptr, *d_T2 = nullptr;     // gmrf_bt_posterior: the samples' panels (their sweep runs beside the mean's)
+    int64_t p2_elems = 0;
     bool sweep_persist_hold = false;      // this call must not use it (its input would be lost if the launch gave up: in-place solve)
     bool no_persist_panels = false;    // batches small enough for it keep potrf_diag128 + the 128^3 products instead of one persistent launch per panel (set_eager bit 15)
     // second branch of the captured factor graph: the inverse assembly of a block's first half runs
     // beside the panel chain of its second half (see potrf_block)
     hipStream_t aux = nullptr;
+    bool aux_distinct = false;         // `aux` was chosen on a hardware queue of its own (gmrf_bt_posterior)
     hipStream_t gemm_stream = nullptr; // stream gemm() launches on (h->stream unless inside the aux branch)
     bool capturing = false;
     std::vector<hipEvent_t> fork_events;
@@ -1623,13 +1626,16 @@ static gmrf_status sweep_persist_prepare(gmrf_handle* h, int kp) {
     return GMRF_OK;
 }
 
-static gmrf_status launch_sweep_persist(gmrf_handle* h, bool backward, int kp, double* Pin, double* Yout) {
+static gmrf_status launch_sweep_persist(gmrf_handle* h, bool backward, int kp, double* Pin, double* Yout, hipStream_t st_over = nullptr,
+                                        double* T_over = nullptr) {
     const int nw = h->sweep_nw;
     const int64_t elems = (int64_t)kp * h->n_pad;
-    if (!h->d_sweep_flags || !h->h_sweep_abort || nw <= 0 || !h->d_Tsw || h->t_elems < elems)
+    hipStream_t st = st_over ? st_over : h->stream;
+    double* Tp = T_over ? T_over : h->d_Tsw;
+    if (!h->d_sweep_flags || !h->h_sweep_abort || nw <= 0 || !Tp || (!T_over && h->t_elems < elems))
         return bad_shape("internal: words / panel of the persistent sweeps not allocated");
     SweepPersistArgs a;
-    a.C = h->d_C; a.Linv = h->d_Linv; a.Pin = Pin; a.T = h->d_Tsw; a.Yout = Yout;
+    a.C = h->d_C; a.Linv = h->d_Linv; a.Pin = Pin; a.T = Tp; a.Yout = Yout;
     a.N = (int)h->N; a.bsp = (int)h->bsp; a.cm = (int)h->cmin; a.rm = (int)h->rmax; a.kp = kp; a.backward = backward ? 1 : 0; a.nw = nw;
     a.npad = h->n_pad; a.ldc = c_ld(h); a.cstride = c_blk(h); a.bstride = (int64_t)h->bsp * h->bsp;
     a.kst = h->d_kst; a.mend = h->d_mend;
@@ -1651,12 +1657,12 @@ static gmrf_status launch_sweep_persist(gmrf_handle* h, bool backward, int kp, d
     {
         // the panels the products read from each other: sentinel everywhere (elems is even: n_pad is a multiple of 64)
         ProfScope ps(h, 5, 16.0 * (double)elems);
-        hipLaunchKernelGGL(sweep_fill_sentinel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, h->stream, h->d_Tsw, Yout, elems);
+        hipLaunchKernelGGL(sweep_fill_sentinel, dim3((unsigned)((elems / 2 + 255) / 256)), dim3(256), 0, st, Tp, Yout, elems);
         HIPCHK(hipGetLastError());
     }
     ProfScope ps(h, kp == 1 ? 19 : 20, work);
-    if (kp == 1) hipLaunchKernelGGL(sweep_persist<true>, dim3((unsigned)nw), dim3(256), 0, h->stream, a);
-    else hipLaunchKernelGGL(sweep_persist<false>, dim3((unsigned)nw), dim3(256), 0, h->stream, a);
+    if (kp == 1) hipLaunchKernelGGL(sweep_persist<true>, dim3((unsigned)nw), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(sweep_persist<false>, dim3((unsigned)nw), dim3(256), 0, st, a);
     HIPCHK(hipGetLastError());
     return GMRF_OK;
 }
@@ -1884,7 +1890,7 @@ gmrf_status gmrf_bt_destroy(gmrf_handle* h) {
     if (!h->external_storage) { free_dev(h->d_L); free_dev(h->d_C); free_dev(h->d_Linv); }
     else if (!h->keep_l) free_dev(h->d_L);               // the one-block work buffer is ours
     free_dev(h->d_S); free_dev(h->d_B); free_dev(h->d_T); free_dev(h->d_W);
-    free_dev(h->d_sweep_flags); free_dev(h->d_Tsw);
+    free_dev(h->d_sweep_flags); free_dev(h->d_Tsw); free_dev(h->d_P2); free_dev(h->d_Y2); free_dev(h->d_T2);
     if (h->h_sweep_abort) { (void)hipHostFree(h->h_sweep_abort); h->h_sweep_abort = nullptr; }
     free_dev(h->d_info); free_dev(h->d_logdet); free_dev(h->d_pflags); free_dev(h->d_kbx); free_dev(h->d_V);
     free_dev(h->d_P); free_dev(h->d_Y); free_dev(h->d_Tp);
@@ -2789,6 +2795,100 @@ gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int6
     (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
     h->stats.sample_ms = ms;
     if (h->profiling) prof_collect(h);
+    return GMRF_OK;
+}
+
+// mean = A^-1 b and k samples mean + L^-T z in ONE call (scripts/darcy/solve_darcy_gmrf-fem.jl:190-191 calls `mean` and `rand` on one
+// factor, one after the other).  The samples' backward sweep needs nothing of the mean -- only their last step, adding it, does --
+// so where the sweeps are persistent launches (one problem, blocks of 512 .. 1024) it runs BESIDE the mean's two sweeps, on a second
+// stream with panels of its own: both are bound by their chains of hand-offs, not by the chip, and two resident workgroups per
+// CU (97 + 189 VGPRs, 13 + 33 KB of LDS) take turns in the same time one takes alone.  The same kernels and the same sums as
+// gmrf_bt_solve + gmrf_bt_sample: bitwise their results.  Anywhere else the call IS those two calls.
+gmrf_status gmrf_bt_posterior(gmrf_handle* h, const double* b, uint64_t seed, int64_t first_id, int64_t k, double* mean,
+                              double* samples, int64_t ld) {
+    if (!h || !b || !mean || !samples) return bad_shape("null pointer");
+    if (!h->factored) { g_last_error = "posterior before factor"; return GMRF_ERR_NO_FACTOR; }
+    if (k <= 0 || ld < h->n) return bad_shape("bad k / ld");
+    HIPCHK(hipSetDevice(h->device));
+    const int kp = pad_k(k);
+    const bool dev_all = is_device_ptr(b) && is_device_ptr(mean) && is_device_ptr(samples);
+    const bool beside = h->B == 1 && k <= KP_CHUNK && k >= 2 && dev_all && b != mean && !h->profiling && sweep_persist_ok(h, 1) && sweep_persist_ok(h, kp);
+    if (!beside) {
+        GCHK(gmrf_bt_solve(h, b, mean, 1, h->n, h->n, GMRF_SOLVE_FULL));
+        return gmrf_bt_sample(h, seed, first_id, k, mean, nullptr, samples, ld);
+    }
+    GCHK(ensure_panels(h, 1));
+    GCHK(sweep_persist_prepare(h, 1));
+    const int64_t elems = (int64_t)kp * h->n_pad;
+    if (!h->d_P2 || h->p2_elems < elems) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        free_dev(h->d_P2); free_dev(h->d_Y2); free_dev(h->d_T2);
+        h->d_P2 = h->d_Y2 = h->d_T2 = nullptr; h->p2_elems = 0;
+        HIPCHK(hipMalloc(&h->d_P2, sizeof(double) * (size_t)elems));
+        HIPCHK(hipMalloc(&h->d_Y2, sizeof(double) * (size_t)elems));
+        HIPCHK(hipMalloc(&h->d_T2, sizeof(double) * (size_t)elems));
+        h->p2_elems = elems;
+    }
+    if (!h->aux_distinct) {
+        // the second stream must sit on a hardware queue of its own (two streams on one queue serialise: gmrf_streams_create):
+        // candidates are timed against this handle's stream with the 1 ms spin kernel, the first that overlaps is kept
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->aux) { (void)hipStreamSynchronize(h->aux); (void)hipStreamDestroy(h->aux); h->aux = nullptr; }
+        const unsigned long long ticks = 100000ull;
+        double one = 1e30;
+        for (int r = 0; r < 2; ++r) one = std::min(one, spin_pair_ms(h->stream, nullptr, ticks));
+        std::vector<hipStream_t> cand;
+        for (int c = 0; c < 12 && !h->aux; ++c) {
+            hipStream_t st = nullptr;
+            HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            hipLaunchKernelGGL(gmrf_spin_kernel, dim3(1), dim3(64), 0, st, 1ull);      // (first use binds the stream to its queue)
+            (void)hipStreamSynchronize(st);
+            const double t = std::min(spin_pair_ms(h->stream, st, ticks), spin_pair_ms(h->stream, st, ticks));
+            if (t < 1.5 * one) h->aux = st; else cand.push_back(st);
+        }
+        if (!h->aux && !cand.empty()) { h->aux = cand.back(); cand.pop_back(); }       // (none overlaps: any will do, serialised)
+        for (hipStream_t st : cand) (void)hipStreamDestroy(st);
+        if (!h->aux) return bad_shape("internal: no second stream");
+        h->aux_distinct = true;
+    }
+    h->fork_next = 0;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    GCHK(fork_event(h, &ev_fork)); GCHK(fork_event(h, &ev_join));
+    h->sweep_persist_launched = true;
+    h->stats.sweep_persist = 1;
+    h->stats.sweep_persist_launches += 3;
+    HIPCHK(hipEventRecord(h->ev0, h->stream));
+    HIPCHK(hipEventRecord(ev_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->aux, ev_fork, 0));
+    // second stream: z -> P2, backward sweep P2 -> Y2
+    {
+        const int64_t total = (int64_t)kp * h->n_pad;
+        hipLaunchKernelGGL(fill_normals_panel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, h->aux, h->d_P2, h->n_pad,
+                           (int)h->bs, (int)h->bsp, (int)k, kp, seed, first_id, k);
+        HIPCHK(hipGetLastError());
+        GCHK(launch_sweep_persist(h, true, kp, h->d_P2, h->d_Y2, h->aux, h->d_T2));
+        HIPCHK(hipEventRecord(ev_join, h->aux));
+    }
+    // this stream: b -> P, forward P -> Y, backward Y -> P, mean out
+    GCHK(launch_pack(h, b, h->n, 1, 1));
+    GCHK(launch_sweep_persist(h, false, 1, h->d_P, h->d_Y));
+    GCHK(launch_sweep_persist(h, true, 1, h->d_Y, h->d_P));
+    GCHK(launch_unpack(h, h->d_P, mean, h->n, 1, nullptr));
+    HIPCHK(hipStreamWaitEvent(h->stream, ev_join, 0));
+    GCHK(launch_unpack(h, h->d_Y2, samples, ld, (int)k, mean));
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    bool repeat = false;
+    GCHK(sweep_persist_check(h, &repeat));
+    if (repeat) {                                      // (a persistent sweep gave up: the two calls, with a launch per product)
+        HIPCHK(hipStreamSynchronize(h->aux));
+        GCHK(gmrf_bt_solve(h, b, mean, 1, h->n, h->n, GMRF_SOLVE_FULL));
+        return gmrf_bt_sample(h, seed, first_id, k, mean, nullptr, samples, ld);
+    }
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, h->ev0, h->ev1);
+    h->stats.solve_ms = ms;                            // (mean and samples together)
+    h->stats.sample_ms = 0.0;
     return GMRF_OK;
 }
 

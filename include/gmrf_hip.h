@@ -157,6 +157,14 @@ gmrf_status gmrf_bt_solve(gmrf_handle* h, const double* b, double* y, int64_t k,
 gmrf_status gmrf_bt_sample(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k,
                            const double* mean, const double* z, double* out, int64_t ld);
 
+/* mean = A^-1 b and k samples mean + L^-T z(id = first_id + s) in ONE call: what
+ * scripts/darcy/solve_darcy_gmrf-fem.jl:190-191 asks of one factor (`mean`, then `rand`).  Results bitwise those of
+ * gmrf_bt_solve(mode 0) followed by gmrf_bt_sample(mean = that mean, z = NULL); where the sweeps of a handle are persistent
+ * launches (one problem, blocks of 512 .. 1024, device pointers, 2 <= k <= 128) the samples' sweep runs BESIDE the mean's two on a
+ * second stream.  b, mean: n doubles; samples: n x k column-major, leading dimension ld.  stats.solve_ms = the whole call. */
+gmrf_status gmrf_bt_posterior(gmrf_handle* h, const double* b, uint64_t seed, int64_t first_id, int64_t k,
+                              double* mean, double* samples, int64_t ld);
+
 /* The N(0,1) draws gmrf_bt_sample would use (for tests and for callers that need z). */
 gmrf_status gmrf_bt_normals(gmrf_handle* h, uint64_t seed, int64_t first_id, int64_t k,
                             double* z, int64_t ld);

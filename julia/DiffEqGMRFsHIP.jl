@@ -212,6 +212,26 @@ function sample(F::TridiagonalCholeskyFactor, k::Integer; mean = nothing, z = no
     return out
 end
 
+"""
+`mean(x_cond)` and `rand(rng, x_cond, k)` of one factor in ONE call (scripts/darcy/solve_darcy_gmrf-fem.jl:190-191): returns
+`(mean, samples)`, bitwise `ldiv(F, b)` and `sample(F, k; mean = ...)`.  On device arrays (pass `CuPtr`-like pointers through
+`posterior!`) the samples' sweep runs beside the mean's two where the handle's sweeps are persistent launches.
+"""
+function posterior(F::TridiagonalCholeskyFactor, b::AbstractVector{Float64}, k::Integer; seed::Integer = 0x5EED, first_id::Integer = 0)
+    mean = Vector{Float64}(undef, F.N)
+    out = Matrix{Float64}(undef, F.N, k)
+    GC.@preserve b mean out check(ccall((:gmrf_bt_posterior, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
+        F.handle, b, seed, first_id, k, mean, out, F.N))
+    return mean, out
+end
+"The same on raw (device) pointers: `b`, `mean` n doubles, `samples` n x k column-major with leading dimension `ld`."
+posterior!(F::TridiagonalCholeskyFactor, b::Ptr{Float64}, mean::Ptr{Float64}, samples::Ptr{Float64}, k::Integer, ld::Integer;
+           seed::Integer = 0x5EED, first_id::Integer = 0) =
+    check(ccall((:gmrf_bt_posterior, libgmrf), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, UInt64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Int64),
+        F.handle, b, seed, first_id, k, mean, samples, ld))
+
 "The N(0,1) draws `sample` uses: Philox4x32-10 keyed by (seed, sample id, dof) -- independent of the GPU count."
 function normals(F::TridiagonalCholeskyFactor, k::Integer; seed::Integer = 0x5EED, first_id::Integer = 0)
     out = Matrix{Float64}(undef, F.N, k * F.batch)

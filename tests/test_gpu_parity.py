@@ -1237,6 +1237,41 @@ def test_persistent_sweeps_of_one_problem_are_the_per_product_sweeps_bitwise(pkg
         gc.collect()
 
 
+def test_posterior_in_one_call_is_mean_then_samples_bitwise(pkg):
+    """gmrf_bt_posterior: `mean(x_cond)` and `rand(rng, x_cond)` of one factor (scripts/darcy/solve_darcy_gmrf-fem.jl:190-191) in
+    ONE call.  Where the handle's sweeps are persistent launches the samples' backward sweep runs BESIDE the mean's two sweeps
+    (a second stream, panels of its own); the results are bitwise those of `ldiv` followed by `sample(mean = ...)` -- with the
+    persistent sweeps, with a launch per product, on device tensors and on host arrays (the call is then the two calls), for
+    one configuration with persistent sweeps (burgers512x64, darcy256) and one without (darcy64: blocks of 256)."""
+    import gc
+    import torch
+    for name in ("burgers512x64", "darcy256", "darcy64"):
+        w = pkg.workloads.make(name)
+        rhs = torch.from_numpy(w.rhs).cuda()
+        F = pkg.tridiagonal_cholesky(w.Q, w.n_blocks)
+        mu_ref = pkg.ldiv(F, rhs)
+        for k, seed in ((64, 3), (16, 5), (48, 7)):
+            X_ref = F.sample(k, mean=mu_ref, seed=seed, like=rhs)
+            for bits in (0, 65536, 1):
+                F.set_eager(bits)
+                mu, X = F.posterior(rhs, k, seed=seed)
+                assert torch.equal(mu, mu_ref) and torch.equal(X, X_ref), (name, k, bits)
+                st = F.stats()
+                assert st["persist_aborts"] == 0
+                assert st["sweep_persist"] == (1 if bits != 65536 and name != "darcy64" else 0), (name, bits, st["sweep_persist"])
+            F.set_eager(0)
+        # twice in a row with another right-hand side (the panels of the two streams are reused), then host arrays
+        rhs2 = torch.flip(rhs, dims=[0]) * 0.5 - 2.0
+        mu2_ref = pkg.ldiv(F, rhs2); X2_ref = F.sample(32, mean=mu2_ref, seed=11, like=rhs)
+        for it in range(3):
+            mu2, X2 = F.posterior(rhs2, 32, seed=11)
+            assert torch.equal(mu2, mu2_ref) and torch.equal(X2, X2_ref), (name, it)
+        mu_h, X_h = F.posterior(w.rhs, 16, seed=5)
+        assert np.array_equal(mu_h, mu_ref.cpu().numpy()) and np.array_equal(X_h, F.sample(16, mean=mu_ref, seed=5, like=rhs).cpu().numpy())
+        del F
+        gc.collect()
+
+
 def test_persistent_sweeps_under_uneven_load(pkg):
     """The hand-offs of the persistent sweeps (data-tagged: a consumer repeats its `sc1` loads of a panel chunk until no value
     is the sentinel) must hold when the chip is NOT idle -- the guide's rule for every inter-workgroup hand-off: test under
@@ -1273,8 +1308,11 @@ def test_persistent_sweeps_under_uneven_load(pkg):
     try:
         bad = 0
         for it in range(30):
-            mu = pkg.ldiv(F, rhs)
-            X = F.sample(16, mean=mu, seed=9, like=rhs)
+            if it % 3 == 2:
+                mu, X = F.posterior(rhs, 16, seed=9)       # (the samples' sweep beside the mean's two: three persistent launches in flight)
+            else:
+                mu = pkg.ldiv(F, rhs)
+                X = F.sample(16, mean=mu, seed=9, like=rhs)
             bad += int(not torch.equal(mu, mu0)) + int(not torch.equal(X, X0))
         st = F.stats()
     finally:
