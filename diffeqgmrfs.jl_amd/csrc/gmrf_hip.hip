@@ -1651,6 +1651,12 @@ static gmrf_status launch_sweep_persist(gmrf_handle* h, bool backward, int kp, d
     a.spin_limit = (unsigned)(limit_ms >= 0 ? limit_ms : 2000) * 100000u;
     static const int dbg = [] { const char* e = getenv("GMRF_SWEEP_DBG"); return e ? atoi(e) : 0; }();      // tuning aid
     a.dbg = dbg;
+    // Pause between two looks at an input that has not arrived: k = 1 looks again at once (8 units = 0.2 us; a longer pause only
+    // adds to every product: +0.28 us per 0.43 us measured).  The k >= 16 bodies look with 4 waves x 16 KB per workgroup, and
+    // their looks load the fabric the OTHER workgroups' stores and looks travel on: 64 units (1.7 us) -- darcy256's 64-sample
+    // sweep 0.96 -> 0.91 ms, and beside the mean's two sweeps (gmrf_bt_posterior) 1.52 -> 1.39 ms for the three; 128 units: 1.05 / 1.35.
+    static const int pause_env = [] { const char* e = getenv("GMRF_SWEEP_PAUSE"); return e ? atoi(e) : -1; }();      // tuning aid
+    a.pause = (kp == 1) ? 8 : (pause_env >= 0 ? pause_env : 64);
     const double N = (double)h->N, bsp = (double)h->bsp;
     const double work = (kp == 1) ? 8.0 * ((N - 1) * h->c_streamed + N * 0.5 * bsp * (bsp + 1))
                                   : kp * (2.0 * (N - 1) * h->c_streamed + N * bsp * (bsp + 1));

@@ -38,6 +38,7 @@ struct SweepArgs {
     unsigned* host_abort = nullptr;
     unsigned spin_limit = 0;
     int narrow = 0;                     // k = 1, transposed: 8-column blocks (one problem or a few, blocks of 512 .. 1024: launch_sweep)
+    int pause = 8;                      // clocks / 64 between two looks at an input that is not there yet (multiples of 8; sweep_persist sets it)
     int dbg = 0;                        // tuning aid (GMRF_SWEEP_DBG): 1 = the k = 1 flow bodies skip their matrix loads (garbage results: the pure hand-off time)
 };
 
@@ -98,7 +99,7 @@ struct SweepVec {
     // one more look has failed: false when the wait is over for good (abort).  The clock and the abort word are looked at every
     // 64th time only (either is a trip of its own through the scalar cache / the fabric, and nearly every wait fails once or twice)
     __device__ __forceinline__ bool again(unsigned& n, unsigned long long& t0) const {
-        __builtin_amdgcn_s_sleep(1);
+        for (int z = sa->pause; z > 0; z -= 8) __builtin_amdgcn_s_sleep(8);        // (s_sleep counts 64 clocks per unit, 8 units at a time)
         if ((++n & 63u) == 0u || sa->spin_limit == 0u) {           // (limit 0, tests: the first look that fails gives up)
             if (__hip_atomic_load(sa->abort_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
             const unsigned long long now = __builtin_amdgcn_s_memrealtime();

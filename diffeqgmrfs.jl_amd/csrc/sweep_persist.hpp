@@ -44,6 +44,7 @@ struct SweepPersistArgs {
     unsigned* abort_w;                       // device word
     unsigned* host_abort;                    // mapped host word (the host reads it without a copy)
     unsigned spin_limit;
+    int pause;                               // s_sleep units (64 clocks) between two looks at an input panel
     int dbg;
 };
 
@@ -94,7 +95,7 @@ __device__ __forceinline__ void sweep_gemv_n_flow(const SweepArgs& s, int vb, sp
     sw_v4u mv[NM];
 #pragma unroll
     for (int u = 0; u < NM; ++u) {
-        if (s.dbg) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
+        if (s.dbg & 1) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
         else if (u < nfull) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * 1024, 0);
         else if (u == nfull && tail) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * 1024, 0);
     }
@@ -142,7 +143,7 @@ __device__ __forceinline__ void sweep_gemv_t_flow(const SweepArgs& s, int cb, sp
     sw_v4u mv[NM];
 #pragma unroll
     for (int u = 0; u < NM; ++u) {
-        if (s.dbg) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
+        if (s.dbg & 1) mv[u] = (sw_v4u){0u, 0x3ff00000u, 0u, 0x3ff00000u};       // (tuning aid: no matrix loads, ones instead)
         else if (u < nfull) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * step, 0);
         else if (u == nfull && tail) mv[u] = __builtin_amdgcn_raw_buffer_load_b128(rm, voff, u * step, 0);
     }
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void sweep_persist(SweepPersistArgs a) {
         const int i = bw ? (a.N - 1 - step) : step;
         s.pMat = s.pXin = s.pBin = s.pOut = 0;
         s.ldx = s.ldb = s.ldo = a.npad;
-        s.abort_w = a.abort_w; s.host_abort = a.host_abort; s.spin_limit = a.spin_limit; s.dbg = a.dbg;
+        s.abort_w = a.abort_w; s.host_abort = a.host_abort; s.spin_limit = a.spin_limit; s.dbg = a.dbg; s.pause = a.pause;
         if (part == 0) {
             // forward: T_i = P_i - C_{i-1} y_{i-1};  backward: T_i = P_i - C_i^T x_{i+1}
             const int ci = bw ? i : (i - 1), prev = bw ? (i + 1) : (i - 1);
